@@ -1,0 +1,282 @@
+"""Generates the golden fixtures under tests/golden/ by importing the REAL reference
+(pycroscopy/atomai at /root/reference) in the dev container.  Run once here:
+
+    python oracle/make_golden.py [seg] [blocks] [config1] [predict] [vae]
+
+The reference's Python never travels to the GPU box; only these small .npz vectors do.
+Every network fixture is emitted twice: reference in fp32 and the same module ``.double()``'d,
+so each golden carries its own fp32 noise floor (SURVEY.md §7 "Parity budget").
+TEST INFRASTRUCTURE ONLY.
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def _np(d, suffix=""):
+    return {k + suffix: v.detach().cpu().numpy().copy() for k, v in d.items()}
+
+
+def _seg_case(aoi, name, model, nb_classes, nb_filters, B, H, seed, upsampling="bilinear",
+              with_dilation=False, steps=3):
+    from atomai.nets import init_fcnn_model
+    from atomai.losses_metrics import select_loss
+    from atomai.utils import set_train_rng
+    out = {}
+    rs = np.random.RandomState(seed + 100)
+    x = rs.rand(B, 1, H, H).astype(np.float32)
+    if nb_classes == 1:
+        y = (rs.rand(B, 1, H, H) > 0.5).astype(np.float32)
+    else:
+        y = rs.randint(0, nb_classes, (B, H, H)).astype(np.int64)
+    out["x"], out["y"] = x, y
+    kw = dict(nb_filters=nb_filters, upsampling=upsampling)
+    if model == "Unet":
+        kw["with_dilation"] = with_dilation
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        set_train_rng(seed)                                   # trainer.py:659-661
+        net, meta = init_fcnn_model(model, nb_classes, **kw)
+        if tag == "f32":
+            out.update(_np(net.state_dict(), "|init"))
+        net = net.to(dt)
+        crit = select_loss("ce", nb_classes)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        xt = torch.from_numpy(x).to(dt)
+        yt = torch.from_numpy(y) if nb_classes > 1 else torch.from_numpy(y).to(dt)
+        losses = []
+        for s in range(steps):
+            net.train()
+            opt.zero_grad()
+            logits = net(xt)
+            loss = crit(logits, yt)
+            loss.backward()
+            if s == 0:
+                out["logits|" + tag] = logits.detach().numpy()
+                out.update({k + "|grad|" + tag: p.grad.detach().numpy().copy()
+                            for k, p in net.named_parameters()})
+            opt.step()
+            losses.append(loss.item())
+            if s == 0:
+                out.update({k + "|bn1|" + tag: v.detach().numpy().copy()
+                            for k, v in net.state_dict().items() if "running" in k})
+        out["losses|" + tag] = np.array(losses)
+        out.update(_np(net.state_dict(), "|after|" + tag))
+        net.eval()
+        with torch.no_grad():
+            out["eval_logits|" + tag] = net(xt).numpy()
+    out["meta"] = np.array([nb_classes, nb_filters, B, H, seed, int(with_dilation)])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "losses f32", out["losses|f32"], "f64", out["losses|f64"])
+
+
+def make_seg(aoi):
+    _seg_case(aoi, "seg_unet_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1)
+    _seg_case(aoi, "seg_unet_c1_nf4_b2_16_nearest", "Unet", 1, 4, 2, 16, 2, upsampling="nearest")
+    _seg_case(aoi, "seg_unet_dil_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1, with_dilation=True)
+    _seg_case(aoi, "seg_dilnet_c1_nf5_b2_32", "dilnet", 1, 5, 2, 32, 1)
+    # default-width nets: pin the RNG-order initialisation by per-tensor moments only
+    from atomai.nets import init_fcnn_model
+    from atomai.utils import set_train_rng
+    out = {}
+    for model, ncls in (("Unet", 3), ("dilnet", 1)):
+        set_train_rng(1)
+        net, meta = init_fcnn_model(model, ncls)
+        for k, v in net.state_dict().items():
+            v = v.double()
+            out[f"{model}|{k}"] = np.array([v.numel(), v.sum().item(), (v * v).sum().item(),
+                                            v.flatten()[0].item(), v.flatten()[-1].item()])
+        out[f"{model}|nparams"] = np.array(sum(p.numel() for p in net.parameters()))
+    np.savez_compressed(os.path.join(GOLD, "seg_default_init_moments.npz"), **out)
+
+
+def make_blocks(aoi):
+    from atomai.nets.blocks import ConvBlock, UpsampleBlock, DilatedBlock
+    out = {}
+    torch.manual_seed(7)
+    rs = np.random.RandomState(7)
+    cases = {
+        "convblock_bn": (lambda: ConvBlock(2, 2, 6, 8, batch_norm=True), (2, 6, 12, 12)),
+        "convblock_nobn_a01": (lambda: ConvBlock(2, 2, 1, 8, lrelu_a=0.1), (2, 1, 12, 12)),
+        "up_bilinear": (lambda: UpsampleBlock(2, 8, 4, mode="bilinear"), (2, 8, 6, 10)),
+        "up_nearest": (lambda: UpsampleBlock(2, 8, 4, mode="nearest"), (2, 8, 6, 10)),
+        "dilated_bn": (lambda: DilatedBlock(2, 6, 8, [2, 4, 6], [2, 4, 6], batch_norm=True),
+                       (2, 6, 16, 16)),
+    }
+    for name, (ctor, shp) in cases.items():
+        m = ctor()
+        x = rs.randn(*shp).astype(np.float32)
+        gy = None
+        out[f"{name}|x"] = x
+        for k, v in m.state_dict().items():
+            out[f"{name}|sd|{k}"] = v.numpy().copy()
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            mm = copy.deepcopy(m).to(dt)
+            for mode in ("train", "eval"):
+                mm.train(mode == "train")
+                xt = torch.from_numpy(x).to(dt).requires_grad_(True)
+                y = mm(xt)
+                if gy is None:
+                    gy = rs.randn(*y.shape).astype(np.float32)
+                    out[f"{name}|gy"] = gy
+                mm.zero_grad()
+                y.backward(torch.from_numpy(gy).to(dt))
+                out[f"{name}|y|{mode}|{tag}"] = y.detach().numpy()
+                out[f"{name}|gx|{mode}|{tag}"] = xt.grad.numpy().copy()
+                for k, p in mm.named_parameters():
+                    out[f"{name}|gp|{k}|{mode}|{tag}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "seg_blocks.npz"), **out)
+    print("blocks:", len(out), "arrays")
+
+
+def make_config1(aoi):
+    """BASELINE.json configs[0]: Segmentor U-Net nb_classes=3, 8x(256x256), 10 cycles, CPU."""
+    rs = np.random.RandomState(0)
+    X = rs.rand(8, 256, 256).astype(np.float32)
+    y = rs.randint(0, 3, (8, 256, 256))
+    Xt = rs.rand(8, 256, 256).astype(np.float32)
+    yt = rs.randint(0, 3, (8, 256, 256))
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        m = aoi.models.Segmentor(nb_classes=3)
+        m.fit(X, y, Xt, yt, training_cycles=10, batch_size=8, plot_training_history=False)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "seg_config1_losses.npz"),
+                        train_loss=np.array(m.loss_acc["train_loss"]),
+                        test_loss=np.array(m.loss_acc["test_loss"]),
+                        batch_idx_train=np.array(m.batch_idx_train),
+                        batch_idx_test=np.array(m.batch_idx_test))
+    print("config1 train", m.loss_acc["train_loss"])
+
+
+def make_predict(aoi):
+    from atomai.utils import img_pad, torch_format_image
+    from atomai.nets import init_fcnn_model
+    from atomai.utils import set_train_rng
+    from atomai.predictors import SegPredictor
+    out = {}
+    rs = np.random.RandomState(3)
+    img = (rs.rand(3, 13, 18) * 7 - 2).astype(np.float32)
+    out["img"] = img
+    for f in (2, 8):
+        out[f"pad{f}"] = img_pad(img.copy(), f)
+        out[f"fmt{f}"] = torch_format_image(img_pad(img.copy(), f)).numpy()
+    for model, ncls, nf in (("Unet", 3, 4), ("dilnet", 1, 5)):
+        set_train_rng(1)
+        net, _ = init_fcnn_model(model, ncls, nb_filters=nf)
+        # make running stats non-trivial so eval-mode BN is actually exercised
+        net.train()
+        with torch.no_grad():
+            for _ in range(2):
+                net(torch.from_numpy(rs.rand(2, 1, 16, 24).astype(np.float32)))
+        for k, v in net.state_dict().items():
+            out[f"{model}|sd|{k}"] = v.numpy().copy()
+        p = SegPredictor(net, use_gpu=False, nb_classes=ncls,
+                         downsampling=8 if model == "Unet" else 2, verbose=False)
+        out[f"{model}|probs"] = p.run(img, compute_coords=False, num_batches=2)
+    np.savez_compressed(os.path.join(GOLD, "seg_predict.npz"), **out)
+    print("predict ok", out["Unet|probs"].shape, out["dilnet|probs"].shape)
+
+
+def make_vae(aoi):
+    from atomai.utils import set_train_rng
+    from atomai.utils.coords import imcoordgrid, transform_coordinates
+    from atomai.losses_metrics import rvae_loss, vae_loss
+    out = {}
+    rs = np.random.RandomState(5)
+    out["grid_7x5"] = imcoordgrid((7, 5)).numpy()
+    out["grid_16x16"] = imcoordgrid((16, 16)).numpy()
+    phi = torch.from_numpy(rs.randn(3).astype(np.float32))
+    dx = torch.from_numpy(rs.randn(3, 1, 2).astype(np.float32) * 0.1)
+    g = imcoordgrid((7, 5)).expand(3, 35, 2)
+    out["tc_phi"], out["tc_dx"] = phi.numpy(), dx.numpy()
+    out["tc_out"] = transform_coordinates(g, phi, dx).numpy()
+
+    def run(name, ctor, fit_kw, in_dim, B, steps=3, inject=True):
+        x = rs.rand(B, *in_dim).astype(np.float32)
+        eps_all = rs.randn(steps, B, 8).astype(np.float32)
+        out[f"{name}|x"], out[f"{name}|eps"] = x, eps_all
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            m = ctor()
+            if tag == "f32":
+                for k, v in m.encoder_net.state_dict().items():
+                    out[f"{name}|enc|{k}"] = v.numpy().copy()
+                for k, v in m.decoder_net.state_dict().items():
+                    out[f"{name}|dec|{k}"] = v.numpy().copy()
+            m.encoder_net.to(dt), m.decoder_net.to(dt)
+            if hasattr(m, "x_coord"):
+                m.x_coord = m.x_coord.to(dt)
+            m.kdict_.update(fit_kw)
+            if "rotation_prior" in fit_kw:
+                m.phi_prior = fit_kw["rotation_prior"]
+            m.loss = "mse"
+            m.compile_trainer((x, None), None, batch_size=B)
+            state = {"i": 0}
+
+            def reparam(z_mean, z_sd, st=state, e=eps_all, d=dt):
+                ee = torch.from_numpy(e[st["i"]][:, :z_mean.shape[1]]).to(d)
+                return z_mean + z_sd * ee
+            m.reparameterize = reparam
+            xt = torch.from_numpy(x).to(dt)
+            elbos = []
+            for s in range(steps):
+                state["i"] = s
+                m.encoder_net.train(), m.decoder_net.train()
+                m.optim.zero_grad()
+                elbo = m.forward_compute_elbo(xt)
+                (-elbo).backward()
+                if s == 0:
+                    for k, p in m.encoder_net.named_parameters():
+                        out[f"{name}|genc|{k}|{tag}"] = p.grad.numpy().copy()
+                    for k, p in m.decoder_net.named_parameters():
+                        out[f"{name}|gdec|{k}|{tag}"] = p.grad.numpy().copy()
+                m.optim.step()
+                elbos.append(elbo.item())
+            out[f"{name}|elbo|{tag}"] = np.array(elbos)
+            for k, v in m.encoder_net.state_dict().items():
+                out[f"{name}|enc_after|{k}|{tag}"] = v.numpy().copy()
+            for k, v in m.decoder_net.state_dict().items():
+                out[f"{name}|dec_after|{k}|{tag}"] = v.numpy().copy()
+            # encode / decode (eval) with the trained nets
+            with torch.no_grad():
+                zm, zs = m.encoder_net(xt)
+            out[f"{name}|zmean|{tag}"], out[f"{name}|zlogsd|{tag}"] = zm.numpy(), zs.numpy()
+        print(name, "elbo f32", out[f"{name}|elbo|f32"], "f64", out[f"{name}|elbo|f64"])
+
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        run("rvae16", lambda: aoi.models.rVAE((16, 16), latent_dim=2, seed=0,
+                                              numhidden_encoder=32, numhidden_decoder=32),
+            dict(), (16, 16), 6)
+        run("rvae16_cap", lambda: aoi.models.rVAE((16, 16), latent_dim=2, seed=0,
+                                                  numhidden_encoder=32, numhidden_decoder=32,
+                                                  translation=False, skip=True),
+            dict(capacity=[5.0, 100, 2.0]), (16, 16), 4)
+        run("vae16", lambda: aoi.models.VAE((16, 16), latent_dim=2, seed=0,
+                                            numhidden_encoder=32, numhidden_decoder=32),
+            dict(), (16, 16), 6)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "vae.npz"), **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae"]
+    aoi = ref_harness.import_reference()
+    torch.set_num_threads(8)
+    for w in what:
+        {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
+         "predict": make_predict, "vae": make_vae}[w](aoi)
+    print("done ->", GOLD)
