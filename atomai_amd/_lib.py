@@ -1,0 +1,95 @@
+"""ctypes binding of the C-ABI shared library (include/atomai_amd.h).
+
+The product library is ``atomai_amd/lib/libatomai_amd.so`` built by ``__graft_entry__.build()``
+with ``hipcc --offload-arch=gfx950``.  It is loaded AFTER torch so that it binds to the HIP runtime
+torch already mapped (one ``libamdhip64`` per process, SURVEY.md §7 "Runtime-linking trap").
+There is no CPU fallback: if the library is missing, or a tensor is not on a GPU, the ops raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libatomai_amd.so")
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_long
+_D = C.c_double
+
+# name -> (restype, argtypes).  Must mirror include/atomai_amd.h exactly.
+SIGNATURES = {
+    "amx_conv2d_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P,
+                            _I, _I, _I, _I, _I, _I, _F, _P]),
+    "amx_conv2d_num_tiles": (_I, [_I, _I, _I]),
+    "amx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "amx_pack_weights_size": (_L, [_I, _I, _I, _I, _I]),
+    "amx_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "amx_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+}
+
+_lib = None
+_is_test_backend = False
+
+
+class AmxError(RuntimeError):
+    pass
+
+
+def _bind(cdll):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)          # AttributeError -> symbol missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def load(path: str = None):
+    """Loads (once) and returns the product library."""
+    global _lib
+    if _lib is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise AmxError(
+                f"{path} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+        _lib = _bind(C.CDLL(path))
+    return _lib
+
+
+def _inject_for_tests(cdll) -> None:
+    """TEST HOOK: tests/emu injects the CPU-emulated build of the same kernel sources so that the
+    host logic can be exercised without a GPU.  Never called by the package itself."""
+    global _lib, _is_test_backend
+    _lib = _bind(cdll)
+    _is_test_backend = True
+
+
+def is_test_backend() -> bool:
+    return _is_test_backend
+
+
+def stream_ptr(t: torch.Tensor):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if not _is_test_backend:
+        raise AmxError("atomai_amd ops need tensors on an MI355X (cuda) device; got a CPU tensor "
+                       "and there is no CPU fallback")
+    return C.c_void_p(0)
+
+
+def ptr(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "atomai_amd kernels need contiguous tensors"
+    assert t.dtype in (torch.float32, torch.int64, torch.uint8, torch.int32, torch.float64)
+    return C.c_void_p(t.data_ptr())
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise AmxError(f"{name} failed with code {rc} "
+                       f"({'bad argument #%d' % -rc if rc < 0 else 'hipError_t'})")

@@ -1,0 +1,33 @@
+// amx_device.h — device prelude shared by every kernel source in atomai_amd/csrc.
+//
+// Product build:  hipcc --offload-arch=gfx950 (MI355X / CDNA4 only; 64-wide wavefronts).
+// Test build:     g++ -DAMX_EMU -include tests/emu/hip_emu.h  (CPU SIMT emulator, `not gpu` tests only).
+#pragma once
+#ifdef AMX_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define AMX_DYN_SMEM(type, name)                                      \
+    extern __shared__ __attribute__((aligned(16))) char name##_raw[]; \
+    type* name = reinterpret_cast<type*>(name##_raw)
+#define AMX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+#endif
+#include <cstdint>
+
+#define AMX_WAVE 64
+
+// Error convention of the C ABI (include/atomai_amd.h): 0 = ok, >0 = hipError_t, <0 = bad argument.
+#define AMX_BADARG(code) return -(code)
+#define AMX_CHECK_LAUNCH()                    \
+    do {                                      \
+        hipError_t e__ = hipGetLastError();   \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static __device__ __forceinline__ void amx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+static __host__ __device__ __forceinline__ int amx_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static __host__ __device__ __forceinline__ int amx_round_up(int a, int b) { return (a + b - 1) / b * b; }

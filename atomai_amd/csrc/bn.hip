@@ -1,0 +1,316 @@
+// bn.hip — BatchNorm2d (after LeakyReLU, reference order conv -> lrelu -> BN, atomai/nets/blocks.py:61-76)
+// split into the pieces the fused pipeline needs.  All HBM-bound; NHWC float4 accesses.
+//
+//   amx_bn_finalize        partial (sum, M2) rows from the conv epilogue -> batch mean / biased var
+//                          (fp64 Chan merge) -> scale = g*invstd, shift = b - mean*scale for the
+//                          CONSUMER to apply on load; running stats updated with torch semantics
+//                          (momentum 0.1, unbiased running_var).
+//   amx_bn_eval_affine     eval mode: scale/shift from running statistics.
+//   amx_affine_nhwc        materialises y = a*scale + shift (module-boundary outputs only).
+//   amx_bn_bwd_reduce      per-channel sum(dy), sum(dy*a) partial rows.
+//   amx_bn_bwd_finalize    -> dgamma, dbeta and the three per-channel constants of
+//                          da = k1*dy + k2*a + k3  (batch-norm backward is affine in dy and a).
+//   amx_bn_bwd_apply       dpre = lrelu'(a) * (k1*dy + k2*a + k3) [+ extra terms for DilatedBlock],
+//                          plus per-channel partial sums of dpre (= conv bias gradient).
+//   amx_reduce_rows        deterministic column sum of partial rows (fp64 accumulate).
+#include "amx_device.h"
+
+// Thread mapping shared by the per-channel reductions over an NHWC tensor: G = Cs/4 channel groups,
+// PL = 256/G pixel lanes.  thread -> (pl = tid / G, cg = tid % G), idle if pl >= PL.
+struct PixMap {
+    int G, PL, pl, cg;
+    bool active;
+    __device__ PixMap(int Cs, int tid) {
+        G = Cs >> 2; PL = 256 / G; pl = tid / G; cg = tid - pl * G; active = pl < PL;
+    }
+};
+
+// ------------------------------------------------------------------ finalize (training)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, float momentum, float eps, int C, int Cs, float* scale, float* shift,
+    float* save_mean, float* save_invstd) {
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double red[256];
+    if (c >= C) {                      // padded channels: normalised value is exactly 0
+        if (tid == 0) { scale[c] = 0.f; shift[c] = 0.f; save_mean[c] = 0.f; save_invstd[c] = 0.f; }
+        return;
+    }
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const long P = (long)N * H * W;
+    auto row_count = [&](int r) -> double {
+        if (mode == 0) {
+            const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
+            const int vx = min(16, W - tx * 16), vy = min(16, H - ty * 16);
+            return (double)(vx * vy);
+        }
+        const long left = P - (long)r * rows_pix;
+        return (double)(left < rows_pix ? left : rows_pix);
+    };
+    double s = 0.0;
+    for (int r = tid; r < rows; r += 256) s += (double)stats[((size_t)r * 2) * cop + c];
+    red[tid] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const double mean = red[0] / (double)P;
+    __syncthreads();
+    double m2 = 0.0;
+    for (int r = tid; r < rows; r += 256) {
+        const double n = row_count(r);
+        const double mi = (double)stats[((size_t)r * 2) * cop + c] / n;
+        m2 += (double)stats[((size_t)r * 2 + 1) * cop + c] + n * (mi - mean) * (mi - mean);
+    }
+    red[tid] = m2; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) {
+        const double var = red[0] / (double)P;                 // biased: used for normalisation
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)((double)gamma[c] * invstd);
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);
+        save_mean[c] = (float)mean;
+        save_invstd[c] = (float)invstd;
+        if (running_mean) {
+            const double unb = P > 1 ? red[0] / (double)(P - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+        }
+    }
+}
+
+extern "C" int amx_bn_finalize(const float* stats, int rows, int cop, int mode, int N, int H, int W,
+                               int rows_pix, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               int C, int Cs, float* scale, float* shift, float* save_mean,
+                               float* save_invstd, void* stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd) AMX_BADARG(1);
+    if (rows <= 0 || C <= 0 || Cs < C || cop < C) AMX_BADARG(2);
+    if (mode != 0 && (mode != 1 || rows_pix <= 0)) AMX_BADARG(3);
+    AMX_LAUNCH(bn_finalize_kernel, dim3(Cs), dim3(256), 0, (hipStream_t)stream, stats, rows, cop, mode,
+               N, H, W, rows_pix, gamma, beta, running_mean, running_var, momentum, eps, C, Cs, scale,
+               shift, save_mean, save_invstd);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ eval-mode affine
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, int C, int Cs, float* scale,
+                                      float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Cs) return;
+    if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; return; }
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * inv;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+extern "C" int amx_bn_eval_affine(const float* gamma, const float* beta, const float* rm,
+                                  const float* rv, float eps, int C, int Cs, float* scale, float* shift,
+                                  void* stream) {
+    if (!gamma || !beta || !rm || !rv || !scale || !shift || C <= 0 || Cs < C) AMX_BADARG(1);
+    AMX_LAUNCH(bn_eval_affine_kernel, dim3(amx_ceil_div(Cs, 64)), dim3(64), 0, (hipStream_t)stream,
+               gamma, beta, rm, rv, eps, C, Cs, scale, shift);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ y = a*scale + shift
+__global__ void affine_nhwc_kernel(const float* __restrict__ a, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ y, size_t n4,
+                                   int G) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        float4 v = amx_ld4(a + i * 4);
+        const float4 sc = amx_ld4(scale + cg * 4), sh = amx_ld4(shift + cg * 4);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        amx_st4(y + i * 4, v);
+    }
+}
+
+extern "C" int amx_affine_nhwc(const float* a, const float* scale, const float* shift, float* y,
+                               long npix, int Cs, void* stream) {
+    if (!a || !scale || !shift || !y || (Cs & 3) || Cs <= 0) AMX_BADARG(1);
+    const size_t n4 = (size_t)npix * (Cs / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    AMX_LAUNCH(affine_nhwc_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a,
+               scale, shift, y, n4, Cs / 4);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward: reductions
+// rows: block b covers pixels [b*ppb, (b+1)*ppb); writes part[b][0][Cs] = sum dy, part[b][1][Cs] = sum dy*a
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ a, long npix,
+                                                            int Cs, int ppb, float* __restrict__ part) {
+    const int tid = threadIdx.x;
+    PixMap m(Cs, tid);
+    AMX_DYN_SMEM(float, s);                       // [2][PL][Cs]
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    if (m.active)
+        for (long p = p0 + m.pl; p < p1; p += m.PL) {
+            const float4 g = amx_ld4(dy + (size_t)p * Cs + m.cg * 4);
+            const float4 v = amx_ld4(a + (size_t)p * Cs + m.cg * 4);
+            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+            s2.x = fmaf(g.x, v.x, s2.x); s2.y = fmaf(g.y, v.y, s2.y);
+            s2.z = fmaf(g.z, v.z, s2.z); s2.w = fmaf(g.w, v.w, s2.w);
+        }
+    if (m.active) {
+        amx_st4(s + ((size_t)m.pl * Cs + m.cg * 4), s1);
+        amx_st4(s + ((size_t)(m.PL + m.pl) * Cs + m.cg * 4), s2);
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * Cs; c += 256) {
+        const int which = c / Cs, ch = c - which * Cs;
+        float acc = 0.f;
+        for (int q = 0; q < m.PL; ++q) acc += s[(size_t)(which * m.PL + q) * Cs + ch];
+        part[((size_t)blockIdx.x * 2 + which) * Cs + ch] = acc;
+    }
+}
+
+static inline int pick_ppb(long npix, int* nblk) {
+    int ppb = 1024;
+    long nb = (npix + ppb - 1) / ppb;
+    while (nb > 4096) { ppb *= 2; nb = (npix + ppb - 1) / ppb; }
+    *nblk = (int)nb;
+    return ppb;
+}
+
+extern "C" int amx_rows_for(long npix) { int nb; pick_ppb(npix, &nb); return nb; }
+extern "C" int amx_rows_pix(long npix) { int nb; return pick_ppb(npix, &nb); }
+
+extern "C" int amx_bn_bwd_reduce(const float* dy, const float* a, long npix, int Cs, float* part,
+                                 void* stream) {
+    if (!dy || !a || !part || (Cs & 3) || Cs <= 0 || Cs > 1024 || npix <= 0) AMX_BADARG(1);
+    int nblk; const int ppb = pick_ppb(npix, &nblk);
+    const int PL = 256 / (Cs / 4);
+    AMX_LAUNCH(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), (size_t)2 * PL * Cs * sizeof(float),
+               (hipStream_t)stream, dy, a, npix, Cs, ppb, part);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ part, int rows, int Cs, int C, double inv_n,
+    const float* __restrict__ gamma, const float* __restrict__ save_mean,
+    const float* __restrict__ save_invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ double r1[256], r2[256];
+    if (c >= C) { if (tid == 0) { k1[c] = 0.f; k2[c] = 0.f; k3[c] = 0.f; } return; }
+    double a1 = 0.0, a2 = 0.0;
+    for (int r = tid; r < rows; r += 256) {
+        a1 += (double)part[((size_t)r * 2) * Cs + c];
+        a2 += (double)part[((size_t)r * 2 + 1) * Cs + c];
+    }
+    r1[tid] = a1; r2[tid] = a2; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { r1[tid] += r1[tid + o]; r2[tid] += r2[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double sdy = r1[0], sdya = r2[0];
+        const double mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
+        const double dg = invstd * (sdya - mean * sdy);
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)sdy;
+        k1[c] = (float)(g * invstd);
+        k2[c] = (float)(-g * invstd * invstd * dg * inv_n);
+        k3[c] = (float)(-g * invstd * sdy * inv_n + g * invstd * invstd * mean * dg * inv_n);
+    }
+}
+
+extern "C" int amx_bn_bwd_finalize(const float* part, int rows, int Cs, int C, long npix,
+                                   const float* gamma, const float* save_mean,
+                                   const float* save_invstd, float* dgamma, float* dbeta, float* k1,
+                                   float* k2, float* k3, void* stream) {
+    if (!part || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !k1 || !k2 || !k3)
+        AMX_BADARG(1);
+    AMX_LAUNCH(bn_bwd_finalize_kernel, dim3(Cs), dim3(256), 0, (hipStream_t)stream, part, rows, Cs, C,
+               1.0 / (double)npix, gamma, save_mean, save_invstd, dgamma, dbeta, k1, k2, k3);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward: apply
+// dpre = gx + lrelu'(a) * (gx + k1*dy + k2*a + k3)      (gx == 0 unless DilatedBlock, blocks.py:321-329)
+// k1/k2/k3 may be null (no BatchNorm): dpre = gx + lrelu'(a) * (gx + dy).
+// part[b][Cs] = per-block sum of dpre (conv bias gradient).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ gx,
+    const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
+    float slope, long npix, int Cs, int ppb, float* __restrict__ dpre, float* __restrict__ part) {
+    const int tid = threadIdx.x;
+    PixMap m(Cs, tid);
+    AMX_DYN_SMEM(float, s);                       // [PL][Cs]
+    float4 sb = make_float4(0, 0, 0, 0);
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    if (m.active) {
+        float4 c1 = make_float4(1, 1, 1, 1), c2 = make_float4(0, 0, 0, 0), c3 = c2;
+        if (k1) { c1 = amx_ld4(k1 + m.cg * 4); c2 = amx_ld4(k2 + m.cg * 4); c3 = amx_ld4(k3 + m.cg * 4); }
+        for (long p = p0 + m.pl; p < p1; p += m.PL) {
+            const size_t o = (size_t)p * Cs + m.cg * 4;
+            const float4 g = amx_ld4(dy + o);
+            const float4 v = amx_ld4(a + o);
+            float4 e = make_float4(0, 0, 0, 0);
+            if (gx) e = amx_ld4(gx + o);
+            float4 d;
+            d.x = e.x + (v.x > 0.f ? 1.f : slope) * (e.x + fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)));
+            d.y = e.y + (v.y > 0.f ? 1.f : slope) * (e.y + fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y)));
+            d.z = e.z + (v.z > 0.f ? 1.f : slope) * (e.z + fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)));
+            d.w = e.w + (v.w > 0.f ? 1.f : slope) * (e.w + fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w)));
+            amx_st4(dpre + o, d);
+            sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+        }
+        amx_st4(s + ((size_t)m.pl * Cs + m.cg * 4), sb);
+    }
+    __syncthreads();
+    if (part)
+        for (int c = tid; c < Cs; c += 256) {
+            float acc = 0.f;
+            for (int q = 0; q < m.PL; ++q) acc += s[(size_t)q * Cs + c];
+            part[(size_t)blockIdx.x * Cs + c] = acc;
+        }
+}
+
+extern "C" int amx_bn_bwd_apply(const float* dy, const float* a, const float* gx, const float* k1,
+                                const float* k2, const float* k3, float slope, long npix, int Cs,
+                                float* dpre, float* part, void* stream) {
+    if (!dy || !a || !dpre || (Cs & 3) || Cs <= 0 || Cs > 1024 || npix <= 0) AMX_BADARG(1);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(2);
+    int nblk; const int ppb = pick_ppb(npix, &nblk);
+    const int PL = 256 / (Cs / 4);
+    AMX_LAUNCH(bn_bwd_apply_kernel, dim3(nblk), dim3(256), (size_t)PL * Cs * sizeof(float),
+               (hipStream_t)stream, dy, a, gx, k1, k2, k3, slope, npix, Cs, ppb, dpre, part);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ out[c] = sum_r part[r][c] (c < C)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, int rows,
+                                                          int stride, int C, float scale,
+                                                          float* __restrict__ out) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int r = tid; r < rows; r += 256) a += (double)part[(size_t)r * stride + c];
+    red[tid] = a; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) out[c] = (float)(red[0] * (double)scale);
+}
+
+extern "C" int amx_reduce_rows(const float* part, int rows, int stride, int C, float scale, float* out,
+                               void* stream) {
+    if (!part || !out || rows <= 0 || C <= 0 || stride < C) AMX_BADARG(1);
+    AMX_LAUNCH(reduce_rows_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, rows, stride, C,
+               scale, out);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

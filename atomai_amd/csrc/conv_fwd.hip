@@ -1,0 +1,332 @@
+// conv_fwd.hip — NHWC direct (im2col-free) 3x3 / dilated-3x3 / 1x1 convolution on fp32 MFMA,
+// fused with: BatchNorm-affine-on-load of up to two concatenated sources, bias, LeakyReLU and the
+// per-channel batch statistics (sum, M2) of the post-activation tensor.
+//
+// Replaces, on the hot path of the reference (all ATen calls):
+//   nn.Conv2d k3 s1 p=d dil=d (+bias)  -> LeakyReLU -> [BatchNorm2d statistics]      atomai/nets/blocks.py:61-76, 300-318
+//   torch.cat([skip, up], dim=1) feeding a conv                                      atomai/nets/fcnn.py:132-138, 223
+//   BatchNorm2d normalisation of the *previous* layer (applied here, on load)        atomai/nets/blocks.py:71-75
+//   nn.Conv2d 1x1 of UpsampleBlock (evaluated at low resolution, it commutes)        atomai/nets/blocks.py:122-132
+// The same kernel is the data-gradient (dgrad) engine: a 3x3 dgrad is a 3x3 forward conv with
+// spatially flipped, in/out-transposed weights (pack.hip builds that weight image); its two
+// concatenated *outputs* (skip / upsampled halves) are written through `y` + `y1`.
+//
+// Mapping to CDNA4 (gfx950):
+//   * implicit GEMM  M = 16x16 output pixels per workgroup, N = 16*NT output channels,
+//     K = taps x 16-channel chunks.  One wave owns 4 image rows x NT channel tiles and issues
+//     v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles): A[pixel][k], B[k][cout].
+//   * LDS operand images are laid out so that every fragment is ONE conflict-free ds_read_b128:
+//       input  tile  [kgroup][pixel slot][4 channels]   (plane stride == 0 mod 16 slots)
+//       weight tile  [tap][kgroup][cout][4 channels]
+//     a lane (p = lane&15, g = lane>>4) reads 4 consecutive channels 4g..4g+3 of pixel/cout p and
+//     feeds them to 4 consecutive MFMAs, so each MFMA contracts channels {kk, 4+kk, 8+kk, 12+kk}.
+//   * global->register prefetch of chunk c+1 is issued before the MFMA phase of chunk c; the
+//     BN affine and the zero padding are applied when registers are written to LDS (padding must
+//     stay zero AFTER the affine, so it cannot be folded into the weights).
+//   * epilogue: bias + LeakyReLU on the accumulators, NHWC store (64 B runs per pixel), then a
+//     two-pass (mean, M2) reduction per workgroup: wave shuffles -> LDS -> one partial row per
+//     tile; bn.hip merges the rows with Chan's formula in fp64 (deterministic, no atomics).
+#include "amx_device.h"
+
+#define TILE 16          // output tile is TILE x TILE pixels
+#define KG 4             // k-groups (of 4 channels) per chunk -> 16 channels per chunk
+
+struct ConvFwdArgs {
+    const float* x0; const float* sc0; const float* sh0; int C0s;
+    const float* x1; const float* sc1; const float* sh1; int C1s;
+    const float* wpk;    // [nchunk][taps][KG][cop][4]
+    const float* bias;   // [cop] or nullptr
+    const float* addend; // optional tensor (same shape as y) added to the first output, or nullptr
+    float* y;  int Y0s;  // first  output: stored channels Y0s, receives couts [0, Y0s)
+    float* y1; int Y1s;  // second output (dgrad of a concat) receives couts [Y0s, Y0s+Y1s), or nullptr
+    float* stats;        // [tiles][2][cop] (sum, M2) or nullptr
+    int N, H, W;
+    int cop;             // Cout rounded up to 16
+    int nchunk;
+    int dil;             // dilation (== halo) for 9 taps; ignored for 1 tap
+    float slope;         // LeakyReLU negative slope; 1.0f == no activation
+    int tiles_x, tiles_y;
+};
+
+template <int TAPS, int NT, int MAXHALO>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+    constexpr int NB = NT * 16;
+    constexpr int MAXI = TILE + 2 * MAXHALO;
+    constexpr int XLD = (MAXI * MAXI * KG + 255) / 256;          // float4 loads per thread (input)
+    constexpr int WLD = (TAPS * KG * NB + 255) / 256;            // float4 loads per thread (weights)
+    AMX_DYN_SMEM(float, smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int IW = TILE + 2 * halo, IH = IW;
+    const int plane = amx_round_up(IH * IW, 16);                 // slots (16 B) per k-group plane
+    float* s_in = smem;                                          // [KG][plane][4]
+    float* s_w = smem + KG * plane * 4;                          // [TAPS][KG][NB][4]
+    float* s_red = s_w;                                          // reused after the K loop
+
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
+    const int n0 = blockIdx.y * NB;                              // first cout of this workgroup
+    const int gy0 = ty * TILE - halo, gx0 = tx * TILE - halo;
+
+    // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
+    const int my_kg = tid & (KG - 1);
+    const int nslots = IH * IW;
+    int x_off[XLD];                                              // pixel offset ((n*H+y)*W+x) or -1
+    #pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+        const int pix = (tid + i * 256) >> 2;
+        int off = -1;
+        if (pix < nslots) {
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) off = (n * a.H + gy) * a.W + gx;
+        }
+        x_off[i] = off;
+    }
+
+    float4 xr[XLD];
+    float4 wr[WLD];
+    float4 r_sc, r_sh;
+
+    auto issue_loads = [&](int chunk) {
+        const int ch = (chunk * KG + my_kg) * 4;                 // channel in the concatenated space
+        const float* src = nullptr; const float* sc = nullptr; const float* sh = nullptr;
+        int Cs = 0, c = 0;
+        if (ch < a.C0s) { src = a.x0; sc = a.sc0; sh = a.sh0; Cs = a.C0s; c = ch; }
+        else if (ch - a.C0s < a.C1s) { src = a.x1; sc = a.sc1; sh = a.sh1; Cs = a.C1s; c = ch - a.C0s; }
+        r_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
+        }
+        const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
+        #pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int idx = tid + i * 256;                       // over [TAPS*KG][NB]
+            wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TAPS * KG * NB) {
+                const int row = idx / NB, col = idx - row * NB;
+                if (n0 + col < a.cop) wr[i] = amx_ld4(wsrc + ((size_t)row * a.cop + n0 + col) * 4);
+            }
+        }
+    };
+
+    auto stage_to_lds = [&]() {
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            const int pix = (tid + i * 256) >> 2;
+            if (pix < nslots) {
+                float4 v = xr[i];
+                if (x_off[i] >= 0) {                             // padding stays exactly zero
+                    v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
+                    v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                }
+                amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < TAPS * KG * NB) amx_st4(s_w + (size_t)idx * 4, wr[i]);
+        }
+    };
+
+    f32x4 acc[4][NT];
+    #pragma unroll
+    for (int m = 0; m < 4; ++m)
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        stage_to_lds();
+        __syncthreads();
+        if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
+
+        #pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            float4 af[4], bf[NT];
+            #pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int slot = (wave * 4 + m + halo + dy) * IW + (p + halo + dx);
+                af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
+            }
+            #pragma unroll
+            for (int q = 0; q < NT; ++q)
+                bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+            #pragma unroll
+            for (int m = 0; m < 4; ++m)
+                #pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf[q].x, acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bf[q].y, acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bf[q].z, acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf[q].w, acc[m][q], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + LeakyReLU (+addend), store, statistics ----
+    // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
+    const int oy0 = ty * TILE + wave * 4, ox0 = tx * TILE + 4 * g;
+    const int ctot = a.Y0s + a.Y1s;
+    float lsum[NT];
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int co = n0 + q * 16 + p;
+        const float b = (a.bias && co < a.cop) ? a.bias[co] : 0.f;
+        float* dst = nullptr; int Cd = 0, cd = 0;
+        if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; }
+        else if (co < ctot) { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
+        lsum[q] = 0.f;
+        #pragma unroll
+        for (int m = 0; m < 4; ++m)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + m, ox = ox0 + r;
+                float v = acc[m][q][r] + b;
+                v = v > 0.f ? v : v * a.slope;
+                const bool ok = (oy < a.H) && (ox < a.W) && dst;
+                if (ok) {
+                    const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
+                    if (a.addend && dst == a.y) v += a.addend[o];
+                    dst[o] = v;
+                    lsum[q] += v;
+                } else {
+                    v = 0.f;
+                }
+                acc[m][q][r] = v;
+            }
+    }
+    if (!a.stats) return;
+
+    const int vy = min(TILE, a.H - ty * TILE), vx = min(TILE, a.W - tx * TILE);
+    const float inv_cnt = 1.0f / (float)(vy * vx);
+    // pass 1: per-cout sum over the tile -> mean
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        float s = lsum[q];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        if (g == 0) s_red[wave * NB + q * 16 + p] = s;
+    }
+    __syncthreads();
+    float mean[NT];
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int c = q * 16 + p;
+        mean[q] = (s_red[c] + s_red[NB + c] + s_red[2 * NB + c] + s_red[3 * NB + c]);
+    }
+    __syncthreads();
+    // pass 2: M2 about the tile mean
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const float mu = mean[q] * inv_cnt;
+        float s2 = 0.f;
+        #pragma unroll
+        for (int m = 0; m < 4; ++m)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
+                const float d = acc[m][q][r] - mu;
+                s2 += ok ? d * d : 0.f;
+            }
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        if (g == 0) s_red[wave * NB + q * 16 + p] = s2;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const int co = n0 + tid;
+        if (co < a.cop) {
+            const float m2 = s_red[tid] + s_red[NB + tid] + s_red[2 * NB + tid] + s_red[3 * NB + tid];
+            a.stats[((size_t)blockIdx.x * 2 + 1) * a.cop + co] = m2;
+        }
+    }
+    // tile sums: every lane holds mean[q] (= tile sum) for column q*16+p; 16 lanes of wave 0 write them
+    if (wave == 0 && g == 0) {
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int co = n0 + q * 16 + p;
+            if (co < a.cop) a.stats[(size_t)blockIdx.x * 2 * a.cop + co] = mean[q];
+        }
+    }
+}
+
+template <int TAPS, int NT, int MAXHALO>
+static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
+    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int I = TILE + 2 * halo;
+    const int plane = amx_round_up(I * I, 16);
+    size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
+    if (lds_w < (size_t)4 * NT * 16 * sizeof(float)) lds_w = (size_t)4 * NT * 16 * sizeof(float);
+    const size_t lds = (size_t)KG * plane * 4 * sizeof(float) + lds_w;
+    dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
+#ifndef AMX_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+#endif
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO>), grid, dim3(256), lds, stream, a);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// C ABI — see include/atomai_amd.h for the contract.
+extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
+                              const float* x1, const float* sc1, const float* sh1, int C1s,
+                              const float* wpk, const float* bias, const float* addend,
+                              float* y, int Y0s, float* y1, int Y1s, float* stats,
+                              int N, int H, int W, int cout, int taps, int dil, float slope,
+                              void* stream) {
+    if (!x0 || !wpk || !y) AMX_BADARG(1);
+    if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
+    if ((C0s & 3) || (C1s & 3) || (Y0s & 3) || (Y1s & 3) || C0s <= 0) AMX_BADARG(3);
+    if (taps != 1 && taps != 9) AMX_BADARG(4);
+    if (taps == 9 && (dil < 1 || dil > 6)) AMX_BADARG(5);
+    if ((x1 == nullptr) != (C1s == 0)) AMX_BADARG(6);
+    if ((y1 == nullptr) != (Y1s == 0)) AMX_BADARG(7);
+    ConvFwdArgs a;
+    a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
+    a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
+    a.wpk = wpk; a.bias = bias; a.addend = addend;
+    a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
+    a.N = N; a.H = H; a.W = W;
+    a.cop = amx_round_up(cout, 16);
+    a.nchunk = amx_ceil_div(C0s + C1s, 4 * KG);
+    a.dil = dil; a.slope = slope;
+    a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, TILE);
+    if (Y0s + Y1s < cout) AMX_BADARG(8);
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = a.cop >= 64 ? 4 : (a.cop > 32 ? 4 : (a.cop > 16 ? 2 : 1));
+    if (taps == 1) {
+        if (nt == 1) return launch_conv_fwd<1, 1, 0>(a, s);
+        if (nt == 2) return launch_conv_fwd<1, 2, 0>(a, s);
+        return launch_conv_fwd<1, 4, 0>(a, s);
+    }
+    if (dil == 1) {
+        if (nt == 1) return launch_conv_fwd<9, 1, 1>(a, s);
+        if (nt == 2) return launch_conv_fwd<9, 2, 1>(a, s);
+        return launch_conv_fwd<9, 4, 1>(a, s);
+    }
+    if (nt == 1) return launch_conv_fwd<9, 1, 6>(a, s);
+    if (nt == 2) return launch_conv_fwd<9, 2, 6>(a, s);
+    return launch_conv_fwd<9, 4, 6>(a, s);
+}
+
+// Number of float partial-statistics rows amx_conv2d_fwd writes: rows x 2 x round_up(cout,16).
+extern "C" int amx_conv2d_num_tiles(int N, int H, int W) {
+    return amx_ceil_div(W, TILE) * amx_ceil_div(H, TILE) * N;
+}

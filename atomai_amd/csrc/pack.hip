@@ -1,0 +1,105 @@
+// pack.hip — weight-image builders and layout converters (all HBM-bound, tiny).
+//
+// The public module tree keeps nn.Conv2d-shaped OIHW fp32 parameters (state-dict compatibility,
+// SURVEY.md §0.4); the MFMA kernels consume a K-chunked image
+//     wpk[chunk][tap][kgroup(4)][n (padded to 16)][4 channels]
+// built here once per optimizer step:
+//   mode 0 (forward):  k runs over the concatenated, 4-padded input channels of (src0|src1), n = cout
+//   mode 1 (dgrad):    k runs over cout, n runs over the concatenated padded input channels, taps are
+//                      spatially flipped (tap -> taps-1-tap)  [dX = conv(dY, flip(W)^T)]
+#include "amx_device.h"
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                    int cout, int cin, int C0, int C0s, int C1, int C1s, int taps,
+                                    int mode, int nop, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int t = idx;
+    const int e = t & 3; t >>= 2;
+    const int n = t % nop; t /= nop;
+    const int kg = t & 3; t >>= 2;
+    const int tap = t % taps; const int chunk = t / taps;
+    const int k = (chunk * 4 + kg) * 4 + e;
+    // map an index of the concatenated padded channel space to a real input channel (or -1)
+    auto cat2ci = [&](int c) -> int {
+        if (c < C0s) return c < C0 ? c : -1;
+        c -= C0s;
+        return (c < C1s && c < C1) ? C0 + c : -1;
+    };
+    int co, ci, tp;
+    if (mode == 0) { ci = cat2ci(k); co = n < cout ? n : -1; tp = tap; }
+    else { co = k < cout ? k : -1; ci = cat2ci(n); tp = taps - 1 - tap; }
+    float v = 0.f;
+    if (co >= 0 && ci >= 0) v = w[((size_t)co * cin + ci) * taps + tp];
+    dst[idx] = v;
+}
+
+extern "C" int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C0, int C0s, int C1,
+                                int C1s, int taps, int mode, void* stream) {
+    if (!w_oihw || !dst) AMX_BADARG(1);
+    if (cout <= 0 || C0 <= 0 || C0s < C0 || C1s < C1 || (C0s & 3) || (C1s & 3)) AMX_BADARG(2);
+    if (taps != 1 && taps != 9) AMX_BADARG(3);
+    const int kspace = mode == 0 ? (C0s + C1s) : amx_round_up(cout, 4);
+    const int nspace = mode == 0 ? cout : (C0s + C1s);
+    const int nchunk = amx_ceil_div(kspace, 16);
+    const int nop = amx_round_up(nspace, 16);
+    const int total = nchunk * taps * 4 * nop * 4;
+    AMX_LAUNCH(pack_weights_kernel, dim3(amx_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+               w_oihw, dst, cout, C0 + C1, C0, C0s, C1, C1s, taps, mode, nop, total);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// number of floats amx_pack_weights writes
+extern "C" long amx_pack_weights_size(int cout, int C0s, int C1s, int taps, int mode) {
+    const int kspace = mode == 0 ? (C0s + C1s) : amx_round_up(cout, 4);
+    const int nspace = mode == 0 ? cout : (C0s + C1s);
+    return (long)amx_ceil_div(kspace, 16) * taps * 4 * amx_round_up(nspace, 16) * 4;
+}
+
+// ---- NCHW <-> NHWC (stored channels Cs = round_up(C,4), zero padded) ----
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                    int C, int Cs, int HW) {
+    const size_t total = (size_t)N * HW * Cs;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cs);
+        const size_t r = i / Cs;
+        const size_t n = r / HW, hw = r - n * HW;
+        dst[i] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                    int C, int Cs, int HW) {
+    const size_t total = (size_t)N * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t hw = i % HW;
+        const size_t r = i / HW;
+        const size_t c = r % C, n = r / C;
+        dst[i] = src[(n * HW + hw) * Cs + c];
+    }
+}
+
+extern "C" int amx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int Cs, int H, int W,
+                                void* stream) {
+    if (!src || !dst || C <= 0 || Cs < C || (Cs & 3)) AMX_BADARG(1);
+    const size_t total = (size_t)N * H * W * Cs;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    AMX_LAUNCH(nchw_to_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, C,
+               Cs, H * W);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int amx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int Cs, int H, int W,
+                                void* stream) {
+    if (!src || !dst || C <= 0 || Cs < C || (Cs & 3)) AMX_BADARG(1);
+    const size_t total = (size_t)N * H * W * C;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    AMX_LAUNCH(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, N, C,
+               Cs, H * W);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
