@@ -19,16 +19,30 @@ _F = C.c_float
 _L = C.c_long
 _D = C.c_double
 
-# name -> (restype, argtypes).  Must mirror include/atomai_amd.h exactly.
-SIGNATURES = {
-    "amx_conv2d_fwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P,
-                            _I, _I, _I, _I, _I, _I, _F, _P]),
-    "amx_conv2d_num_tiles": (_I, [_I, _I, _I]),
-    "amx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "amx_pack_weights_size": (_L, [_I, _I, _I, _I, _I]),
-    "amx_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "amx_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-}
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "atomai_amd.h")
+
+_CTYPES = {"int": _I, "long": _L, "float": _F, "double": _D}
+
+
+def parse_header(path: str = None):
+    """Parses the C-ABI header into {name: (restype, [argtypes])}; any pointer -> c_void_p."""
+    import re
+    text = open(path or HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(int|long)\s+(amx_\w+)\s*\(([^)]*)\)\s*;", text):
+        res, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            if "*" in a:
+                argtypes.append(_P)
+            else:
+                argtypes.append(_CTYPES[a.split()[-2] if len(a.split()) > 1 else a])
+        sigs[name] = (_CTYPES[res], argtypes)
+    return sigs
+
+
+SIGNATURES = parse_header()
 
 _lib = None
 _is_test_backend = False

@@ -1,0 +1,216 @@
+// conv1.hip — first-layer convolution (Cin == 1: the microscopy image itself) and its weight gradient.
+// K = 9 is too small for MFMA; the layer is bound by the HBM write of its Cout-channel output, so this is
+// a VALU kernel organised for perfectly coalesced 16 B/lane NHWC stores: G = Cs/4 lanes share a pixel,
+// each producing 4 output channels.
+//
+//   c1 = ConvBlock(2, nbl[0], 1, nb_filters): Conv2d(1, F, 3, padding=1) -> LeakyReLU -> BN stats
+//                                                   atomai/nets/fcnn.py:66-69, 186-189; blocks.py:61-76
+#include "amx_device.h"
+
+// Per-thread Welford state for 4 channels; merged across the block with Chan's formula.
+struct Wf4 { float4 mean, m2; float n; };
+
+__device__ __forceinline__ void wf_push(Wf4& s, const float4 v) {
+    s.n += 1.f;
+    const float r = 1.f / s.n;
+    float d;
+    d = v.x - s.mean.x; s.mean.x += d * r; s.m2.x = fmaf(d, v.x - s.mean.x, s.m2.x);
+    d = v.y - s.mean.y; s.mean.y += d * r; s.m2.y = fmaf(d, v.y - s.mean.y, s.m2.y);
+    d = v.z - s.mean.z; s.mean.z += d * r; s.m2.z = fmaf(d, v.z - s.mean.z, s.m2.z);
+    d = v.w - s.mean.w; s.mean.w += d * r; s.m2.w = fmaf(d, v.w - s.mean.w, s.m2.w);
+}
+
+// x [N][H][W] (single channel), w OIHW [Cout][1][3][3], y NHWC [P][Cs].
+// Block b owns pixels [b*ppb, (b+1)*ppb); stats row b = (sum, M2 about the row mean) per channel.
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, float* __restrict__ stats,
+                                                        int N, int H, int W, int Cout, int Cs, int dil,
+                                                        float slope, int ppb, int cop) {
+    const int G = Cs >> 2, PL = 256 / G;
+    const int tid = threadIdx.x;
+    const int pl = tid / G, cg = tid - pl * G;
+    const bool active = pl < PL;
+    AMX_DYN_SMEM(float, s);                       // [PL][3][Cs]: mean, m2, n
+    const long npix = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    float4 wt[9];
+    float4 b4 = make_float4(0, 0, 0, 0);
+    if (active) {
+        #pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int c = cg * 4;
+            wt[t].x = c + 0 < Cout ? w[(c + 0) * 9 + t] : 0.f; wt[t].y = c + 1 < Cout ? w[(c + 1) * 9 + t] : 0.f;
+            wt[t].z = c + 2 < Cout ? w[(c + 2) * 9 + t] : 0.f; wt[t].w = c + 3 < Cout ? w[(c + 3) * 9 + t] : 0.f;
+        }
+        const int c = cg * 4;
+        if (bias) {
+            b4.x = c + 0 < Cout ? bias[c + 0] : 0.f; b4.y = c + 1 < Cout ? bias[c + 1] : 0.f;
+            b4.z = c + 2 < Cout ? bias[c + 2] : 0.f; b4.w = c + 3 < Cout ? bias[c + 3] : 0.f;
+        }
+    }
+    Wf4 st; st.mean = make_float4(0, 0, 0, 0); st.m2 = st.mean; st.n = 0.f;
+    if (active)
+        for (long p = p0 + pl; p < p1; p += PL) {
+            const int xx = (int)(p % W);
+            const long r = p / W;
+            const int yy = (int)(r % H);
+            const long nimg = r / H;
+            const float* img = x + (size_t)nimg * H * W;
+            float4 acc = b4;
+            #pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
+                float v = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(size_t)iy * W + ix];
+                acc.x = fmaf(v, wt[t].x, acc.x); acc.y = fmaf(v, wt[t].y, acc.y);
+                acc.z = fmaf(v, wt[t].z, acc.z); acc.w = fmaf(v, wt[t].w, acc.w);
+            }
+            acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+            acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+            amx_st4(y + (size_t)p * Cs + cg * 4, acc);
+            wf_push(st, acc);
+        }
+    if (!stats) return;
+    if (active) {
+        amx_st4(s + ((size_t)(pl * 3 + 0) * Cs + cg * 4), st.mean);
+        amx_st4(s + ((size_t)(pl * 3 + 1) * Cs + cg * 4), st.m2);
+        s[(size_t)(pl * 3 + 2) * Cs + cg * 4] = st.n;
+    }
+    __syncthreads();
+    for (int c = tid; c < Cs; c += 256) {
+        const int cgc = c >> 2;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        for (int q = 0; q < PL; ++q) {
+            const float nq = s[(size_t)(q * 3 + 2) * Cs + cgc * 4];
+            if (nq == 0.f) continue;
+            const float mq = s[(size_t)(q * 3 + 0) * Cs + c], m2q = s[(size_t)(q * 3 + 1) * Cs + c];
+            const float nt = n + nq, d = mq - mean;
+            mean += d * (nq / nt);
+            m2 += m2q + d * d * (n * nq / nt);
+            n = nt;
+        }
+        stats[((size_t)blockIdx.x * 2 + 0) * cop + c] = mean * n;
+        stats[((size_t)blockIdx.x * 2 + 1) * cop + c] = m2;
+    }
+}
+
+extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+                             int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows,
+                             int rows_pix, void* stream) {
+    if (!x || !w || !y || Cout <= 0 || Cs < Cout || (Cs & 3) || Cs > 256 || dil < 1) AMX_BADARG(1);
+    const long npix = (long)N * H * W;
+    if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
+    const int PL = 256 / (Cs / 4);
+    AMX_LAUNCH(conv1_fwd_kernel, dim3(rows), dim3(256), (size_t)PL * 3 * Cs * sizeof(float),
+               (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
+               amx_round_up(Cout, 16));
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW[co][0][t] = sum_p dpre[p][co] * x[p + tap t];  partial rows part[blk][9][Cs]
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ dpre,
+                                                          float* __restrict__ part, int N, int H, int W,
+                                                          int Cs, int dil, int ppb) {
+    const int G = Cs >> 2, PL = 256 / G;
+    const int tid = threadIdx.x;
+    const int pl = tid / G, cg = tid - pl * G;
+    const bool active = pl < PL;
+    AMX_DYN_SMEM(float, s);                       // [PL][Cs] (one tap at a time)
+    const long npix = (long)N * H * W;
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    float4 acc[9];
+    #pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
+    if (active)
+        for (long p = p0 + pl; p < p1; p += PL) {
+            const int xx = (int)(p % W);
+            const long r = p / W;
+            const int yy = (int)(r % H);
+            const long nimg = r / H;
+            const float* img = x + (size_t)nimg * H * W;
+            const float4 g = amx_ld4(dpre + (size_t)p * Cs + cg * 4);
+            #pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
+                float v = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(size_t)iy * W + ix];
+                acc[t].x = fmaf(v, g.x, acc[t].x); acc[t].y = fmaf(v, g.y, acc[t].y);
+                acc[t].z = fmaf(v, g.z, acc[t].z); acc[t].w = fmaf(v, g.w, acc[t].w);
+            }
+        }
+    #pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (active) amx_st4(s + ((size_t)pl * Cs + cg * 4), acc[t]);
+        __syncthreads();
+        for (int c = tid; c < Cs; c += 256) {
+            float a = 0.f;
+            for (int q = 0; q < PL; ++q) a += s[(size_t)q * Cs + c];
+            part[((size_t)blockIdx.x * 9 + t) * Cs + c] = a;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int amx_conv1_wgrad(const float* x, const float* dpre, float* part, int N, int H, int W,
+                               int Cs, int dil, int rows, int rows_pix, void* stream) {
+    if (!x || !dpre || !part || (Cs & 3) || Cs <= 0 || Cs > 256 || dil < 1) AMX_BADARG(1);
+    const long npix = (long)N * H * W;
+    if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
+    const int PL = 256 / (Cs / 4);
+    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)PL * Cs * sizeof(float),
+               (hipStream_t)stream, x, dpre, part, N, H, W, Cs, dil, rows_pix);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// Reduces wgrad partial rows [rows][taps][ci_pad][co_pad] into the OIHW gradient dW[co][ci][tap].
+// A block owns 32 consecutive (tap, pci, co) columns (co fastest -> coalesced 128 B row reads) and
+// splits the rows over 8 lanes; fp64 accumulation, fixed order -> deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int rows,
+                                                           int taps, int ci_pad, int co_pad, int C0,
+                                                           int C0s, int C1s, int Cin, int Cout,
+                                                           float* __restrict__ dw) {
+    __shared__ double red[8][32];
+    const int tid = threadIdx.x;
+    const int col = tid & 31, rl = tid >> 5;
+    const long ncols = (long)taps * ci_pad * co_pad;
+    const long c = (long)blockIdx.x * 32 + col;
+    double acc = 0.0;
+    if (c < ncols)
+        for (int r = rl; r < rows; r += 8) acc += (double)part[(size_t)r * ncols + c];
+    red[rl][col] = acc;
+    __syncthreads();
+    if (rl == 0 && c < ncols) {
+        double s = 0.0;
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][col];
+        const int co = (int)(c % co_pad);
+        const long r2 = c / co_pad;
+        const int pci = (int)(r2 % ci_pad);
+        const int t = (int)(r2 / ci_pad);
+        // padded-concat channel index -> real input channel (or none)
+        int ci = -1;
+        if (pci < C0s) { if (pci < C0) ci = pci; }
+        else if (pci - C0s < C1s && pci - C0s < Cin - C0) ci = C0 + (pci - C0s);
+        if (ci >= 0 && co < Cout) dw[((size_t)co * Cin + ci) * taps + t] = (float)s;
+    }
+}
+
+extern "C" int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0,
+                                int C0s, int C1, int Cout, float* dw, void* stream) {
+    if (!part || !dw || rows <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || co_pad < Cout) AMX_BADARG(1);
+    if (C0s < C0) AMX_BADARG(2);
+    const int Cin = C0 + C1;
+    const int C1s = amx_round_up(C1, 4);
+    const long ncols = (long)taps * ci_pad * co_pad;
+    AMX_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((ncols + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+               part, rows, taps, ci_pad, co_pad, C0, C0s, C1s, Cin, Cout, dw);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

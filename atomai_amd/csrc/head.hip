@@ -1,0 +1,272 @@
+// head.hip — the network head: the final pixel-wise 1x1 convolution `px` (Cout = nb_classes, far too
+// narrow for MFMA -> VALU, bandwidth-bound) and the segmentation losses, forward fused with backward.
+//
+//   self.px = nn.Conv2d(nb_filters, nb_classes, 1, 1, 0)                 atomai/nets/fcnn.py:115, 212
+//   select_loss('ce'): CrossEntropyLoss (nb_classes > 2) / BCEWithLogitsLoss (== 1)   atomai/losses_metrics/losses.py:152-155
+//   SegPredictor.forward_: softmax(dim=1) / sigmoid, permute to NHWC     atomai/predictors/predictor.py:219-229
+#include "amx_device.h"
+
+#define MAXCLS 8
+
+// ------------------------------------------------------------------ px forward
+// logits[n][k][h][w] (NCHW, the module's public output) = sum_c xn[p][c] * W[k][c] + b[k],
+// xn = a*scale + shift (BN of the previous block applied on load).  LPP lanes cooperate on a pixel.
+// mode 0: raw logits NCHW.  mode 1: probabilities NHWC [P][K] (sigmoid if K == 1 else softmax).
+__global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ out,
+                                                     long npix, long HW, int C, int Cs, int K, int LPP,
+                                                     int mode) {
+    const int G = Cs >> 2;
+    const int tid = threadIdx.x;
+    const int cg = tid % LPP;
+    const int ppb = 256 / LPP;
+    for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
+        const long p = p0 + tid / LPP;
+        float acc[MAXCLS];
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) acc[k] = 0.f;
+        if (p < npix && cg < G) {
+            float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
+            if (scale) {
+                const float4 sc = amx_ld4(scale + cg * 4), sh = amx_ld4(shift + cg * 4);
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            }
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) {
+                if (k >= K) break;
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = cg * 4 + e;
+                    if (c < C) acc[k] = fmaf(vv[e], w[k * C + c], acc[k]);
+                }
+            }
+        }
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) {
+            if (k >= K) break;
+            for (int o = 1; o < LPP; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
+            acc[k] += b[k];
+        }
+        if (p < npix) {
+            if (mode == 0) {
+                const long n = p / HW, hw = p - n * HW;
+                if (cg < K) {
+                    float v = 0.f;
+                    #pragma unroll
+                    for (int k = 0; k < MAXCLS; ++k) if (k == cg) v = acc[k];
+                    out[((size_t)n * K + cg) * HW + hw] = v;
+                }
+                if (LPP < K && cg == 0)
+                    for (int k = LPP; k < K; ++k) out[((size_t)n * K + k) * HW + hw] = acc[k];
+            } else if (cg == 0) {
+                if (K == 1) out[p] = 1.f / (1.f + expf(-acc[0]));
+                else {
+                    float mx = acc[0];
+                    for (int k = 1; k < K; ++k) mx = fmaxf(mx, acc[k]);
+                    float s = 0.f, e[MAXCLS];
+                    for (int k = 0; k < K; ++k) { e[k] = expf(acc[k] - mx); s += e[k]; }
+                    for (int k = 0; k < K; ++k) out[(size_t)p * K + k] = e[k] / s;
+                }
+            }
+        }
+    }
+}
+
+static int lanes_per_pixel(int Cs) {
+    int g = Cs / 4, l = 1;
+    while (l < g) l <<= 1;
+    return l;
+}
+
+extern "C" int amx_px_fwd(const float* a, const float* scale, const float* shift, const float* w,
+                          const float* b, float* out, int N, int H, int W, int C, int Cs, int K, int mode,
+                          void* stream) {
+    if (!a || !w || !b || !out || (Cs & 3) || C <= 0 || Cs < C || Cs > 256) AMX_BADARG(1);
+    if (K < 1 || K > MAXCLS) AMX_BADARG(2);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
+    const long npix = (long)N * H * W;
+    const int LPP = lanes_per_pixel(Cs), ppb = 256 / LPP;
+    long nb = (npix + ppb - 1) / ppb;
+    if (nb > 16384) nb = 16384;
+    AMX_LAUNCH(px_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, scale, shift, w, b,
+               out, npix, (long)H * W, C, Cs, K, LPP, mode);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ px backward
+// dxn[p][c] = sum_k dl[n][k][hw] * W[k][c];  partial rows: part[blk][K][Cs] (dW) and partb[blk][K] (db)
+__global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ dl,
+                                                     const float* __restrict__ a,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift,
+                                                     const float* __restrict__ w, float* __restrict__ dxn,
+                                                     float* __restrict__ part, float* __restrict__ partb,
+                                                     long npix, long HW, int C, int Cs, int K, int ppb) {
+    const int G = Cs >> 2, PL = 256 / G;
+    const int tid = threadIdx.x;
+    const int pl = tid / G, cg = tid - pl * G;
+    const bool active = pl < PL;
+    AMX_DYN_SMEM(float, s);                       // [PL][K][Cs] + [PL][K]
+    float4 dw[MAXCLS];
+    float db[MAXCLS];
+    #pragma unroll
+    for (int k = 0; k < MAXCLS; ++k) { dw[k] = make_float4(0, 0, 0, 0); db[k] = 0.f; }
+    float4 wk[MAXCLS];
+    #pragma unroll
+    for (int k = 0; k < MAXCLS; ++k) {
+        wk[k] = make_float4(0, 0, 0, 0);
+        if (k < K && active) {
+            const int c = cg * 4;
+            wk[k].x = c + 0 < C ? w[k * C + c + 0] : 0.f; wk[k].y = c + 1 < C ? w[k * C + c + 1] : 0.f;
+            wk[k].z = c + 2 < C ? w[k * C + c + 2] : 0.f; wk[k].w = c + 3 < C ? w[k * C + c + 3] : 0.f;
+        }
+    }
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    if (active) {
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
+        for (long p = p0 + pl; p < p1; p += PL) {
+            const long n = p / HW, hw = p - n * HW;
+            float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            float4 d = make_float4(0, 0, 0, 0);
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) {
+                if (k >= K) break;
+                const float g = dl[((size_t)n * K + k) * HW + hw];
+                d.x = fmaf(g, wk[k].x, d.x); d.y = fmaf(g, wk[k].y, d.y);
+                d.z = fmaf(g, wk[k].z, d.z); d.w = fmaf(g, wk[k].w, d.w);
+                dw[k].x = fmaf(g, v.x, dw[k].x); dw[k].y = fmaf(g, v.y, dw[k].y);
+                dw[k].z = fmaf(g, v.z, dw[k].z); dw[k].w = fmaf(g, v.w, dw[k].w);
+                db[k] += g;
+            }
+            amx_st4(dxn + (size_t)p * Cs + cg * 4, d);
+        }
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) {
+            if (k >= K) break;
+            amx_st4(s + ((size_t)(pl * K + k) * Cs + cg * 4), dw[k]);
+            if (cg == 0) s[(size_t)PL * K * Cs + pl * K + k] = db[k];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * Cs; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < PL; ++q) acc += s[(size_t)q * K * Cs + i];
+        part[(size_t)blockIdx.x * K * Cs + i] = acc;
+    }
+    if (tid < K) {
+        float acc = 0.f;
+        for (int q = 0; q < PL; ++q) acc += s[(size_t)PL * K * Cs + q * K + tid];
+        partb[(size_t)blockIdx.x * K + tid] = acc;
+    }
+}
+
+extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, const float* shift,
+                          const float* w, float* dxn, float* part, float* partb, int N, int H, int W,
+                          int C, int Cs, int K, int rows, int rows_pix, void* stream) {
+    if (!dl || !a || !w || !dxn || !part || !partb || (Cs & 3) || C <= 0 || Cs < C || Cs > 256)
+        AMX_BADARG(1);
+    if (K < 1 || K > MAXCLS) AMX_BADARG(2);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
+    const long npix = (long)N * H * W;
+    if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(4);
+    const int PL = 256 / (Cs / 4);
+    const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K) * sizeof(float);
+    AMX_LAUNCH(px_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, dl, a, scale, shift, w, dxn,
+               part, partb, npix, (long)H * W, C, Cs, K, rows_pix);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ cross entropy (fwd + bwd fused)
+// logits NCHW [N][K][HW], target int64 [N][HW].  loss = mean over valid pixels of (lse - x_t);
+// dlogits = (softmax - onehot) / n_valid is written in the same pass (NCHW) so that backward is free.
+// part[blk][2] = (sum of per-pixel losses, number of valid pixels); the mean is taken in the finalize
+// kernel in fp64 and the gradient is scaled by 1/n_valid there-after by the caller-provided inv_count
+// (n_valid is known a priori when no ignore_index is present: the reference never produces one).
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ x,
+                                                         const long long* __restrict__ tgt,
+                                                         float* __restrict__ dx, float* __restrict__ part,
+                                                         long npix, long HW, int K, float inv_count) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float lsum = 0.f;
+    for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
+        const long n = p / HW, hw = p - n * HW;
+        const float* xp = x + (size_t)n * K * HW + hw;
+        float v[MAXCLS];
+        float mx = -3.4e38f;
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = xp[(size_t)k * HW]; mx = fmaxf(mx, v[k]); }
+        const int t = (int)tgt[p];
+        float s = 0.f, xt = 0.f;
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) {
+            if (k >= K) break;
+            if (k == t) xt = v[k] - mx;
+            v[k] = expf(v[k] - mx); s += v[k];
+        }
+        const float inv_s = 1.f / s;
+        #pragma unroll
+        for (int k = 0; k < MAXCLS; ++k) {
+            if (k >= K) break;
+            const float sm = v[k] * inv_s;
+            if (dx) dx[(size_t)n * K * HW + (size_t)k * HW + hw] = (sm - (k == t ? 1.f : 0.f)) * inv_count;
+        }
+        lsum += logf(s) - xt;
+    }
+    red[tid] = lsum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+
+extern "C" int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits, float* part,
+                              int rows, int N, int K, long HW, void* stream) {
+    if (!logits || !target || !part || K < 2 || K > MAXCLS || rows <= 0) AMX_BADARG(1);
+    const long npix = (long)N * HW;
+    AMX_LAUNCH(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits,
+               part, npix, HW, K, 1.0f / (float)npix);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ BCE with logits (fwd + bwd fused)
+// loss = mean( max(x,0) - x*y + log(1 + exp(-|x|)) );  dx = (sigmoid(x) - y) / numel
+__global__ __launch_bounds__(256) void bce_fwd_bwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ y,
+                                                          float* __restrict__ dx, float* __restrict__ part,
+                                                          long n, float inv_count) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float lsum = 0.f;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i], t = y[i];
+        const float e = expf(-fabsf(v));
+        lsum += fmaxf(v, 0.f) - v * t + log1pf(e);
+        if (dx) {
+            const float sg = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            dx[i] = (sg - t) * inv_count;
+        }
+    }
+    red[tid] = lsum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+
+extern "C" int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part,
+                               int rows, long numel, void* stream) {
+    if (!logits || !target || !part || rows <= 0 || numel <= 0) AMX_BADARG(1);
+    AMX_LAUNCH(bce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits,
+               part, numel, 1.0f / (float)numel);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

@@ -103,3 +103,23 @@ extern "C" int amx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int 
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// dst += src (gradient accumulation when a kernel cannot accumulate in place)
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = amx_ld4(dst + i * 4);
+        const float4 b = amx_ld4(src + i * 4);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        amx_st4(dst + i * 4, a);
+    }
+}
+
+extern "C" int amx_add_inplace(float* dst, const float* src, long n, void* stream) {
+    if (!dst || !src || n <= 0 || (n & 3)) AMX_BADARG(1);
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    AMX_LAUNCH(add_inplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n4);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,271 @@
+// spatial.hip — max-pool, x2 upsampling (bilinear / nearest) and the DilatedBlock sum, NHWC float4.
+// All HBM-bound elementwise/gather kernels: one float4 (4 channels) per thread, consecutive threads
+// on consecutive channel groups -> fully coalesced 16 B/lane accesses.
+//
+//   F.max_pool2d(x, 2, 2) on the BN output                                  atomai/nets/fcnn.py:123-127, 219
+//   F.interpolate(scale_factor=2, mode=bilinear|nearest), align_corners=False   atomai/nets/blocks.py:130-131
+//   DilatedBlock: sum of every sub-layer output                              atomai/nets/blocks.py:321-329
+#include "amx_device.h"
+
+#define GRID_FOR(n) dim3((unsigned)(((n) + 255) / 256 < 16384 ? ((n) + 255) / 256 : 16384))
+
+// ------------------------------------------------------------------ max pool 2x2 / stride 2
+// Reads the RAW post-activation tensor a plus the producer's BN affine (scale may be negative, so the
+// affine is applied before the max); writes the normalised pooled tensor.
+__global__ void pool_fwd_kernel(const float* __restrict__ a, const float* __restrict__ scale,
+                                const float* __restrict__ shift, float* __restrict__ d, int N, int H,
+                                int W, int G) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        size_t r = i / G;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho); const int n = (int)(r / Ho);
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
+        float4 best;
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
+            float4 v = amx_ld4(a + (((size_t)n * H + y) * W + x) * G * 4 + cg * 4);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            if (k == 0) best = v;
+            else {
+                best.x = v.x > best.x ? v.x : best.x; best.y = v.y > best.y ? v.y : best.y;
+                best.z = v.z > best.z ? v.z : best.z; best.w = v.w > best.w ? v.w : best.w;
+            }
+        }
+        amx_st4(d + i * 4, best);
+    }
+}
+
+extern "C" int amx_pool2x2_fwd(const float* a, const float* scale, const float* shift, float* d, int N,
+                               int H, int W, int Cs, void* stream) {
+    if (!a || !d || (Cs & 3) || Cs <= 0 || H < 2 || W < 2) AMX_BADARG(1);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(2);
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (Cs / 4);
+    AMX_LAUNCH(pool_fwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, a, scale, shift, d,
+               N, H, W, Cs / 4);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward: dy[full res] = skip_grad (optional) + route(g) where the gradient of each 2x2 window goes
+// to its FIRST maximum in scan order (torch semantics); the arg-max is recomputed from a + affine.
+__global__ void pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                const float* __restrict__ skip, float* __restrict__ dy, int N, int H,
+                                int W, int G) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;      // also cover an odd last row/col (skip only)
+    const size_t total = (size_t)N * Hc * Wc * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        size_t r = i / G;
+        const int xo = (int)(r % Wc); r /= Wc;
+        const int yo = (int)(r % Hc); const int n = (int)(r / Hc);
+        const bool inwin = (yo < Ho) && (xo < Wo);
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
+        float4 v[4];
+        bool ok[4];
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
+            ok[k] = (y < H) && (x < W);
+            v[k] = make_float4(0, 0, 0, 0);
+            if (ok[k] && inwin) {
+                float4 t = amx_ld4(a + (((size_t)n * H + y) * W + x) * G * 4 + cg * 4);
+                t.x = fmaf(t.x, sc.x, sh.x); t.y = fmaf(t.y, sc.y, sh.y);
+                t.z = fmaf(t.z, sc.z, sh.z); t.w = fmaf(t.w, sc.w, sh.w);
+                v[k] = t;
+            }
+        }
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        float4 gg = make_float4(0, 0, 0, 0);
+        if (inwin) {
+            float4 best = v[0];
+            #pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                if (v[k].x > best.x) { best.x = v[k].x; ax = k; }
+                if (v[k].y > best.y) { best.y = v[k].y; ay = k; }
+                if (v[k].z > best.z) { best.z = v[k].z; az = k; }
+                if (v[k].w > best.w) { best.w = v[k].w; aw = k; }
+            }
+            gg = amx_ld4(g + (((size_t)n * Ho + yo) * Wo + xo) * G * 4 + cg * 4);
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
+            const size_t o = (((size_t)n * H + y) * W + x) * G * 4 + cg * 4;
+            float4 out = make_float4(0, 0, 0, 0);
+            if (skip) out = amx_ld4(skip + o);
+            if (inwin) {
+                out.x += ax == k ? gg.x : 0.f; out.y += ay == k ? gg.y : 0.f;
+                out.z += az == k ? gg.z : 0.f; out.w += aw == k ? gg.w : 0.f;
+            }
+            amx_st4(dy + o, out);
+        }
+    }
+}
+
+extern "C" int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const float* shift,
+                               const float* skip, float* dy, int N, int H, int W, int Cs, void* stream) {
+    if (!g || !a || !dy || (Cs & 3) || Cs <= 0 || H < 2 || W < 2) AMX_BADARG(1);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(2);
+    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cs / 4);
+    AMX_LAUNCH(pool_bwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, g, a, scale, shift,
+               skip, dy, N, H, W, Cs / 4);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ upsample x2
+// bilinear, align_corners=False, scale 2:  out(2i)   = .25*in(i-1) + .75*in(i)
+//                                          out(2i+1) = .75*in(i)   + .25*in(i+1)   (indices clamped)
+__device__ __forceinline__ void up_taps(int o, int n, int mode, int& i0, int& i1, float& w0, float& w1) {
+    if (mode == 1) { i0 = i1 = o >> 1; w0 = 1.f; w1 = 0.f; return; }        // nearest: floor(o/2)
+    const int i = o >> 1;
+    if (o & 1) { i0 = i; i1 = i + 1 < n ? i + 1 : n - 1; w0 = 0.75f; w1 = 0.25f; }
+    else { i0 = i > 0 ? i - 1 : 0; i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ v, float* __restrict__ u, int N, int h,
+                                    int w, int G, int mode) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        size_t r = i / G;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); const int n = (int)(r / H);
+        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+        up_taps(y, h, mode, y0, y1, wy0, wy1);
+        up_taps(x, w, mode, x0, x1, wx0, wx1);
+        const float* base = v + (size_t)n * h * w * G * 4 + cg * 4;
+        const float4 a00 = amx_ld4(base + ((size_t)y0 * w + x0) * G * 4);
+        float4 o;
+        if (mode == 1) { o = a00; }
+        else {
+            const float4 a01 = amx_ld4(base + ((size_t)y0 * w + x1) * G * 4);
+            const float4 a10 = amx_ld4(base + ((size_t)y1 * w + x0) * G * 4);
+            const float4 a11 = amx_ld4(base + ((size_t)y1 * w + x1) * G * 4);
+            // same association order as ATen's upsample_bilinear2d: rows first, then columns
+            o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+            o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+            o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+            o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+        }
+        amx_st4(u + i * 4, o);
+    }
+}
+
+extern "C" int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode,
+                                  void* stream) {
+    if (!v || !u || (Cs & 3) || Cs <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
+    const size_t total = (size_t)N * 4 * h * w * (Cs / 4);
+    AMX_LAUNCH(upsample_fwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, v, u, N, h, w,
+               Cs / 4, mode);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward as a deterministic GATHER (ATen's CUDA backward scatters with atomics): each low-res pixel
+// collects from the <= 4x4 high-res pixels it contributed to.
+__device__ __forceinline__ int up_bwd_taps(int i, int n, int mode, int* o, float* wgt) {
+    if (mode == 1) { o[0] = 2 * i; wgt[0] = 1.f; o[1] = 2 * i + 1; wgt[1] = 1.f; return 2; }
+    int c = 0;
+    // out(2i) gets .75 in(i); out(2i+1) gets .75 in(i)
+    o[c] = 2 * i; wgt[c++] = 0.75f + (i == 0 ? 0.25f : 0.f);            // clamp at the low edge
+    o[c] = 2 * i + 1; wgt[c++] = 0.75f + (i == n - 1 ? 0.25f : 0.f);    // clamp at the high edge
+    if (i > 0) { o[c] = 2 * i - 1; wgt[c++] = 0.25f; }                  // out(2(i-1)+1) uses in(i) * .25
+    if (i + 1 < n) { o[c] = 2 * i + 2; wgt[c++] = 0.25f; }              // out(2(i+1))   uses in(i) * .25
+    return c;
+}
+
+__global__ void upsample_bwd_kernel(const float* __restrict__ du, float* __restrict__ dv, int N, int h,
+                                    int w, int G, int mode) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t total = (size_t)N * h * w * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        size_t r = i / G;
+        const int x = (int)(r % w); r /= w;
+        const int y = (int)(r % h); const int n = (int)(r / h);
+        int oy[4], ox[4]; float wy[4], wx[4];
+        const int ny = up_bwd_taps(y, h, mode, oy, wy);
+        const int nx = up_bwd_taps(x, w, mode, ox, wx);
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                const float4 g = amx_ld4(du + (((size_t)n * H + oy[a]) * W + ox[b]) * G * 4 + cg * 4);
+                const float wt = wy[a] * wx[b];
+                acc.x = fmaf(wt, g.x, acc.x); acc.y = fmaf(wt, g.y, acc.y);
+                acc.z = fmaf(wt, g.z, acc.z); acc.w = fmaf(wt, g.w, acc.w);
+            }
+        amx_st4(dv + i * 4, acc);
+    }
+}
+
+extern "C" int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int w, int Cs, int mode,
+                                  void* stream) {
+    if (!du || !dv || (Cs & 3) || Cs <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
+    const size_t total = (size_t)N * h * w * (Cs / 4);
+    AMX_LAUNCH(upsample_bwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, du, dv, N, h, w,
+               Cs / 4, mode);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ DilatedBlock sum
+// out (+)= sum_i [ pre_i + a_i + bn_i ],  pre_i = a_i > 0 ? a_i : a_i / slope  (inverse LeakyReLU),
+// bn_i = a_i*scale_i + shift_i (omitted when the block has no BatchNorm: scale_i == nullptr).
+struct DilSumArgs {
+    const float* a[4]; const float* scale[4]; const float* shift[4];
+    int n; int accumulate; float inv_slope;
+};
+
+__global__ void dilated_sum_kernel(DilSumArgs p, float* __restrict__ out, size_t n4, int G) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        float4 acc = make_float4(0, 0, 0, 0);
+        if (p.accumulate) acc = amx_ld4(out + i * 4);
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= p.n) break;
+            const float4 v = amx_ld4(p.a[k] + i * 4);
+            float4 sc = make_float4(0, 0, 0, 0), sh = sc;
+            if (p.scale[k]) { sc = amx_ld4(p.scale[k] + cg * 4); sh = amx_ld4(p.shift[k] + cg * 4); }
+            acc.x += (v.x > 0.f ? v.x : v.x * p.inv_slope) + v.x + fmaf(v.x, sc.x, sh.x);
+            acc.y += (v.y > 0.f ? v.y : v.y * p.inv_slope) + v.y + fmaf(v.y, sc.y, sh.y);
+            acc.z += (v.z > 0.f ? v.z : v.z * p.inv_slope) + v.z + fmaf(v.z, sc.z, sh.z);
+            acc.w += (v.w > 0.f ? v.w : v.w * p.inv_slope) + v.w + fmaf(v.w, sc.w, sh.w);
+        }
+        amx_st4(out + i * 4, acc);
+    }
+}
+
+extern "C" int amx_dilated_sum(const float* const* a, const float* const* scale,
+                               const float* const* shift, int n, float slope, int accumulate,
+                               float* out, long npix, int Cs, void* stream) {
+    if (!a || !out || n < 1 || n > 4 || (Cs & 3) || Cs <= 0 || slope == 0.f) AMX_BADARG(1);
+    DilSumArgs p;
+    for (int k = 0; k < 4; ++k) {
+        p.a[k] = k < n ? a[k] : nullptr;
+        p.scale[k] = (k < n && scale) ? scale[k] : nullptr;
+        p.shift[k] = (k < n && shift) ? shift[k] : nullptr;
+    }
+    p.n = n; p.accumulate = accumulate; p.inv_slope = 1.0f / slope;
+    const size_t n4 = (size_t)npix * (Cs / 4);
+    AMX_LAUNCH(dilated_sum_kernel, GRID_FOR(n4), dim3(256), 0, (hipStream_t)stream, p, out, n4, Cs / 4);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

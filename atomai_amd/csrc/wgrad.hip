@@ -1,0 +1,268 @@
+// wgrad.hip — weight gradient of the 3x3 / dilated / 1x1 convolutions on fp32 MFMA.
+//
+//   dW[co][ci][tap] = sum over pixels p of  dpre[p][co] * xin[p + tap*dil][ci]
+// where xin is the layer input as the forward pass saw it: BN affine of the producer applied on load,
+// two concatenated sources (skip | upsampled), zero padding.   (autograd of nn.Conv2d in
+// atomai/nets/blocks.py:63-67, 304-310; the reference gets it from ATen's conv backward.)
+//
+// GEMM view per tap: M = ci (16-tiles), N = co (16-tiles), K = pixels.  v_mfma_f32_16x16x4_f32 with
+// A[i = ci][k = pixel], B[k = pixel][j = co]: one k-step = 4 consecutive pixels of an image row.
+// A workgroup keeps an (8 x 16)-pixel tile of dpre and the matching halo tile of xin in LDS
+// (pixel-major, channel stride == 16 mod 32 floats so that the fragment reads `ds_read_b32` are
+// conflict free) and sweeps all taps against the SAME B fragments, so 9*NT MFMAs are issued per
+// (NT + 9) LDS reads.  Waves split the ci tiles (WM), co tiles (WN) and pixel rows (WK).
+// Split-K over workgroups; every (workgroup, wk) writes its own partial row which
+// amx_wgrad_reduce (conv1.hip) sums in fp64 -> deterministic, no float atomics.
+#include "amx_device.h"
+
+#define TW 16
+#define TH 8
+
+struct WgradArgs {
+    const float* x0; const float* sc0; const float* sh0; int C0s;
+    const float* x1; const float* sc1; const float* sh1; int C1s;
+    const float* dpre; int Dos;      // stored channels of dpre
+    float* part;                     // [rows][taps][ci_pad][co_pad]
+    int N, H, W, dil;
+    int ci_pad, co_pad;              // multiples of 16
+    int WN, WK;                      // wave grid (WM is a template parameter)
+    int ksplit, tiles_x, tiles_y;
+    int co_blocks;
+};
+
+template <int TAPS, int NT, int WM, int MAXHALO>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int CIB = 16 * WM;
+    constexpr int CG = CIB / 4;                                   // float4 groups per pixel (x)
+    constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;         // == 16 mod 32
+    constexpr int MAXPIX = (TH + 2 * MAXHALO) * (TW + 2 * MAXHALO);
+    constexpr int XLD = (MAXPIX * CG + 255) / 256;
+    AMX_DYN_SMEM(float, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int IW = TW + 2 * halo, IH = TH + 2 * halo;
+    const int COB = 16 * NT * a.WN;
+    const int DG = COB / 4;                                       // float4 groups per pixel (dpre)
+    const int SD = (COB % 32 == 16) ? COB : COB + 16;
+    float* s_x = smem;                                            // [IH*IW][SX]
+    float* s_d = smem + (size_t)IH * IW * SX;                     // [TH*TW][SD]
+
+    const int wm = wave % WM;
+    const int wn = (wave / WM) % a.WN;
+    const int wk = wave / (WM * a.WN);
+    const int cb = blockIdx.y / a.co_blocks, ob = blockIdx.y % a.co_blocks;
+    const int ci0 = cb * CIB;                                     // first concat-padded input channel
+    const int co0 = ob * COB;
+
+    // x loader: this thread always handles channel group xg of the block
+    const int xg = tid % CG;
+    const int ch = ci0 + xg * 4;
+    const float* xsrc = nullptr; int xCs = 0, xc = 0;
+    float4 r_sc = make_float4(1, 1, 1, 1), r_sh = make_float4(0, 0, 0, 0);
+    if (ch < a.C0s) { xsrc = a.x0; xCs = a.C0s; xc = ch; if (a.sc0) { r_sc = amx_ld4(a.sc0 + xc); r_sh = amx_ld4(a.sh0 + xc); } }
+    else if (ch - a.C0s < a.C1s) { xsrc = a.x1; xCs = a.C1s; xc = ch - a.C0s; if (a.sc1) { r_sc = amx_ld4(a.sc1 + xc); r_sh = amx_ld4(a.sh1 + xc); } }
+    const int npix_x = IH * IW;
+    const int nd4 = TH * TW * DG;                                 // float4 loads of the dpre tile
+    constexpr int DLD_MAX = (TH * TW * 16 + 255) / 256;           // COB <= 64 -> DG <= 16
+
+    float4 xr[XLD];
+    float4 dr[DLD_MAX];
+    unsigned xvalid = 0;
+
+    auto issue = [&](int tile) {
+        int t = tile;
+        const int tx = t % a.tiles_x; t /= a.tiles_x;
+        const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
+        const int gy0 = ty * TH - halo, gx0 = tx * TW - halo;
+        xvalid = 0;
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            const int pix = (tid + i * 256) / CG;
+            xr[i] = make_float4(0, 0, 0, 0);
+            if (pix < npix_x && xsrc) {
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int gy = gy0 + iy, gx = gx0 + ix;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    xr[i] = amx_ld4(xsrc + ((size_t)(n * a.H + gy) * a.W + gx) * xCs + xc);
+                    xvalid |= 1u << i;
+                }
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < DLD_MAX; ++i) {
+            const int idx = tid + i * 256;
+            dr[i] = make_float4(0, 0, 0, 0);
+            if (idx < nd4) {
+                const int pix = idx / DG, dg = idx - pix * DG;
+                const int iy = pix / TW, ix = pix - iy * TW;
+                const int gy = ty * TH + iy, gx = tx * TW + ix;
+                const int c = co0 + dg * 4;
+                if (gy < a.H && gx < a.W && c < a.Dos)
+                    dr[i] = amx_ld4(a.dpre + ((size_t)(n * a.H + gy) * a.W + gx) * a.Dos + c);
+            }
+        }
+    };
+    auto stage = [&]() {
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            const int pix = (tid + i * 256) / CG;
+            if (pix < npix_x) {
+                float4 v = xr[i];
+                if (xvalid & (1u << i)) {
+                    v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
+                    v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                }
+                amx_st4(s_x + (size_t)pix * SX + xg * 4, v);
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < DLD_MAX; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nd4) {
+                const int pix = idx / DG, dg = idx - pix * DG;
+                amx_st4(s_d + (size_t)pix * SD + dg * 4, dr[i]);
+            }
+        }
+    };
+
+    f32x4 acc[TAPS][NT];
+    #pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = a.tiles_x * a.tiles_y * a.N;
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += a.ksplit) {
+        stage();
+        __syncthreads();
+        if (tile + a.ksplit < ntiles) issue(tile + a.ksplit);
+        for (int r = wk; r < TH; r += a.WK) {
+            #pragma unroll
+            for (int kx = 0; kx < TW / 4; ++kx) {
+                float bf[NT];
+                #pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    bf[q] = s_d[(size_t)(r * TW + kx * 4 + g) * SD + (wn * NT + q) * 16 + p];
+                #pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int dy = (TAPS == 9) ? (t / 3 - 1) * a.dil : 0;
+                    const int dx = (TAPS == 9) ? (t % 3 - 1) * a.dil : 0;
+                    const float af = s_x[(size_t)((r + halo + dy) * IW + kx * 4 + g + halo + dx) * SX + wm * 16 + p];
+                    #pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[q], acc[t][q], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // D fragment: row (ci) = 4*g + reg, col (co) = p.  Partial row index = blockIdx.x * WK + wk.
+    const size_t row = (size_t)blockIdx.x * a.WK + wk;
+    #pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int co = co0 + (wn * NT + q) * 16 + p;
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = ci0 + wm * 16 + 4 * g + r;
+                if (ci < a.ci_pad && co < a.co_pad)
+                    a.part[((row * TAPS + t) * a.ci_pad + ci) * a.co_pad + co] = acc[t][q][r];
+            }
+        }
+}
+
+template <int TAPS, int NT, int WM, int MAXHALO>
+static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
+    constexpr int CIB = 16 * WM;
+    constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;
+    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int COB = 16 * NT * a.WN;
+    const int SD = (COB % 32 == 16) ? COB : COB + 16;
+    const size_t lds = ((size_t)(TH + 2 * halo) * (TW + 2 * halo) * SX + (size_t)TH * TW * SD) * sizeof(float);
+    dim3 grid(a.ksplit, amx_ceil_div(a.ci_pad, CIB) * a.co_blocks);
+#ifndef AMX_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TAPS, NT, WM, MAXHALO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+#endif
+    AMX_LAUNCH((wgrad_kernel<TAPS, NT, WM, MAXHALO>), grid, dim3(256), lds, stream, a);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+struct WgradPlan { int NT, WM, WN, WK, ksplit, rows, ci_pad, co_pad; };
+
+static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, int dil) {
+    WgradPlan pl;
+    pl.ci_pad = amx_round_up(Cin_s, 16);
+    pl.co_pad = amx_round_up(cout, 16);
+    pl.NT = pl.co_pad >= 32 ? 2 : 1;
+    pl.WM = pl.ci_pad >= 64 ? 4 : (pl.ci_pad >= 32 ? 2 : 1);
+    if (taps == 9 && dil > 1) pl.WM = 1;
+    const int rem = 4 / pl.WM;
+    const int co_tiles = pl.co_pad / (16 * pl.NT);                // wave-level co tiles needed
+    pl.WN = 1;
+    while (pl.WN * 2 <= rem && pl.WN * 2 <= co_tiles && 16 * pl.NT * pl.WN * 2 <= 64) pl.WN *= 2;
+    pl.WK = rem / pl.WN;
+    const int blocks = amx_ceil_div(pl.ci_pad, 16 * pl.WM) * amx_ceil_div(pl.co_pad, 16 * pl.NT * pl.WN);
+    const int ntiles = amx_ceil_div(W, TW) * amx_ceil_div(H, TH) * N;
+    int ks = amx_ceil_div(1024, blocks);
+    if (ks > ntiles) ks = ntiles;
+    if (ks < 1) ks = 1;
+    pl.ksplit = ks;
+    pl.rows = ks * pl.WK;
+    return pl;
+}
+
+// rows / floats of the partial buffer amx_conv2d_wgrad needs
+extern "C" int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil) {
+    return plan_wgrad(N, H, W, Cin_s, cout, taps, dil).rows;
+}
+
+extern "C" int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* sh0, int C0s,
+                                const float* x1, const float* sc1, const float* sh1, int C1s,
+                                const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
+                                int taps, int dil, void* stream) {
+    if (!x0 || !dpre || !part) AMX_BADARG(1);
+    if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
+    if ((C0s & 3) || (C1s & 3) || (Dos & 3) || C0s <= 0 || Dos < cout) AMX_BADARG(3);
+    if (taps != 1 && taps != 9) AMX_BADARG(4);
+    if (taps == 9 && (dil < 1 || dil > 6)) AMX_BADARG(5);
+    if ((x1 == nullptr) != (C1s == 0)) AMX_BADARG(6);
+    const WgradPlan pl = plan_wgrad(N, H, W, C0s + C1s, cout, taps, dil);
+    WgradArgs a;
+    a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
+    a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
+    a.dpre = dpre; a.Dos = Dos; a.part = part;
+    a.N = N; a.H = H; a.W = W; a.dil = dil;
+    a.ci_pad = pl.ci_pad; a.co_pad = pl.co_pad;
+    a.WN = pl.WN; a.WK = pl.WK; a.ksplit = pl.ksplit;
+    a.tiles_x = amx_ceil_div(W, TW); a.tiles_y = amx_ceil_div(H, TH);
+    a.co_blocks = amx_ceil_div(pl.co_pad, 16 * pl.NT * pl.WN);
+    hipStream_t s = (hipStream_t)stream;
+#define WG_DISPATCH(T, H_)                                                         \
+    if (pl.NT == 1) {                                                              \
+        if (pl.WM == 1) return launch_wgrad<T, 1, 1, H_>(a, s);                     \
+        if (pl.WM == 2) return launch_wgrad<T, 1, 2, H_>(a, s);                     \
+        return launch_wgrad<T, 1, 4, H_>(a, s);                                     \
+    } else {                                                                       \
+        if (pl.WM == 1) return launch_wgrad<T, 2, 1, H_>(a, s);                     \
+        if (pl.WM == 2) return launch_wgrad<T, 2, 2, H_>(a, s);                     \
+        return launch_wgrad<T, 2, 4, H_>(a, s);                                     \
+    }
+    if (taps == 1) { WG_DISPATCH(1, 0) }
+    if (dil == 1) { WG_DISPATCH(9, 1) }
+    if (pl.NT == 1) return launch_wgrad<9, 1, 1, 6>(a, s);
+    return launch_wgrad<9, 2, 1, 6>(a, s);
+#undef WG_DISPATCH
+}

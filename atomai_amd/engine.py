@@ -1,0 +1,501 @@
+"""Define-by-run tape over the HIP kernels (include/atomai_amd.h): forward AND hand-written backward.
+
+Why not torch.autograd per op: the fused pipeline passes *lazy* activations between layers — the raw
+post-LeakyReLU tensor plus the producer's BatchNorm (scale, shift), which the consumer applies while
+loading (conv_fwd.hip).  Gradients are therefore defined w.r.t. the *normalised* value while the tensor
+that exists in HBM is the raw one; a hand-written backward keeps that bookkeeping explicit and lets
+dgrad / wgrad / BN-backward share buffers.  The whole tape is exposed to PyTorch as ONE
+autograd.Function (nets/_function.py), so ``loss.backward()`` / ``optimizer.step()`` work unchanged
+(atomai/trainers/trainer.py:201-207).
+
+Everything here is plumbing: shapes, workspaces (torch allocator), launch order.  All arithmetic is in
+the kernels.  No CPU fallback exists; `_lib` raises if the extension is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def r4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def r16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+# generation counter bumped by the fused optimizer (it writes weights through raw pointers, which does
+# not touch torch's version counters); part of the packed-weight cache key
+_weight_generation = [0]
+
+
+def bump_weight_generation() -> None:
+    _weight_generation[0] += 1
+
+
+class Act:
+    """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
+    per-channel affine of the producing BatchNorm (None == identity)."""
+    __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad")
+
+    def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
+        self.t = t
+        self.N, self.H, self.W, self.Cs = t.shape
+        self.C = C
+        self.scale, self.shift = scale, shift
+        self.grad: Optional[torch.Tensor] = None      # d loss / d (normalised value), NHWC
+        self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
+        self.needs_grad = needs_grad
+
+    @property
+    def npix(self) -> int:
+        return self.N * self.H * self.W
+
+
+class _PackCache:
+    """Packed weight images keyed by (storage, version, optimizer generation, layout)."""
+
+    def __init__(self):
+        self.store: Dict[tuple, tuple] = {}
+
+    def get(self, w: torch.Tensor, key_extra: tuple, build):
+        key = (id(w),) + key_extra
+        ver = (w.data_ptr(), w._version, _weight_generation[0])
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = build()
+        self.store[key] = (ver, val)
+        return val
+
+
+_pack_cache = _PackCache()
+
+
+def _empty(shape, like: torch.Tensor, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _sp(t):
+    return L.stream_ptr(t)
+
+
+def pack_weights(w: torch.Tensor, C0, C0s, C1, C1s, taps, mode) -> torch.Tensor:
+    def build():
+        n = L.load().amx_pack_weights_size(w.shape[0], C0s, C1s, taps, mode)
+        dst = _empty((n,), w)
+        L.call("amx_pack_weights", L.ptr(w.detach()), L.ptr(dst), w.shape[0], C0, C0s, C1, C1s, taps,
+               mode, _sp(w))
+        return dst
+    return _pack_cache.get(w, (C0, C0s, C1, C1s, taps, mode), build)
+
+
+def padded_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    """bias vector zero-padded to n (cached like the packed weights)."""
+    def build():
+        out = torch.zeros(n, dtype=torch.float32, device=v.device)
+        out[: v.numel()].copy_(v.detach())
+        return out
+    return _pack_cache.get(v, ("pad", n), build)
+
+
+# ====================================================================================== nodes
+class _Node:
+    def backward(self, tape: "Tape") -> None:
+        raise NotImplementedError
+
+
+class ConvNode(_Node):
+    """conv (3x3 / dilated / 1x1) [+bias] [+LeakyReLU] [+BatchNorm statistics] over 1 or 2 sources."""
+
+    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None):
+        self.srcs = list(srcs)
+        self.conv, self.bn, self.slope = conv, bn, float(slope)
+        self.x_plain = x_plain                           # (N,1,H,W) tensor for the Cin==1 kernel
+        w = conv.weight
+        self.cout = w.shape[0]
+        self.taps = w.shape[2] * w.shape[3]
+        assert self.taps in (1, 9) and w.shape[2] == w.shape[3], "3x3 or 1x1 kernels only"
+        self.dil = int(conv.dilation[0]) if self.taps == 9 else 1
+        assert tuple(conv.stride) == (1, 1)
+        if self.taps == 9:
+            assert int(conv.padding[0]) == self.dil and int(conv.padding[1]) == self.dil, \
+                "padding must equal dilation ('same' convolution)"
+        else:
+            assert tuple(conv.padding) == (0, 0)
+        self.out = self._forward(tape)
+
+    # -------------------------------------------------------------------------------- forward
+    def _forward(self, tape) -> Act:
+        w, b = self.conv.weight, self.conv.bias
+        cos, cop = r4(self.cout), r16(self.cout)
+        training_bn = self.bn is not None and tape.training
+        if self.x_plain is not None:
+            x = self.x_plain
+            N, _, H, W = x.shape
+            y = _empty((N, H, W, cos), x)
+            npix = N * H * W
+            self.rows = L.load().amx_rows_for(npix)
+            self.rows_pix = L.load().amx_rows_pix(npix)
+            stats = _empty((self.rows, 2, cop), x) if training_bn else None
+            L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
+                   L.ptr(y), L.ptr(stats), N, H, W, self.cout, cos, self.dil, self.slope, self.rows,
+                   self.rows_pix, _sp(x))
+            stat_mode = 1
+        else:
+            s0 = self.srcs[0]
+            s1 = self.srcs[1] if len(self.srcs) > 1 else None
+            N, H, W = s0.N, s0.H, s0.W
+            C0, C0s = s0.C, s0.Cs
+            C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
+            assert w.shape[1] == C0 + C1, "channel mismatch between conv weight and its sources"
+            wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 0)
+            bias = padded_vec(b, cop) if b is not None else None
+            y = _empty((N, H, W, cos), s0.t)
+            self.rows = L.load().amx_conv2d_num_tiles(N, H, W)
+            self.rows_pix = 0
+            stats = _empty((self.rows, 2, cop), s0.t) if training_bn else None
+            L.call("amx_conv2d_fwd", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+                   L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+                   L.ptr(s1.shift if s1 else None), C1s, L.ptr(wpk), L.ptr(bias), None,
+                   L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
+                   self.slope, _sp(y))
+            stat_mode = 0
+        scale = shift = None
+        if self.bn is not None:
+            bn = self.bn
+            scale, shift = _empty((cos,), y), _empty((cos,), y)
+            if tape.training:
+                self.save_mean, self.save_invstd = _empty((cos,), y), _empty((cos,), y)
+                mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+                L.call("amx_bn_finalize", L.ptr(stats), self.rows, cop, stat_mode, N, H, W, self.rows_pix,
+                       L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
+                       L.ptr(bn.running_var), mom, bn.eps, self.cout, cos, L.ptr(scale), L.ptr(shift),
+                       L.ptr(self.save_mean), L.ptr(self.save_invstd), _sp(y))
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+            else:
+                L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
+                       L.ptr(bn.running_mean), L.ptr(bn.running_var), bn.eps, self.cout, cos,
+                       L.ptr(scale), L.ptr(shift), _sp(y))
+        needs = tape.need_grad
+        return Act(y, self.cout, scale, shift, needs_grad=needs)
+
+    # -------------------------------------------------------------------------------- backward
+    def backward(self, tape) -> None:
+        out = self.out
+        dy = out.grad if out.grad is not None else out.gx
+        if dy is None:
+            return                                        # output never used downstream
+        a = out.t
+        npix, cos = out.npix, out.Cs
+        rows = L.load().amx_rows_for(npix)
+        sp = _sp(a)
+        has_bias = self.conv.bias is not None
+        bias_part = _empty((rows, cos), a) if has_bias else None
+        training_bn = self.bn is not None and tape.training
+        if self.bn is not None and not tape.training:
+            raise L.AmxError("backward through eval-mode BatchNorm is not on the hot path")
+        if training_bn:
+            bn = self.bn
+            part = _empty((rows, 2, cos), a)
+            L.call("amx_bn_bwd_reduce", L.ptr(dy), L.ptr(a), npix, cos, L.ptr(part), sp)
+            dgamma, dbeta = _empty((self.cout,), a), _empty((self.cout,), a)
+            k = _empty((3, cos), a)
+            L.call("amx_bn_bwd_finalize", L.ptr(part), rows, cos, self.cout, npix,
+                   L.ptr(bn.weight.detach()), L.ptr(self.save_mean), L.ptr(self.save_invstd),
+                   L.ptr(dgamma), L.ptr(dbeta), L.ptr(k[0]), L.ptr(k[1]), L.ptr(k[2]), sp)
+            tape.add_param_grad(bn.weight, dgamma)
+            tape.add_param_grad(bn.bias, dbeta)
+            dpre = _empty(a.shape, a)
+            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), L.ptr(k[0]), L.ptr(k[1]),
+                   L.ptr(k[2]), self.slope, npix, cos, L.ptr(dpre), L.ptr(bias_part), sp)
+        elif self.slope != 1.0 or out.gx is not None or has_bias:
+            # dpre = gx + lrelu'(a) * (gx + dy)   (no BatchNorm); also yields the bias partial sums
+            inplace = self.slope == 1.0 and out.gx is None
+            dpre = dy if inplace else _empty(a.shape, a)
+            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), None, None, None,
+                   self.slope, npix, cos, L.ptr(dpre), L.ptr(bias_part), sp)
+        else:
+            dpre = dy
+        if has_bias:
+            db = _empty((self.cout,), a)
+            L.call("amx_reduce_rows", L.ptr(bias_part), rows, cos, self.cout, 1.0, L.ptr(db), sp)
+            tape.add_param_grad(self.conv.bias, db)
+        w = self.conv.weight
+        dw = _empty(w.shape, a)
+        if self.x_plain is not None:
+            x = self.x_plain
+            N, _, H, W = x.shape
+            part = _empty((self.rows, 9, cos), a)
+            L.call("amx_conv1_wgrad", L.ptr(x), L.ptr(dpre), L.ptr(part), N, H, W, cos, self.dil,
+                   self.rows, self.rows_pix, sp)
+            L.call("amx_wgrad_reduce", L.ptr(part), self.rows, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
+            tape.add_param_grad(w, dw)
+            return
+        s0 = self.srcs[0]
+        s1 = self.srcs[1] if len(self.srcs) > 1 else None
+        N, H, W = s0.N, s0.H, s0.W
+        C0, C0s = s0.C, s0.Cs
+        C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
+        wrows = L.load().amx_conv2d_wgrad_rows(N, H, W, C0s + C1s, self.cout, self.taps, self.dil)
+        ci_pad, co_pad = r16(C0s + C1s), r16(self.cout)
+        part = _empty((wrows, self.taps, ci_pad, co_pad), a)
+        L.call("amx_conv2d_wgrad", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+               L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+               L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), cos, L.ptr(part), N, H, W, self.cout,
+               self.taps, self.dil, sp)
+        L.call("amx_wgrad_reduce", L.ptr(part), wrows, self.taps, ci_pad, co_pad, C0, C0s, C1, self.cout,
+               L.ptr(dw), sp)
+        tape.add_param_grad(w, dw)
+        # ---- data gradient(s): forward conv of dpre with the flipped / transposed weight image
+        need0 = s0.needs_grad
+        need1 = bool(s1 and s1.needs_grad)
+        if not (need0 or need1):
+            return
+        wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 1)
+        tgt = []
+        for s in (s0, s1):
+            if s is None:
+                tgt.append((None, None))
+                continue
+            if s.grad is None:
+                s.grad = _empty(s.t.shape, s.t)
+                tgt.append((s.grad, s.gx))               # first writer; DilatedBlock adds its gx here
+            else:
+                tgt.append((s.grad, s.grad))             # accumulate in place
+        add0 = tgt[0][1]
+        if s1 is not None and tgt[1][1] is not None:
+            # the kernel accumulates only into its first output: pre-add the second one
+            scratch = _empty(s1.t.shape, s1.t)
+            y1 = scratch
+        else:
+            scratch, y1 = None, tgt[1][0]
+        L.call("amx_conv2d_fwd", L.ptr(dpre), None, None, cos, None, None, None, 0, L.ptr(wpk), None,
+               L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, None, N, H, W, C0s + C1s, self.taps,
+               self.dil, 1.0, sp)
+        if scratch is not None:
+            L.call("amx_add_inplace", L.ptr(tgt[1][0]), L.ptr(scratch), scratch.numel(), sp)
+
+
+class PoolNode(_Node):
+    def __init__(self, tape, src: Act):
+        self.src = src
+        y = _empty((src.N, src.H // 2, src.W // 2, src.Cs), src.t)
+        L.call("amx_pool2x2_fwd", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(y), src.N,
+               src.H, src.W, src.Cs, _sp(y))
+        self.out = Act(y, src.C, needs_grad=src.needs_grad)
+
+    def backward(self, tape) -> None:
+        s, g = self.src, self.out.grad
+        if g is None or not s.needs_grad:
+            return
+        skip = s.grad
+        if s.grad is None:
+            s.grad = _empty(s.t.shape, s.t)
+            skip = s.gx
+        L.call("amx_pool2x2_bwd", L.ptr(g), L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift), L.ptr(skip),
+               L.ptr(s.grad), s.N, s.H, s.W, s.Cs, _sp(g))
+
+
+class UpsampleNode(_Node):
+    def __init__(self, tape, src: Act, mode: str):
+        assert src.scale is None, "upsample expects a materialised (affine-free) activation"
+        self.src, self.mode = src, {"bilinear": 0, "nearest": 1}[mode]
+        y = _empty((src.N, 2 * src.H, 2 * src.W, src.Cs), src.t)
+        L.call("amx_upsample2x_fwd", L.ptr(src.t), L.ptr(y), src.N, src.H, src.W, src.Cs, self.mode, _sp(y))
+        self.out = Act(y, src.C, needs_grad=src.needs_grad)
+
+    def backward(self, tape) -> None:
+        s, g = self.src, self.out.grad
+        if g is None or not s.needs_grad:
+            return
+        dv = _empty(s.t.shape, s.t)
+        L.call("amx_upsample2x_bwd", L.ptr(g), L.ptr(dv), s.N, s.H, s.W, s.Cs, self.mode, _sp(g))
+        tape.accumulate(s, dv)
+
+
+class DilatedSumNode(_Node):
+    """out = sum_i (pre_i + a_i + bn_i) over the layers of a DilatedBlock (blocks.py:321-329)."""
+
+    def __init__(self, tape, acts: Sequence[Act], slope: float):
+        self.acts, self.slope = list(acts), slope
+        a0 = acts[0]
+        y = _empty(a0.t.shape, a0.t)
+        PP = ctypes.c_void_p * 4
+        for i in range(0, len(acts), 4):
+            grp = acts[i:i + 4]
+            pa = PP(*[x.t.data_ptr() for x in grp] + [0] * (4 - len(grp)))
+            ps = PP(*[(x.scale.data_ptr() if x.scale is not None else 0) for x in grp] + [0] * (4 - len(grp)))
+            ph = PP(*[(x.shift.data_ptr() if x.shift is not None else 0) for x in grp] + [0] * (4 - len(grp)))
+            L.call("amx_dilated_sum", pa, ps, ph, len(grp), slope, 1 if i else 0, L.ptr(y), a0.npix,
+                   a0.Cs, _sp(y))
+        self.out = Act(y, a0.C, needs_grad=a0.needs_grad)
+
+    def backward(self, tape) -> None:
+        g = self.out.grad
+        if g is None:
+            return
+        for a in self.acts:
+            assert a.grad is None and a.gx is None
+            a.gx = g
+
+
+class InputNode(_Node):
+    """NCHW tensor at the module boundary -> NHWC activation."""
+
+    def __init__(self, tape, x: torch.Tensor):
+        N, C, H, W = x.shape
+        self.x_shape = x.shape
+        cs = r4(C)
+        t = _empty((N, H, W, cs), x)
+        L.call("amx_nchw_to_nhwc", L.ptr(x.detach().contiguous()), L.ptr(t), N, C, cs, H, W, _sp(x))
+        self.out = Act(t, C, needs_grad=bool(x.requires_grad and tape.need_grad))
+        self.grad_nchw = None
+
+    def backward(self, tape) -> None:
+        a = self.out
+        g = a.grad if a.grad is not None else a.gx
+        if not a.needs_grad or g is None:
+            return
+        N, C, H, W = self.x_shape
+        out = _empty(self.x_shape, a.t)
+        L.call("amx_nhwc_to_nchw", L.ptr(g), L.ptr(out), N, C, a.Cs, H, W, _sp(out))
+        self.grad_nchw = out
+
+
+class OutputNode(_Node):
+    """NHWC activation (pending affine materialised) -> NCHW tensor at the module boundary."""
+
+    def __init__(self, tape, src: Act):
+        self.src = src
+        t = src.t
+        if src.scale is not None:
+            t = _empty(src.t.shape, src.t)
+            L.call("amx_affine_nhwc", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(t), src.npix,
+                   src.Cs, _sp(t))
+        self.value = _empty((src.N, src.C, src.H, src.W), t)
+        L.call("amx_nhwc_to_nchw", L.ptr(t), L.ptr(self.value), src.N, src.C, src.Cs, src.H, src.W, _sp(t))
+        self.grad_out: Optional[torch.Tensor] = None
+
+    def backward(self, tape) -> None:
+        s = self.src
+        if self.grad_out is None or not s.needs_grad:
+            return
+        g = _empty(s.t.shape, s.t)
+        L.call("amx_nchw_to_nhwc", L.ptr(self.grad_out.contiguous()), L.ptr(g), s.N, s.C, s.Cs, s.H, s.W,
+               _sp(g))
+        tape.accumulate(s, g)
+
+
+class PxNode(_Node):
+    """Final 1x1 conv to nb_classes; logits NCHW (mode 0) or probabilities NHWC (mode 1)."""
+
+    def __init__(self, tape, src: Act, conv, mode: int = 0):
+        self.src, self.conv = src, conv
+        K = conv.weight.shape[0]
+        assert conv.weight.shape[1] == src.C and conv.weight.shape[2:] == (1, 1)
+        self.K = K
+        shape = (src.N, K, src.H, src.W) if mode == 0 else (src.N, src.H, src.W, K)
+        self.value = _empty(shape, src.t)
+        L.call("amx_px_fwd", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift),
+               L.ptr(conv.weight.detach()), L.ptr(conv.bias.detach()), L.ptr(self.value), src.N, src.H,
+               src.W, src.C, src.Cs, K, mode, _sp(src.t))
+        self.grad_out: Optional[torch.Tensor] = None
+
+    def backward(self, tape) -> None:
+        s, dl = self.src, self.grad_out
+        if dl is None:
+            return
+        dl = dl.contiguous()
+        rows = L.load().amx_rows_for(s.npix)
+        rows_pix = L.load().amx_rows_pix(s.npix)
+        dxn = _empty(s.t.shape, s.t)
+        part = _empty((rows, self.K, s.Cs), s.t)
+        partb = _empty((rows, self.K), s.t)
+        sp = _sp(dl)
+        L.call("amx_px_bwd", L.ptr(dl), L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift),
+               L.ptr(self.conv.weight.detach()), L.ptr(dxn), L.ptr(part), L.ptr(partb), s.N, s.H, s.W,
+               s.C, s.Cs, self.K, rows, rows_pix, sp)
+        dw = _empty((self.K * s.Cs,), s.t)
+        L.call("amx_reduce_rows", L.ptr(part), rows, self.K * s.Cs, self.K * s.Cs, 1.0, L.ptr(dw), sp)
+        db = _empty((self.K,), s.t)
+        L.call("amx_reduce_rows", L.ptr(partb), rows, self.K, self.K, 1.0, L.ptr(db), sp)
+        tape.add_param_grad(self.conv.weight, dw.view(self.K, s.Cs)[:, : s.C].reshape(self.K, s.C, 1, 1))
+        tape.add_param_grad(self.conv.bias, db)
+        if s.needs_grad:
+            tape.accumulate(s, dxn)
+
+
+# ====================================================================================== tape
+class Tape:
+    def __init__(self, training: bool, need_grad: bool):
+        self.training = training
+        self.need_grad = need_grad
+        self.nodes: List[_Node] = []
+        self.param_grads: Dict[int, tuple] = {}
+
+    # ---- graph construction (each call launches the forward kernels immediately)
+    def _push(self, node):
+        if self.need_grad:
+            self.nodes.append(node)
+        return node
+
+    def input(self, x: torch.Tensor) -> InputNode:
+        return self._push(InputNode(self, x))
+
+    def conv(self, srcs, conv, bn=None, slope: float = 1.0) -> Act:
+        return self._push(ConvNode(self, srcs, conv, bn, slope)).out
+
+    def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0) -> Act:
+        return self._push(ConvNode(self, [], conv, bn, slope, x_plain=x_plain.detach().contiguous())).out
+
+    def pool(self, src: Act) -> Act:
+        return self._push(PoolNode(self, src)).out
+
+    def upsample(self, src: Act, mode: str) -> Act:
+        return self._push(UpsampleNode(self, src, mode)).out
+
+    def dilated_sum(self, acts, slope) -> Act:
+        return self._push(DilatedSumNode(self, acts, slope)).out
+
+    def output(self, src: Act) -> OutputNode:
+        return self._push(OutputNode(self, src))
+
+    def px(self, src: Act, conv, mode: int = 0) -> PxNode:
+        return self._push(PxNode(self, src, conv, mode))
+
+    # ---- backward helpers
+    def accumulate(self, act: Act, g: torch.Tensor) -> None:
+        if act.grad is None:
+            if act.gx is not None:
+                L.call("amx_add_inplace", L.ptr(g), L.ptr(act.gx), g.numel(), _sp(g))
+            act.grad = g
+        else:
+            L.call("amx_add_inplace", L.ptr(act.grad), L.ptr(g), g.numel(), _sp(g))
+
+    def add_param_grad(self, p: torch.Tensor, g: torch.Tensor) -> None:
+        key = id(p)
+        if key in self.param_grads:
+            prev = self.param_grads[key][1]
+            gg = g.contiguous()
+            n = gg.numel()
+            if n % 4 == 0:
+                L.call("amx_add_inplace", L.ptr(prev), L.ptr(gg), n, _sp(gg))
+            else:
+                prev.add_(gg)
+        else:
+            self.param_grads[key] = (p, g.contiguous())
+
+    def backward(self) -> None:
+        for node in reversed(self.nodes):
+            node.backward(self)
+        self.nodes = []

@@ -1,0 +1,102 @@
+"""Segmentation losses on the HIP path (reference: atomai/losses_metrics/losses.py:139-174).
+
+``select_loss('ce', nb_classes)`` returns a module with the same call signature as
+``torch.nn.CrossEntropyLoss()`` / ``torch.nn.BCEWithLogitsLoss()`` (mean reduction), whose forward is ONE
+kernel that also produces d loss / d logits, so ``loss.backward()`` costs nothing extra on this op.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        N, K = logits.shape[0], logits.shape[1]
+        HW = logits[0, 0].numel()
+        x = logits.detach().contiguous()
+        t = target.contiguous()
+        need = logits.requires_grad
+        dl = torch.empty_like(x) if need else None
+        rows = max(1, min(1024, (N * HW + 255) // 256))
+        part = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.call("amx_ce_fwd_bwd", L.ptr(x), L.ptr(t), L.ptr(dl), L.ptr(part), rows, N, K, HW,
+               L.stream_ptr(x))
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.call("amx_reduce_rows", L.ptr(part), rows, 1, 1, 1.0 / (N * HW), L.ptr(loss), L.stream_ptr(x))
+        ctx.dl = dl
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, ctx.dl = ctx.dl, None
+        return dl * g, None
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.detach().contiguous()
+        t = target.detach().contiguous().to(torch.float32)
+        n = x.numel()
+        need = logits.requires_grad
+        dl = torch.empty_like(x) if need else None
+        rows = max(1, min(1024, (n + 255) // 256))
+        part = torch.empty(rows, dtype=torch.float32, device=x.device)
+        L.call("amx_bce_fwd_bwd", L.ptr(x), L.ptr(t), L.ptr(dl), L.ptr(part), rows, n, L.stream_ptr(x))
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        L.call("amx_reduce_rows", L.ptr(part), rows, 1, 1, 1.0 / n, L.ptr(loss), L.stream_ptr(x))
+        ctx.dl = dl
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, ctx.dl = ctx.dl, None
+        return dl * g, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """torch.nn.CrossEntropyLoss() semantics: logits (N,K,H,W), int64 targets (N,H,W), mean."""
+
+    def forward(self, logits, target):
+        if target.dtype != torch.int64 or logits.ndim < 3 or target.shape != logits.shape[:1] + logits.shape[2:]:
+            raise ValueError("expected logits (N,K,...) and int64 targets (N,...)")
+        return _CEFn.apply(logits, target)
+
+    def __repr__(self):
+        return "CrossEntropyLoss()"
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """torch.nn.BCEWithLogitsLoss() semantics (mean over all elements)."""
+
+    def forward(self, logits, target):
+        if target.shape != logits.shape:
+            raise ValueError(f"Target size ({target.shape}) must be the same as input size ({logits.shape})")
+        return _BCEFn.apply(logits, target)
+
+    def __repr__(self):
+        return "BCEWithLogitsLoss()"
+
+
+def select_loss(loss: str, nb_classes: int = None, **kwargs):
+    """Same selection logic and error behaviour as the reference (losses.py:139-174) for the losses on
+    the hot path ('ce', callables); the others are outside this build's scope."""
+    if loss in ['ce', 'multitask'] and nb_classes is None:
+        raise ValueError("For cross-entropy loss function, you must specify the number of classes")
+    if loss == 'ce' and nb_classes == 1:
+        return BCEWithLogitsLoss()
+    if loss == 'ce' and nb_classes > 2:
+        return CrossEntropyLoss()
+    if loss == 'mse':
+        return torch.nn.MSELoss()
+    if hasattr(loss, "__call__"):
+        return loss
+    if loss in ('dice', 'focal', 'nll', 'multitask_nll', 'multitask_ce'):
+        raise NotImplementedError(f"loss '{loss}' is outside the MI355X hot path of this build")
+    raise NotImplementedError(
+        "Select Dice loss ('dice'), focal loss ('focal') "
+        " cross-entropy loss ('ce'), means-squared error ('mse'),"
+        " multitask loss (multitask_nll and multitask_ce)"
+        " or pass your custom loss function")

@@ -1,0 +1,161 @@
+"""Drop-in Unet / dilnet / init_fcnn_model (reference: atomai/nets/fcnn.py:18-226, 379-442)."""
+from typing import List, Type, Union
+
+import torch
+import torch.nn as nn
+
+from .blocks import ConvBlock, DilatedBlock, UpsampleBlock
+from ._function import run_tape
+
+
+class _HipNet(nn.Module):
+    def _build(self, tape, x):
+        raise NotImplementedError
+
+    def _modular(self, x):
+        raise NotImplementedError
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # Utilities such as get_downsample_factor hook every top-level child and need it invoked via
+        # __call__ (atomai/utils/nn.py:215-228): honour that with the block-by-block path.
+        if any(len(m._forward_hooks) or len(m._forward_pre_hooks) for m in self.children()):
+            return self._modular(x)
+        return run_tape(self._build, x, list(self.parameters()), self.training)
+
+
+class Unet(_HipNet):
+    """U-Net: c1-pool-c2-pool-c3-pool-bn-up1-cat-c4-up2-cat-c5-up3-cat-c6-px (fcnn.py:18-142)."""
+
+    def __init__(self, nb_classes: int = 1, nb_filters: int = 16, dropout: bool = False,
+                 batch_norm: bool = True, upsampling_mode: str = "bilinear", with_dilation: bool = False,
+                 **kwargs: List[int]) -> None:
+        super().__init__()
+        nbl = kwargs.get("layers", [1, 2, 2, 3])
+        dilation_values = torch.arange(2, 2 * nbl[-1] + 1, 2).tolist()
+        padding_values = dilation_values.copy()
+        dropout_vals = [.1, .2, .1] if dropout else [0, 0, 0]
+        self.c1 = ConvBlock(2, nbl[0], 1, nb_filters, batch_norm=batch_norm)
+        self.c2 = ConvBlock(2, nbl[1], nb_filters, nb_filters * 2, batch_norm=batch_norm)
+        self.c3 = ConvBlock(2, nbl[2], nb_filters * 2, nb_filters * 4, batch_norm=batch_norm,
+                            dropout_=dropout_vals[0])
+        if with_dilation:
+            self.bn = DilatedBlock(2, nb_filters * 4, nb_filters * 8, dilation_values=dilation_values,
+                                   padding_values=padding_values, batch_norm=batch_norm,
+                                   dropout_=dropout_vals[1])
+        else:
+            self.bn = ConvBlock(2, nbl[3], nb_filters * 4, nb_filters * 8, batch_norm=batch_norm,
+                                dropout_=dropout_vals[1])
+        self.upsample_block1 = UpsampleBlock(2, nb_filters * 8, nb_filters * 4, mode=upsampling_mode)
+        self.c4 = ConvBlock(2, nbl[2], nb_filters * 8, nb_filters * 4, batch_norm=batch_norm,
+                            dropout_=dropout_vals[2])
+        self.upsample_block2 = UpsampleBlock(2, nb_filters * 4, nb_filters * 2, mode=upsampling_mode)
+        self.c5 = ConvBlock(2, nbl[1], nb_filters * 4, nb_filters * 2, batch_norm=batch_norm)
+        self.upsample_block3 = UpsampleBlock(2, nb_filters * 2, nb_filters, mode=upsampling_mode)
+        self.c6 = ConvBlock(2, nbl[0], nb_filters * 2, nb_filters, batch_norm=batch_norm)
+        self.px = nn.Conv2d(nb_filters, nb_classes, 1, 1, 0)
+
+    def _build(self, tape, x, px_mode: int = 0):
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise AssertionError("Unet needs H and W divisible by 8 (three 2x2 poolings); "
+                                 "SegPredictor pads inputs accordingly")
+        node, c1 = self.c1._emit_input(tape, x)
+        d1 = tape.pool(c1)
+        c2 = self.c2._emit(tape, [d1])
+        d2 = tape.pool(c2)
+        c3 = self.c3._emit(tape, [d2])
+        d3 = tape.pool(c3)
+        bn = self.bn._emit(tape, [d3])
+        u3 = self.upsample_block1._emit(tape, [bn])
+        u3 = self.c4._emit(tape, [c3, u3])
+        u2 = self.upsample_block2._emit(tape, [u3])
+        u2 = self.c5._emit(tape, [c2, u2])
+        u1 = self.upsample_block3._emit(tape, [u2])
+        u1 = self.c6._emit(tape, [c1, u1])
+        return node, tape.px(u1, self.px, px_mode)
+
+    def _modular(self, x):
+        import torch.nn.functional as F   # only glue between separately-emitted HIP blocks
+        c1 = self.c1(x)
+        d1 = F.max_pool2d(c1, 2, 2)
+        c2 = self.c2(d1)
+        d2 = F.max_pool2d(c2, 2, 2)
+        c3 = self.c3(d2)
+        d3 = F.max_pool2d(c3, 2, 2)
+        bn = self.bn(d3)
+        u3 = self.c4(torch.cat([c3, self.upsample_block1(bn)], dim=1))
+        u2 = self.c5(torch.cat([c2, self.upsample_block2(u3)], dim=1))
+        u1 = self.c6(torch.cat([c1, self.upsample_block3(u2)], dim=1))
+        return self.px(u1)
+
+
+class dilnet(_HipNet):
+    """c1-pool-at1-at2-up1-cat(c1,u1)-c2-px (fcnn.py:145-226)."""
+
+    def __init__(self, nb_classes: int = 1, nb_filters: int = 25, dropout: bool = False,
+                 batch_norm: bool = True, upsampling_mode: str = "bilinear", **kwargs: List[int]) -> None:
+        super().__init__()
+        nbl = kwargs.get("layers", [3, 3, 3, 3])
+        dilation_values_1 = torch.arange(2, 2 * nbl[1] + 1, 2).tolist()
+        padding_values_1 = dilation_values_1.copy()
+        dilation_values_2 = torch.arange(2, 2 * nbl[2] + 1, 2).tolist()
+        padding_values_2 = dilation_values_2.copy()
+        dropout_vals = [.3, .3] if dropout else [0, 0]
+        self.c1 = ConvBlock(2, nbl[0], 1, nb_filters, batch_norm=batch_norm)
+        self.at1 = DilatedBlock(2, nb_filters, nb_filters * 2, dilation_values=dilation_values_1,
+                                padding_values=padding_values_1, batch_norm=batch_norm,
+                                dropout_=dropout_vals[0])
+        self.at2 = DilatedBlock(2, nb_filters * 2, nb_filters * 2, dilation_values=dilation_values_2,
+                                padding_values=padding_values_2, batch_norm=batch_norm,
+                                dropout_=dropout_vals[1])
+        self.up1 = UpsampleBlock(2, nb_filters * 2, nb_filters, mode=upsampling_mode)
+        self.c2 = ConvBlock(2, nbl[3], nb_filters * 2, nb_filters, batch_norm=batch_norm)
+        self.px = nn.Conv2d(nb_filters, nb_classes, 1, 1, 0)
+
+    def _build(self, tape, x, px_mode: int = 0):
+        if x.shape[2] % 2 or x.shape[3] % 2:
+            raise AssertionError("dilnet needs even H and W (one 2x2 pooling)")
+        node, c1 = self.c1._emit_input(tape, x)
+        d1 = tape.pool(c1)
+        at1 = self.at1._emit(tape, [d1])
+        at2 = self.at2._emit(tape, [at1])
+        u1 = self.up1._emit(tape, [at2])
+        u1 = self.c2._emit(tape, [c1, u1])
+        return node, tape.px(u1, self.px, px_mode)
+
+    def _modular(self, x):
+        import torch.nn.functional as F
+        c1 = self.c1(x)
+        d1 = F.max_pool2d(c1, 2, 2)
+        u1 = self.up1(self.at2(self.at1(d1)))
+        return self.px(self.c2(torch.cat([c1, u1], dim=1)))
+
+
+def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwargs):
+    """Factory + meta_state_dict, same keys as the reference (fcnn.py:379-442)."""
+    if not isinstance(model, str) and hasattr(model, "state_dict"):
+        meta_state_dict = {'model_type': 'Seg', model: 'custom', 'nb_classes': nb_classes}
+        return model, meta_state_dict
+    batch_norm = kwargs.get('batch_norm', True)
+    dropout = kwargs.get('dropout', False)
+    upsampling = kwargs.get('upsampling', kwargs.get('upsampling_mode', "bilinear"))
+    meta_state_dict = {'model_type': 'seg', 'model': model, 'nb_classes': nb_classes,
+                       'batch_norm': batch_norm, 'dropout': dropout, 'upsampling': upsampling}
+    if isinstance(model, str) and model == 'Unet':
+        with_dilation = kwargs.get('with_dilation', False)
+        nb_filters = kwargs.get('nb_filters', 16)
+        layers = kwargs.get("layers", [1, 2, 2, 3])
+        net = Unet(nb_classes, nb_filters, dropout, batch_norm, upsampling, with_dilation, layers=layers)
+        meta_state_dict["with_dilation"] = with_dilation
+    elif isinstance(model, str) and model == 'dilnet':
+        nb_filters = kwargs.get('nb_filters', 25)
+        layers = kwargs.get("layers", [1, 3, 3, 1])
+        net = dilnet(nb_classes, nb_filters, dropout, batch_norm, upsampling, layers=layers)
+    elif isinstance(model, str) and model in ('SegResNet', 'ResHedNet'):
+        raise NotImplementedError(f"'{model}' is outside the MI355X hot path of this build "
+                                  "(SURVEY.md §8-f rank 4); use 'Unet' or 'dilnet'")
+    else:
+        raise NotImplementedError(
+            "Currently implemented models are 'Unet', 'dilnet', SegResNet', and 'ResHedNet'")
+    meta_state_dict["nb_filters"] = nb_filters
+    meta_state_dict["layers"] = layers
+    return net, meta_state_dict

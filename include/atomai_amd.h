@@ -1,0 +1,113 @@
+/* atomai_amd.h — C ABI of libatomai_amd.so: the MI355X (gfx950) hot path of pycroscopy/atomai.
+ *
+ * The reference has NO native/FFI interface (it is pure Python on stock PyTorch), so
+ * the seam these entry points replace is the set of ATen operator calls made by the reference's
+ * nn.Modules and loss callables on the Segmentor / rVAE / DKL paths.  Each entry point cites the
+ * reference lines whose work it takes over.  The Python host (atomai_amd/*.py, mirroring the
+ * reference's module/trainer API) binds this header with ctypes (atomai_amd/_lib.py parses THIS file).
+ *
+ * Conventions
+ *   - plain C: pointers, ints, floats; no torch / C++ types.  Every function returns int:
+ *       0 = ok, >0 = hipError_t from the launch, <0 = -(index of the offending argument group).
+ *   - the caller owns all memory (device pointers of torch-allocated buffers, incl. workspaces);
+ *     nothing allocates, nothing synchronises; the last argument is the hipStream_t to launch on.
+ *   - activations are NHWC fp32 with the channel count padded to a multiple of 4 ("Cs"), padding
+ *     channels hold zeros.  Weights stay OIHW fp32 at the ABI (state-dict layout) and are re-imaged by
+ *     amx_pack_weights.  "scale/shift" pairs are the producer's BatchNorm affine, applied by the
+ *     consumer while loading (zero padding stays zero after the affine).
+ */
+#ifndef ATOMAI_AMD_H
+#define ATOMAI_AMD_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution: nn.Conv2d(k=3|1, padding=dilation) + bias + LeakyReLU + BN batch statistics,
+ * reading torch.cat([src0, src1], 1) with each source's BN affine applied on load.
+ * atomai/nets/blocks.py:61-76 (ConvBlock), :122-132 (UpsampleBlock 1x1), :300-318 (DilatedBlock);
+ * atomai/nets/fcnn.py:132-138,223 (cat).  Also the data-gradient engine (weights packed with mode 1):
+ * y/y1 are then the gradients w.r.t. src0/src1.  stats: [amx_conv2d_num_tiles][2][round_up(cout,16)]. */
+int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
+                   const float* x1, const float* sc1, const float* sh1, int C1s,
+                   const float* wpk, const float* bias, const float* addend,
+                   float* y, int Y0s, float* y1, int Y1s, float* stats,
+                   int N, int H, int W, int cout, int taps, int dil, float slope, void* stream);
+int amx_conv2d_num_tiles(int N, int H, int W);
+
+/* weight gradient of the same convolution (autograd of nn.Conv2d; trainer.py:205 loss.backward()).
+ * part: [amx_conv2d_wgrad_rows][taps][round_up(C0s+C1s,16)][round_up(cout,16)] partial rows. */
+int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* sh0, int C0s,
+                     const float* x1, const float* sc1, const float* sh1, int C1s,
+                     const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
+                     int taps, int dil, void* stream);
+int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
+int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,
+                     int C1, int Cout, float* dw, void* stream);
+
+/* first layer, Cin == 1 (Conv2d(1, F, 3) of c1: fcnn.py:66-69,186-189) and its weight gradient */
+int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+                  int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows, int rows_pix,
+                  void* stream);
+int amx_conv1_wgrad(const float* x, const float* dpre, float* part, int N, int H, int W, int Cs,
+                    int dil, int rows, int rows_pix, void* stream);
+
+/* OIHW -> MFMA weight image (mode 0 forward, 1 dgrad) and NCHW<->NHWC at the module boundary */
+int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C0, int C0s, int C1, int C1s,
+                     int taps, int mode, void* stream);
+long amx_pack_weights_size(int cout, int C0s, int C1s, int taps, int mode);
+int amx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
+int amx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
+int amx_add_inplace(float* dst, const float* src, long n, void* stream);
+
+/* ---- BatchNorm2d after LeakyReLU (blocks.py:71-75; torch defaults eps 1e-5, momentum 0.1) */
+int amx_bn_finalize(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int C, int Cs, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, void* stream);
+int amx_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                       float eps, int C, int Cs, float* scale, float* shift, void* stream);
+int amx_affine_nhwc(const float* a, const float* scale, const float* shift, float* y, long npix, int Cs,
+                    void* stream);
+int amx_rows_for(long npix);
+int amx_rows_pix(long npix);
+int amx_bn_bwd_reduce(const float* dy, const float* a, long npix, int Cs, float* part, void* stream);
+int amx_bn_bwd_finalize(const float* part, int rows, int Cs, int C, long npix, const float* gamma,
+                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                        float* k1, float* k2, float* k3, void* stream);
+int amx_bn_bwd_apply(const float* dy, const float* a, const float* gx, const float* k1, const float* k2,
+                     const float* k3, float slope, long npix, int Cs, float* dpre, float* part,
+                     void* stream);
+int amx_reduce_rows(const float* part, int rows, int stride, int C, float scale, float* out, void* stream);
+
+/* ---- F.max_pool2d(x,2,2) (fcnn.py:123-127,219), F.interpolate x2 (blocks.py:130-131), DilatedBlock sum
+ * (blocks.py:321-329).  mode: 0 bilinear (align_corners=False), 1 nearest. */
+int amx_pool2x2_fwd(const float* a, const float* scale, const float* shift, float* d, int N, int H, int W,
+                    int Cs, void* stream);
+int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const float* shift,
+                    const float* skip, float* dy, int N, int H, int W, int Cs, void* stream);
+int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode, void* stream);
+int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int w, int Cs, int mode, void* stream);
+int amx_dilated_sum(const float* const* a, const float* const* scale, const float* const* shift, int n,
+                    float slope, int accumulate, float* out, long npix, int Cs, void* stream);
+
+/* ---- head: px = Conv2d(F, nb_classes, 1) (fcnn.py:115,212); losses select_loss('ce')
+ * (losses_metrics/losses.py:152-155) fused fwd+bwd; mode 1 of px = SegPredictor.forward_ probabilities
+ * (predictors/predictor.py:219-229) */
+int amx_px_fwd(const float* a, const float* scale, const float* shift, const float* w, const float* b,
+               float* out, int N, int H, int W, int C, int Cs, int K, int mode, void* stream);
+int amx_px_bwd(const float* dl, const float* a, const float* scale, const float* shift, const float* w,
+               float* dxn, float* part, float* partb, int N, int H, int W, int C, int Cs, int K, int rows,
+               int rows_pix, void* stream);
+int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits, float* part, int rows,
+                   int N, int K, long HW, void* stream);
+int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
+                    long numel, void* stream);
+
+/* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
+int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                  float eps, double bc1, double bc2, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,7 +8,7 @@ mkdir -p build
 for f in $SRC/*.hip; do
   o=build/$(basename $f .hip).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ hip_emu.h -nt $o ] || [ $SRC/amx_device.h -nt $o ]; then
-    g++ -O2 -g -std=c++17 -fPIC -DAMX_EMU -I. -I$SRC -x c++ -c $f -o $o &
+    g++ -O2 -g -std=c++17 -Wno-psabi -fPIC -DAMX_EMU -I. -I$SRC -x c++ -c $f -o $o &
   fi
   OBJS="$OBJS $o"
 done
