@@ -35,13 +35,14 @@ struct ConvFwdArgs {
     const float* x0; const float* sc0; const float* sh0; int C0s;
     const float* x1; const float* sc1; const float* sh1; int C1s;
     const float* wpk;    // [nchunk][taps][KG][cop][4]
-    const float* bias;   // [cop] or nullptr
+    const float* bias;   // [cout] or nullptr
     const float* addend; // optional tensor (same shape as y) added to the first output, or nullptr
     float* y;  int Y0s;  // first  output: stored channels Y0s, receives couts [0, Y0s)
     float* y1; int Y1s;  // second output (dgrad of a concat) receives couts [Y0s, Y0s+Y1s), or nullptr
     float* stats;        // [tiles][2][cop] (sum, M2) or nullptr
     int N, H, W;
-    int cop;             // Cout rounded up to 16
+    int cout;            // real number of output channels
+    int cop;             // cout rounded up to 16
     int nchunk;
     int dil;             // dilation (== halo) for 9 taps; ignored for 1 tap
     float slope;         // LeakyReLU negative slope; 1.0f == no activation
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     #pragma unroll
     for (int q = 0; q < NT; ++q) {
         const int co = n0 + q * 16 + p;
-        const float b = (a.bias && co < a.cop) ? a.bias[co] : 0.f;
+        const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
         float* dst = nullptr; int Cd = 0, cd = 0;
         if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; }
         else if (co < ctot) { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
@@ -304,6 +305,7 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     a.wpk = wpk; a.bias = bias; a.addend = addend;
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
     a.N = N; a.H = H; a.W = W;
+    a.cout = cout;
     a.cop = amx_round_up(cout, 16);
     a.nchunk = amx_ceil_div(C0s + C1s, 4 * KG);
     a.dil = dil; a.slope = slope;

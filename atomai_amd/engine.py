@@ -88,6 +88,15 @@ def _sp(t):
     return L.stream_ptr(t)
 
 
+def grad_buffer(p: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """Where a kernel should write d loss / d p: the optimizer's flat-bucket view when the parameter has
+    one and no gradient is pending accumulation (optim.FusedAdam), else a fresh tensor."""
+    v = getattr(p, "_amx_grad", None)
+    if v is not None and p.grad is None and v.shape == p.shape and v.device == like.device:
+        return v
+    return torch.empty(p.shape, dtype=torch.float32, device=like.device)
+
+
 def pack_weights(w: torch.Tensor, C0, C0s, C1, C1s, taps, mode) -> torch.Tensor:
     def build():
         n = L.load().amx_pack_weights_size(w.shape[0], C0s, C1s, taps, mode)
@@ -158,7 +167,7 @@ class ConvNode(_Node):
             C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
             assert w.shape[1] == C0 + C1, "channel mismatch between conv weight and its sources"
             wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 0)
-            bias = padded_vec(b, cop) if b is not None else None
+            bias = b.detach() if b is not None else None
             y = _empty((N, H, W, cos), s0.t)
             self.rows = L.load().amx_conv2d_num_tiles(N, H, W)
             self.rows_pix = 0
@@ -208,7 +217,7 @@ class ConvNode(_Node):
             bn = self.bn
             part = _empty((rows, 2, cos), a)
             L.call("amx_bn_bwd_reduce", L.ptr(dy), L.ptr(a), npix, cos, L.ptr(part), sp)
-            dgamma, dbeta = _empty((self.cout,), a), _empty((self.cout,), a)
+            dgamma, dbeta = grad_buffer(bn.weight, a), grad_buffer(bn.bias, a)
             k = _empty((3, cos), a)
             L.call("amx_bn_bwd_finalize", L.ptr(part), rows, cos, self.cout, npix,
                    L.ptr(bn.weight.detach()), L.ptr(self.save_mean), L.ptr(self.save_invstd),
@@ -227,11 +236,11 @@ class ConvNode(_Node):
         else:
             dpre = dy
         if has_bias:
-            db = _empty((self.cout,), a)
+            db = grad_buffer(self.conv.bias, a)
             L.call("amx_reduce_rows", L.ptr(bias_part), rows, cos, self.cout, 1.0, L.ptr(db), sp)
             tape.add_param_grad(self.conv.bias, db)
         w = self.conv.weight
-        dw = _empty(w.shape, a)
+        dw = grad_buffer(w, a)
         if self.x_plain is not None:
             x = self.x_plain
             N, _, H, W = x.shape
@@ -427,7 +436,7 @@ class PxNode(_Node):
                s.C, s.Cs, self.K, rows, rows_pix, sp)
         dw = _empty((self.K * s.Cs,), s.t)
         L.call("amx_reduce_rows", L.ptr(part), rows, self.K * s.Cs, self.K * s.Cs, 1.0, L.ptr(dw), sp)
-        db = _empty((self.K,), s.t)
+        db = grad_buffer(self.conv.bias, s.t)
         L.call("amx_reduce_rows", L.ptr(partb), rows, self.K, self.K, 1.0, L.ptr(db), sp)
         tape.add_param_grad(self.conv.weight, dw.view(self.K, s.Cs)[:, : s.C].reshape(self.K, s.C, 1, 1))
         tape.add_param_grad(self.conv.bias, db)

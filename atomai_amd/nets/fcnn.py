@@ -159,3 +159,14 @@ def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwarg
     meta_state_dict["nb_filters"] = nb_filters
     meta_state_dict["layers"] = layers
     return net, meta_state_dict
+
+
+def predict_proba(net: _HipNet, x: torch.Tensor) -> torch.Tensor:
+    """Eval-mode forward returning class probabilities in NHWC — sigmoid (1 class) / softmax fused into
+    the px kernel together with the NCHW->NHWC permute of SegPredictor.forward_
+    (atomai/predictors/predictor.py:219-229)."""
+    from ..engine import Tape
+    assert not net.training
+    with torch.no_grad():
+        tape = Tape(False, False)
+        return net._build(tape, x, px_mode=1)[1].value

@@ -1,0 +1,3 @@
+from .predictor import BasePredictor, SegPredictor
+
+__all__ = ["BasePredictor", "SegPredictor"]

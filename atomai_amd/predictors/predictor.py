@@ -1,0 +1,174 @@
+"""BasePredictor / SegPredictor (reference: atomai/predictors/predictor.py:23-298).
+
+Same constructor arguments and numpy-in / numpy-out behaviour.  The frame loop of the reference (one
+frame per launch, synchronous H2D/D2H, host ``torch.zeros`` of the whole output) is replaced by a
+chunked pipeline: pinned staging buffers, H2D / kernels / D2H of consecutive chunks overlapped on HIP
+streams.  In eval mode BatchNorm uses running statistics, so frames are independent and the result does
+not depend on how the stack is chunked (``num_batches`` keeps its meaning for the caller only).
+"""
+import time
+from typing import Dict, List, Tuple, Type, Union
+
+import numpy as np
+import torch
+
+from ..nets.fcnn import _HipNet, predict_proba
+from ..utils import get_downsample_factor, get_nb_classes, img_pad, set_train_rng, torch_format_image
+
+
+class BasePredictor:
+    def __init__(self, model: Type[torch.nn.Module] = None, use_gpu: bool = False, **kwargs) -> None:
+        self.model = model
+        self.device = "cpu"
+        if use_gpu and torch.cuda.is_available():
+            self.device = kwargs.get("device") or "cuda"
+        if self.model is not None:
+            self.model.to(self.device)
+        self.verbose = kwargs.get("verbose", False)
+
+    def preprocess(self, data):
+        if isinstance(data, np.ndarray):
+            data = torch.from_numpy(data).float()
+        return data
+
+    def _model2device(self, device: str = None) -> None:
+        self.model.to(device or self.device)
+
+    def _data2device(self, data: torch.Tensor, device: str = None) -> torch.Tensor:
+        return data.to(device or self.device)
+
+    def forward_(self, xnew: torch.Tensor) -> torch.Tensor:
+        self.model.eval()
+        with torch.no_grad():
+            return self.model(xnew.to(self.device))
+
+    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int) -> torch.Tensor:
+        """Batch-by-batch prediction into a host tensor (predictor.py:82-106)."""
+        bs = max(1, len(data) // max(1, num_batches))
+        out = torch.empty(out_shape)
+        for i in range(0, len(data), bs):
+            out[i:i + bs] = self.forward_(data[i:i + bs]).cpu()
+        return out
+
+    def predict(self, data: torch.Tensor, out_shape: Tuple[int] = None, num_batches: int = 1):
+        out_shape = data.shape if out_shape is None else (data.shape[0], *out_shape)
+        return self.batch_predict(self.preprocess(data), out_shape, num_batches)
+
+
+class SegPredictor(BasePredictor):
+    """Prediction with a trained segmentation net (predictor.py:124-298)."""
+
+    def __init__(self, trained_model: Type[torch.nn.Module], refine: bool = False,
+                 resize: Union[Tuple, List] = None, use_gpu: bool = False, logits: bool = True,
+                 **kwargs: Union[int, float, bool]) -> None:
+        super().__init__(trained_model, use_gpu)
+        set_train_rng(1)
+        self.nb_classes = kwargs.get('nb_classes', None)
+        if self.nb_classes is None:
+            self.nb_classes = get_nb_classes(trained_model)
+        self.downsampling = kwargs.get('downsampling', None)
+        if self.downsampling is None:
+            self.downsampling = get_downsample_factor(trained_model)
+        self.resize = resize
+        self.logits = logits
+        self.refine = refine
+        self.d = kwargs.get("d", None)
+        self.thresh = kwargs.get("thresh", .5)
+        self.use_gpu = use_gpu
+        self.verbose = kwargs.get("verbose", True)
+        self.chunk_bytes = int(kwargs.get("chunk_bytes", 256 << 20))
+
+    def preprocess(self, image_data: np.ndarray, norm: bool = True) -> torch.Tensor:
+        if image_data.ndim == 2:
+            image_data = image_data[np.newaxis, ...]
+        elif image_data.ndim == 4:
+            if image_data.shape[-1] == 1:
+                image_data = image_data[..., 0]
+            elif image_data.shape[1] == 1:
+                image_data = image_data[:, 0, ...]
+        if self.resize is not None:
+            raise NotImplementedError("resize needs cv2 (outside the MI355X hot path of this build)")
+        image_data = img_pad(image_data, self.downsampling)
+        return torch_format_image(image_data, norm)
+
+    def forward_(self, images: torch.Tensor) -> torch.Tensor:
+        """Probabilities (N,H,W,C) for a batch already on / moved to the model's device."""
+        images = images.to(self.device)
+        self.model.eval()
+        if isinstance(self.model, _HipNet) and self.logits:
+            return predict_proba(self.model, images)
+        with torch.no_grad():
+            prob = self.model(images)
+        if self.logits:
+            prob = torch.softmax(prob, dim=1) if self.nb_classes > 1 else torch.sigmoid(prob)
+        elif self.nb_classes > 1:
+            prob = torch.exp(prob)
+        return prob.permute(0, 2, 3, 1)
+
+    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int) -> torch.Tensor:
+        if not (torch.cuda.is_available() and str(self.device).startswith("cuda")):
+            return super().batch_predict(data, out_shape, num_batches)
+        n = len(data)
+        out = torch.empty(out_shape)
+        per_frame = max(data[0].numel(), int(np.prod(out_shape[1:]))) * 4
+        chunk = max(1, min(n, self.chunk_bytes // per_frame))
+        dev = torch.device(self.device)
+        copy_in, copy_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        pin_in = [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(2)]
+        pin_out = [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(2)]
+        pending = [None, None]                      # per staging slot: (event, start, count)
+
+        def drain(slot):
+            if pending[slot] is not None:
+                ev, ps, pm = pending[slot]
+                ev.synchronize()
+                out[ps:ps + pm] = pin_out[slot][:pm]
+                pending[slot] = None
+
+        for k, s in enumerate(range(0, n, chunk)):
+            slot, m = k % 2, min(chunk, n - s)
+            drain(slot)                             # the slot's buffers are free again after this
+            pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of chunk k-1
+            with torch.cuda.stream(copy_in):
+                d = pin_in[slot][:m].to(dev, non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(copy_in)
+            main.wait_event(ev_in)
+            prob = self.forward_(d)
+            d.record_stream(main)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(copy_out):
+                copy_out.wait_event(done)
+                pin_out[slot][:m].copy_(prob, non_blocking=True)
+                prob.record_stream(copy_out)
+                ev_out = torch.cuda.Event()
+                ev_out.record(copy_out)
+            pending[slot] = (ev_out, s, m)
+        drain(0)
+        drain(1)
+        return out
+
+    def predict(self, image_data: np.ndarray, return_image: bool = False, **kwargs: int):
+        image_data = self.preprocess(image_data, kwargs.get("norm", True))
+        n, _, w, h = image_data.shape
+        num_batches = kwargs.get("num_batches")
+        if num_batches is None:
+            num_batches = len(image_data) if (w >= 256 or h >= 256) else 10
+        segmented = self.batch_predict(image_data, (n, w, h, self.nb_classes), num_batches)
+        if return_image:
+            return image_data.permute(0, 2, 3, 1).numpy(), segmented.numpy()
+        return segmented.numpy()
+
+    def run(self, image_data: np.ndarray, compute_coords=True, **kwargs: int):
+        start_time = time.time()
+        if compute_coords:
+            raise NotImplementedError("coordinate extraction (Locator: cv2 + scipy.ndimage on the CPU) is "
+                                      "the next widening step (SURVEY.md §8-f rank 1); pass "
+                                      "compute_coords=False")
+        decoded = self.predict(image_data, **kwargs)
+        if self.verbose:
+            print(f"\n{decoded.shape[0]} image(s) decoded in approximately "
+                  f"{np.around(time.time() - start_time, decimals=4)} seconds")
+        return decoded

@@ -1,0 +1,138 @@
+"""Shared bodies of the Segmentor parity tests.  The SAME checks run
+  * on the CPU through the SIMT emulator build of the kernel sources (`not gpu` tier), and
+  * on a real MI355X through libatomai_amd.so (`gpu` tier),
+against golden vectors generated from the real reference (tests/golden, oracle/make_golden.py)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "seg_unet_c3_nf4_b2_32": ("Unet", dict()),
+    "seg_unet_c1_nf4_b2_16_nearest": ("Unet", dict(upsampling="nearest")),
+    "seg_unet_dil_c3_nf4_b2_32": ("Unet", dict(with_dilation=True)),
+    "seg_dilnet_c1_nf5_b2_32": ("dilnet", dict()),
+}
+REL_TOL = 1e-4          # north_star: "within 1e-4 rel fp32"
+
+
+def relmax(a, ref):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def check_net_case(name, device):
+    from atomai_amd.nets import init_fcnn_model
+    from atomai_amd.losses_metrics import select_loss
+    from atomai_amd.optim import FusedAdam
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    ncls, nf, B, H, seed, dil = [int(v) for v in g["meta"]]
+    model, kw = CASES[name]
+    torch.manual_seed(seed)                                  # set_train_rng(seed) of the reference
+    net, meta = init_fcnn_model(model, ncls, nb_filters=nf, **kw)
+    for k, v in net.state_dict().items():                    # RNG-order initialisation == reference
+        assert np.array_equal(v.numpy(), g[k + "|init"]), k
+    assert meta["model"] == model and meta["nb_classes"] == ncls
+    net.to(device)
+    x = torch.from_numpy(g["x"]).to(device)
+    y = torch.from_numpy(g["y"]).to(device)
+    crit = select_loss("ce", ncls)
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    opt.prepare()
+    losses = []
+    for s in range(3):
+        net.train()
+        opt.zero_grad()
+        logits = net(x)
+        loss = crit(logits, y)
+        loss.backward()
+        if s == 0:
+            assert relmax(logits.detach().cpu().numpy(), g["logits|f64"]) < REL_TOL
+            gmax = max(np.abs(g[k + "|grad|f64"]).max() for k, _ in net.named_parameters())
+            for k, p in net.named_parameters():
+                ref = g[k + "|grad|f64"]
+                err = np.abs(p.grad.cpu().numpy() - ref).max() / gmax
+                ref32 = np.abs(g[k + "|grad|f32"] - ref).max() / gmax
+                # gradients: judged against fp64, normalised by the global gradient scale and relative to
+                # the reference's own fp32 noise (SURVEY.md §7 "Parity budget")
+                assert err <= max(4 * ref32, 2e-5), (k, err, ref32)
+        opt.step()
+        if s == 0:
+            for k, v in net.state_dict().items():
+                if "running" in k:
+                    np.testing.assert_allclose(v.cpu().numpy(), g[k + "|bn1|f64"], rtol=REL_TOL, atol=1e-6)
+                if "num_batches_tracked" in k:
+                    assert int(v) == 1
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses|f64"], rtol=REL_TOL)
+    # the optimizer state keeps torch.optim.Adam's format
+    st = opt.state_dict()["state"]
+    assert set(st[0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(st[0]["step"]) == 3
+    net.eval()
+    with torch.no_grad():
+        ev = net(x).cpu().numpy()
+    ref = g["eval_logits|f32"]
+    assert relmax(ev, ref.astype(np.float64)) < 2e-2        # parameters after Adam steps: loose
+
+
+def check_blocks(device):
+    from atomai_amd.nets import ConvBlock, DilatedBlock, UpsampleBlock
+    g = np.load(os.path.join(GOLD, "seg_blocks.npz"))
+    ctors = {
+        "convblock_bn": lambda: ConvBlock(2, 2, 6, 8, batch_norm=True),
+        "convblock_nobn_a01": lambda: ConvBlock(2, 2, 1, 8, lrelu_a=0.1),
+        "up_bilinear": lambda: UpsampleBlock(2, 8, 4, mode="bilinear"),
+        "up_nearest": lambda: UpsampleBlock(2, 8, 4, mode="nearest"),
+        "dilated_bn": lambda: DilatedBlock(2, 6, 8, [2, 4, 6], [2, 4, 6], batch_norm=True),
+    }
+    for name, ctor in ctors.items():
+        m = ctor()
+        sd = OrderedDict((k.split("|sd|")[1], torch.from_numpy(g[k])) for k in g.files
+                         if k.startswith(name + "|sd|"))
+        assert list(sd.keys()) == list(m.state_dict().keys()), name       # module tree / key names
+        m.load_state_dict(sd)
+        m.to(device)
+        for mode in ("train", "eval"):
+            # (the golden's eval pass ran after its training pass, i.e. with updated running statistics)
+            m.train(mode == "train")
+            x = torch.from_numpy(g[f"{name}|x"]).to(device).requires_grad_(True)
+            y = m(x)
+            assert relmax(y.detach().cpu().numpy(), g[f"{name}|y|{mode}|f64"]) < REL_TOL, (name, mode)
+            if mode == "eval" and "bn" in name:
+                continue        # backward through eval-mode BN is not on the hot path
+            m.zero_grad()
+            y.backward(torch.from_numpy(g[f"{name}|gy"]).to(device))
+            refx = g[f"{name}|gx|{mode}|f64"]
+            scale = max(np.abs(refx).max(), 1e-30)
+            e = np.abs(x.grad.cpu().numpy() - refx).max() / scale
+            e32 = np.abs(g[f"{name}|gx|{mode}|f32"] - refx).max() / scale
+            assert e <= max(4 * e32, 2e-5), (name, mode, "gx", e, e32)
+            for k, p in m.named_parameters():
+                ref = g[f"{name}|gp|{k}|{mode}|f64"]
+                sc = max(np.abs(ref).max(), 1e-30)
+                e = np.abs(p.grad.cpu().numpy() - ref).max() / sc
+                e32 = np.abs(g[f"{name}|gp|{k}|{mode}|f32"] - ref).max() / sc
+                assert e <= max(4 * e32, 5e-5), (name, mode, k, e, e32)
+
+
+def check_predict(device_is_gpu):
+    import atomai_amd as aoi
+    from atomai_amd.utils import img_pad, torch_format_image
+    g = np.load(os.path.join(GOLD, "seg_predict.npz"))
+    img = g["img"]
+    for f in (2, 8):
+        assert np.array_equal(img_pad(img.copy(), f), g[f"pad{f}"])
+        np.testing.assert_array_equal(torch_format_image(img_pad(img.copy(), f)).numpy(), g[f"fmt{f}"])
+    for model, ncls, nf in (("Unet", 3, 4), ("dilnet", 1, 5)):
+        torch.manual_seed(1)
+        net, _ = aoi.nets.init_fcnn_model(model, ncls, nb_filters=nf)
+        sd = OrderedDict((k.split("|sd|")[1], torch.from_numpy(g[k])) for k in g.files
+                         if k.startswith(model + "|sd|"))
+        net.load_state_dict(sd)
+        p = aoi.predictors.SegPredictor(net, use_gpu=device_is_gpu, nb_classes=ncls, verbose=False)
+        assert p.downsampling == (8 if model == "Unet" else 2)           # via hooks + mock forward
+        probs = p.run(img, compute_coords=False, num_batches=2)
+        assert probs.shape == g[f"{model}|probs"].shape
+        np.testing.assert_allclose(probs, g[f"{model}|probs"], rtol=REL_TOL, atol=1e-6)
