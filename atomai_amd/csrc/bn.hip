@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     const long P = (long)N * H * W;
+    const int planes = mode == 2 ? 3 : 2;
     auto row_count = [&](int r) -> double {
+        if (mode == 2) return (double)stats[((size_t)r * 3 + 2) * cop + c];
         if (mode == 0) {
             const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
             const int vx = min(16, W - tx * 16), vy = min(16, H - ty * 16);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         return (double)(left < rows_pix ? left : rows_pix);
     };
     double s = 0.0;
-    for (int r = tid; r < rows; r += 256) s += (double)stats[((size_t)r * 2) * cop + c];
+    for (int r = tid; r < rows; r += 256) s += (double)stats[((size_t)r * planes) * cop + c];
     red[tid] = s; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     const double mean = red[0] / (double)P;
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     double m2 = 0.0;
     for (int r = tid; r < rows; r += 256) {
         const double n = row_count(r);
-        const double mi = (double)stats[((size_t)r * 2) * cop + c] / n;
-        m2 += (double)stats[((size_t)r * 2 + 1) * cop + c] + n * (mi - mean) * (mi - mean);
+        if (n <= 0.0) continue;
+        const double mi = (double)stats[((size_t)r * planes) * cop + c] / n;
+        m2 += (double)stats[((size_t)r * planes + 1) * cop + c] + n * (mi - mean) * (mi - mean);
     }
     red[tid] = m2; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
@@ -86,7 +89,7 @@ extern "C" int amx_bn_finalize(const float* stats, int rows, int cop, int mode, 
                                float* save_invstd, void* stream) {
     if (!stats || !gamma || !beta || !scale || !shift || !save_mean || !save_invstd) AMX_BADARG(1);
     if (rows <= 0 || C <= 0 || Cs < C || cop < C) AMX_BADARG(2);
-    if (mode != 0 && (mode != 1 || rows_pix <= 0)) AMX_BADARG(3);
+    if (mode < 0 || mode > 2 || (mode == 1 && rows_pix <= 0)) AMX_BADARG(3);
     AMX_LAUNCH(bn_finalize_kernel, dim3(Cs), dim3(256), 0, (hipStream_t)stream, stats, rows, cop, mode,
                N, H, W, rows_pix, gamma, beta, running_mean, running_var, momentum, eps, C, Cs, scale,
                shift, save_mean, save_invstd);
@@ -311,6 +314,74 @@ extern "C" int amx_reduce_rows(const float* part, int rows, int stride, int C, f
     if (!part || !out || rows <= 0 || C <= 0 || stride < C) AMX_BADARG(1);
     AMX_LAUNCH(reduce_rows_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, part, rows, stride, C,
                scale, out);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------ stage-1 merges (coalesced, parallel)
+// Merges chunks of (sum, M2) rows into [RB][3][cop] rows (sum, M2 about the chunk mean, count) with Chan's
+// formula in fp64, so that amx_bn_finalize (mode 2) only has to walk RB rows per channel.
+__global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ stats, int rows,
+                                                            int cop, int mode, int N, int H, int W,
+                                                            int rows_pix, int chunk,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= cop) return;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const long P = (long)N * H * W;
+    const int r0 = blockIdx.y * chunk;
+    const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        double nr;
+        if (mode == 0) {
+            const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
+            nr = (double)(min(16, W - tx * 16) * min(16, H - ty * 16));
+        } else {
+            const long left = P - (long)r * rows_pix;
+            nr = (double)(left < rows_pix ? left : rows_pix);
+        }
+        const double mr = (double)stats[((size_t)r * 2) * cop + c] / nr;
+        const double m2r = (double)stats[((size_t)r * 2 + 1) * cop + c];
+        const double nt = n + nr, d = mr - mean;
+        mean += d * (nr / nt);
+        m2 += m2r + d * d * (n * nr / nt);
+        n = nt;
+    }
+    out[((size_t)blockIdx.y * 3 + 0) * cop + c] = (float)(mean * n);
+    out[((size_t)blockIdx.y * 3 + 1) * cop + c] = (float)m2;
+    out[((size_t)blockIdx.y * 3 + 2) * cop + c] = (float)n;
+}
+
+extern "C" int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W,
+                                  int rows_pix, int nchunks, float* out, void* stream) {
+    if (!stats || !out || rows <= 0 || cop <= 0 || nchunks <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
+    const int chunk = amx_ceil_div(rows, nchunks);
+    AMX_LAUNCH(bn_stats_merge_kernel, dim3(amx_ceil_div(cop, 64), amx_ceil_div(rows, chunk)), dim3(64), 0,
+               (hipStream_t)stream, stats, rows, cop, mode, N, H, W, rows_pix, chunk, out);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[b][c] = sum over the b-th chunk of rows of part[r][c]  (thread per column: coalesced)
+__global__ __launch_bounds__(256) void reduce_rows_chunked_kernel(const float* __restrict__ part, int rows,
+                                                                  long ncols, int chunk,
+                                                                  float* __restrict__ out) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    const int r0 = blockIdx.y * chunk;
+    const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    double a = 0.0;
+    for (int r = r0; r < r1; ++r) a += (double)part[(size_t)r * ncols + c];
+    out[(size_t)blockIdx.y * ncols + c] = (float)a;
+}
+
+extern "C" int amx_reduce_rows_chunked(const float* part, int rows, long ncols, int nchunks, float* out,
+                                       void* stream) {
+    if (!part || !out || rows <= 0 || ncols <= 0 || nchunks <= 0) AMX_BADARG(1);
+    const int chunk = amx_ceil_div(rows, nchunks);
+    AMX_LAUNCH(reduce_rows_chunked_kernel, dim3((unsigned)((ncols + 255) / 256), amx_ceil_div(rows, chunk)),
+               dim3(256), 0, (hipStream_t)stream, part, rows, ncols, chunk, out);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -185,7 +185,14 @@ class ConvNode(_Node):
             if tape.training:
                 self.save_mean, self.save_invstd = _empty((cos,), y), _empty((cos,), y)
                 mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
-                L.call("amx_bn_finalize", L.ptr(stats), self.rows, cop, stat_mode, N, H, W, self.rows_pix,
+                nrows = self.rows
+                if nrows > 512:          # two-stage merge: coalesced chunk merge first, then per channel
+                    nch = 128
+                    merged = _empty((nch, 3, cop), y)
+                    L.call("amx_bn_stats_merge", L.ptr(stats), nrows, cop, stat_mode, N, H, W,
+                           self.rows_pix, nch, L.ptr(merged), _sp(y))
+                    stats, nrows, stat_mode = merged, -(-nrows // -(-nrows // nch)), 2
+                L.call("amx_bn_finalize", L.ptr(stats), nrows, cop, stat_mode, N, H, W, self.rows_pix,
                        L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
                        L.ptr(bn.running_var), mom, bn.eps, self.cout, cos, L.ptr(scale), L.ptr(shift),
                        L.ptr(self.save_mean), L.ptr(self.save_invstd), _sp(y))
@@ -262,6 +269,12 @@ class ConvNode(_Node):
                L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
                L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), cos, L.ptr(part), N, H, W, self.cout,
                self.taps, self.dil, sp)
+        if wrows > 64:                   # two-stage: coalesced chunk sums first
+            nch = 32
+            ncols = self.taps * ci_pad * co_pad
+            part2 = _empty((nch, ncols), a)
+            L.call("amx_reduce_rows_chunked", L.ptr(part), wrows, ncols, nch, L.ptr(part2), sp)
+            part, wrows = part2, -(-wrows // -(-wrows // nch))
         L.call("amx_wgrad_reduce", L.ptr(part), wrows, self.taps, ci_pad, co_pad, C0, C0s, C1, self.cout,
                L.ptr(dw), sp)
         tape.add_param_grad(w, dw)

@@ -78,6 +78,9 @@ int amx_bn_bwd_apply(const float* dy, const float* a, const float* gx, const flo
                      const float* k3, float slope, long npix, int Cs, float* dpre, float* part,
                      void* stream);
 int amx_reduce_rows(const float* part, int rows, int stride, int C, float scale, float* out, void* stream);
+int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,
+                       int nchunks, float* out, void* stream);
+int amx_reduce_rows_chunked(const float* part, int rows, long ncols, int nchunks, float* out, void* stream);
 
 /* ---- F.max_pool2d(x,2,2) (fcnn.py:123-127,219), F.interpolate x2 (blocks.py:130-131), DilatedBlock sum
  * (blocks.py:321-329).  mode: 0 bilinear (align_corners=False), 1 nearest. */

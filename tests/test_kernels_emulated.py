@@ -1,0 +1,85 @@
+"""Unit checks (emulator) of kernels whose multi-stage paths only trigger at large sizes in the nets."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator():
+    if torch.cuda.is_available():
+        pytest.skip("emulator tier is for GPU-less hosts")
+    import emu_backend
+    emu_backend.use_emulator()
+
+
+def test_two_stage_bn_statistics_equal_single_stage():
+    from atomai_amd import _lib as L
+    N, H, W, C = 3, 40, 52, 20
+    cs, cop = 20, 32
+    x = torch.randn(N, H, W, cs) * 2 + 0.7
+    tiles = [(n, ty, tx) for n in range(N) for ty in range(3) for tx in range(4)]
+    stats = torch.zeros(len(tiles), 2, cop)
+    for i, (n, ty, tx) in enumerate(tiles):
+        t = x[n, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16].reshape(-1, cs).double()
+        stats[i, 0, :cs] = t.sum(0).float()
+        stats[i, 1, :cs] = ((t - t.mean(0)) ** 2).sum(0).float()
+    g, b = torch.rand(C) + 0.5, torch.randn(C)
+    outs = []
+    for two_stage in (False, True):
+        rm, rv = torch.zeros(C), torch.ones(C)
+        sc, sh, mu, iv = (torch.empty(cs) for _ in range(4))
+        st, rows, mode = stats, len(tiles), 0
+        if two_stage:
+            nch = 5
+            merged = torch.empty(nch, 3, cop)
+            L.call("amx_bn_stats_merge", L.ptr(stats), rows, cop, 0, N, H, W, 0, nch, L.ptr(merged), None)
+            st, rows, mode = merged, -(-rows // -(-rows // nch)), 2
+        L.call("amx_bn_finalize", L.ptr(st), rows, cop, mode, N, H, W, 0, L.ptr(g), L.ptr(b), L.ptr(rm),
+               L.ptr(rv), 0.1, 1e-5, C, cs, L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(iv), None)
+        outs.append((sc, sh, mu, iv, rm, rv))
+    xr = x[..., :C].reshape(-1, C).double()
+    np.testing.assert_allclose(outs[0][2][:C].numpy(), xr.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(outs[0][3][:C].numpy(), (1 / (xr.var(0, unbiased=False) + 1e-5).sqrt()).numpy(),
+                               rtol=1e-5)
+    np.testing.assert_allclose(outs[0][5].numpy(), (0.9 + 0.1 * xr.var(0, unbiased=True)).numpy(), rtol=1e-5)
+    for a, c in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a.numpy(), c.numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_chunked_row_reduction():
+    from atomai_amd import _lib as L
+    rows, ncols = 77, 600
+    part = torch.randn(rows, ncols)
+    nch = 8
+    out = torch.empty(nch, ncols)
+    L.call("amx_reduce_rows_chunked", L.ptr(part), rows, ncols, nch, L.ptr(out), None)
+    chunk = -(-rows // nch)
+    used = -(-rows // chunk)
+    np.testing.assert_allclose(out[:used].sum(0).numpy(), part.double().sum(0).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,H,N", [(64, 32, 16, 1), (32, 80, 24, 1), (16, 64, 16, 2)])
+def test_conv_layer_wide_channels(cin, cout, H, N):
+    """Channel widths of the default nets (wave layouts WM=4/2/1, NT=2, multiple cout blocks) in one layer:
+    forward, dgrad, wgrad, BatchNorm backward vs torch autograd in fp64."""
+    import copy
+    import torch.nn as nn
+    from atomai_amd.nets import ConvBlock
+    torch.manual_seed(0)
+    m = ConvBlock(2, 1, cin, cout, batch_norm=True)
+    ref = nn.Sequential(*[copy.deepcopy(l) for l in m.block]).double()
+    x = torch.randn(N, cin, H, H)
+    x1, x2 = x.clone().requires_grad_(True), x.double().clone().requires_grad_(True)
+    y, yr = m(x1), ref(x2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr.backward(gy.double())
+    assert float((y.double() - yr).abs().max()) < 1e-4
+    assert float((x1.grad.double() - x2.grad).abs().max() / x2.grad.abs().max()) < 1e-4
+    for (k, p), (_, p2) in zip(m.block.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.double() - p2.grad).abs().max() / p2.grad.abs().max()) < 1e-4, k
