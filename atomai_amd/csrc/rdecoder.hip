@@ -1,0 +1,512 @@
+// rdecoder.hip — the rVAE "spatial decoder": an MLP evaluated at EVERY pixel coordinate.
+//
+//   rDecoderNet.forward + coord_latent.forward            atomai/nets/ed.py:626-642, 672-687
+//     h0 = [tanh](Wc (x',y') + bc + Wz z)                 (tanh unless skip)
+//     h_l = tanh(W_l h_{l-1} + b_l) [+ h0 if skip]        l = 1..NL
+//     out = Wo h_NL + bo                                  one value per pixel (grayscale)
+//
+// This is where the rVAE step spends its time: B*H*W rows x HID hidden units
+// (2.1 M x 128 at bs 512, 64x64 => 139 GFLOP forward), and the reference materialises every hidden
+// activation in HBM (1 GB each).  Here one workgroup owns one sample and streams its pixels in tiles of
+// MT; all hidden activations live ONLY in LDS:
+//   * activation images in LDS are [feature/4][pixel][4] so that an MFMA operand fragment is one
+//     conflict-free ds_read_b128 (same trick as conv_fwd.hip);
+//   * the layer GEMM is evaluated transposed, D'[feature][pixel] = W · h^T, with A = W fragments held in
+//     registers (one wave owns 16 output features) and B = activations from LDS, so the accumulator
+//     fragment of a lane is 4 consecutive FEATURES of one pixel = exactly one b128 LDS store of the next
+//     layer's operand image;
+//   * backward recomputes the forward per tile, then runs output-layer, wgrad (MFMA, contraction over
+//     pixels) and dgrad (MFMA with W^T) entirely from LDS; weight-gradient accumulators stay in registers
+//     across all tiles of the sample and are written once as a per-sample partial row (summed by
+//     amx_reduce_rows in fp64 -> deterministic).
+#include "amx_device.h"
+
+struct RDecArgs {
+    const float* coords;   // [B][n][2] transformed pixel coordinates
+    const float* z;        // [B][L]
+    const float* Wc;       // [HID][2]
+    const float* bc;       // [HID]
+    const float* Wz;       // [HID][L]
+    const float* W;        // [NL][HID][HID]
+    const float* Wt;       // [NL][HID][HID] transposed copies (backward only)
+    const float* b;        // [NL][HID]
+    const float* Wo;       // [HID]
+    const float* bo;       // [1]
+    float* xrec;           // [B][n]                     (forward)
+    const float* dxrec;    // [B][n]                     (backward)
+    float* dcoords;        // [B][n][2]
+    float* dz;             // [B][L]
+    float* pW;             // [B][NL][HID][HID] partial rows
+    float* pb;             // [B][NL][HID]
+    float* pWo;            // [B][HID]
+    float* pbo;            // [B]
+    float* pWc;            // [B][HID][2]
+    float* pbc;            // [B][HID]
+    float* pWz;            // [B][HID][L]
+    int B, n, L, NL, skip;
+};
+
+#define MAXL 8
+
+// --------------------------------------------------------------------------------------------------
+// shared pieces
+template <int HID, int MT>
+struct Geo {
+    static constexpr int NW = HID / 16;          // waves
+    static constexpr int NT = 64 * NW;           // threads
+    static constexpr int KG = HID / 4;           // feature groups of 4
+    static constexpr int PT = MT / 16;           // pixel tiles per wave GEMM
+    static constexpr int BUF = HID * MT;         // floats per activation image
+    static constexpr int SPT = KG * MT / NT;     // (kg,pixel) slots per thread  (= MT/16)
+    static constexpr int TPP = NT / MT;          // threads per pixel in the output stage
+};
+
+// h0 tile -> dst (KG layout).  Also stores x',y' per pixel when s_xy != nullptr.
+template <int HID, int MT>
+__device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix0, const float* s_zc,
+                                            float* dst, float* s_xy, int tid) {
+    using G = Geo<HID, MT>;
+    #pragma unroll
+    for (int i = 0; i < G::SPT; ++i) {
+        const int s = tid + i * G::NT;
+        const int kg = s / MT, p = s - kg * MT;
+        const int q = pix0 + p;
+        float4 h = make_float4(0, 0, 0, 0);
+        if (q < a.n) {
+            const float xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
+            const float yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+            if (s_xy && kg == 0) { s_xy[2 * p] = xx; s_xy[2 * p + 1] = yy; }
+            const int f = kg * 4;
+            h.x = fmaf(a.Wc[2 * f + 0], xx, fmaf(a.Wc[2 * f + 1], yy, s_zc[f + 0]));
+            h.y = fmaf(a.Wc[2 * f + 2], xx, fmaf(a.Wc[2 * f + 3], yy, s_zc[f + 1]));
+            h.z = fmaf(a.Wc[2 * f + 4], xx, fmaf(a.Wc[2 * f + 5], yy, s_zc[f + 2]));
+            h.w = fmaf(a.Wc[2 * f + 6], xx, fmaf(a.Wc[2 * f + 7], yy, s_zc[f + 3]));
+            if (!a.skip) { h.x = tanhf(h.x); h.y = tanhf(h.y); h.z = tanhf(h.z); h.w = tanhf(h.w); }
+        }
+        amx_st4(dst + (size_t)s * 4, h);
+    }
+}
+
+// One hidden layer on a tile: dst = tanh(W src + b) [+ res].  src/dst/res are KG-layout LDS images.
+template <int HID, int MT>
+__device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, const float* src, float* dst,
+                                             const float* res, int wave, int lane) {
+    using G = Geo<HID, MT>;
+    const int p = lane & 15, g = lane >> 4;
+    float4 areg[HID / 16];
+    #pragma unroll
+    for (int c = 0; c < HID / 16; ++c) areg[c] = amx_ld4(Wl + (size_t)(16 * wave + p) * HID + 16 * c + 4 * g);
+    f32x4 acc[G::PT];
+    #pragma unroll
+    for (int t = 0; t < G::PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+    for (int c = 0; c < HID / 16; ++c) {
+        #pragma unroll
+        for (int t = 0; t < G::PT; ++t) {
+            const float4 bq = amx_ld4(src + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq.w, acc[t], 0, 0, 0);
+        }
+    }
+    // D'[row = feature 16*wave + 4g + r][col = pixel 16t + p]
+    const float4 bias = amx_ld4(bl + 16 * wave + 4 * g);
+    #pragma unroll
+    for (int t = 0; t < G::PT; ++t) {
+        float4 v;
+        v.x = tanhf(acc[t][0] + bias.x); v.y = tanhf(acc[t][1] + bias.y);
+        v.z = tanhf(acc[t][2] + bias.z); v.w = tanhf(acc[t][3] + bias.w);
+        const size_t o = ((size_t)(4 * wave + g) * MT + 16 * t + p) * 4;
+        if (res) { const float4 r = amx_ld4(res + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        amx_st4(dst + o, v);
+    }
+}
+
+// out[p] = Wo . h[p] + bo for the tile; result left in s_out[0..MT)
+template <int HID, int MT>
+__device__ __forceinline__ void output_layer(const RDecArgs& a, const float* h, float* s_part, float* s_out,
+                                             int tid) {
+    using G = Geo<HID, MT>;
+    const int p = tid % MT, part = tid / MT;
+    float acc = 0.f;
+    for (int kg = part; kg < G::KG; kg += G::TPP) {
+        const float4 v = amx_ld4(h + ((size_t)kg * MT + p) * 4);
+        const float4 w = amx_ld4(a.Wo + kg * 4);
+        acc = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc))));
+    }
+    s_part[part * MT + p] = acc;
+    __syncthreads();
+    if (tid < MT) {
+        float t = a.bo[0];
+        #pragma unroll
+        for (int q = 0; q < G::TPP; ++q) t += s_part[q * MT + tid];
+        s_out[tid] = t;
+    }
+    __syncthreads();
+}
+
+// zc[f] = bc[f] + sum_l Wz[f][l] z[l]
+template <int HID>
+__device__ __forceinline__ void latent_bias(const RDecArgs& a, int bidx, float* s_zc, float* s_z, int tid) {
+    if (tid < a.L) s_z[tid] = a.z[(size_t)bidx * a.L + tid];
+    __syncthreads();
+    if (tid < HID) {
+        float v = a.bc[tid];
+        for (int l = 0; l < a.L; ++l) v = fmaf(a.Wz[tid * a.L + l], s_z[l], v);
+        s_zc[tid] = v;
+    }
+    __syncthreads();
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int HID, int MT>
+__global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
+    using G = Geo<HID, MT>;
+    AMX_DYN_SMEM(float, smem);
+    float* buf0 = smem;
+    float* buf1 = buf0 + G::BUF;
+    float* buf2 = buf1 + G::BUF;                      // only with skip (keeps h0)
+    float* s_zc = buf1 + G::BUF * (a.skip ? 2 : 1);
+    float* s_z = s_zc + HID;
+    float* s_part = s_z + MAXL;
+    float* s_out = s_part + G::TPP * MT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bidx = blockIdx.x;
+    latent_bias<HID>(a, bidx, s_zc, s_z, tid);
+    for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
+        float* h0 = a.skip ? buf2 : buf0;
+        coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, tid);
+        __syncthreads();
+        const float* src = h0;
+        for (int l = 0; l < a.NL; ++l) {
+            float* dst = (src == buf0) ? buf1 : buf0;
+            hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, src, dst,
+                                  a.skip ? h0 : nullptr, wave, lane);
+            __syncthreads();
+            src = dst;
+        }
+        output_layer<HID, MT>(a, src, s_part, s_out, tid);
+        if (tid < MT && pix0 + tid < a.n) a.xrec[(size_t)bidx * a.n + pix0 + tid] = s_out[tid];
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int HID, int MT, int NL>
+__global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
+    using G = Geo<HID, MT>;
+    AMX_DYN_SMEM(float, smem);
+    float* H[NL + 1];
+    #pragma unroll
+    for (int l = 0; l <= NL; ++l) H[l] = smem + (size_t)l * G::BUF;
+    float* GR = smem + (size_t)(NL + 1) * G::BUF;                     // skip only: residual gradient
+    float* s_zc = smem + (size_t)(NL + 1 + (a.skip ? 1 : 0)) * G::BUF;
+    float* s_z = s_zc + HID;
+    float* s_part = s_z + MAXL;
+    float* s_out = s_part + G::TPP * MT;           // x_rec, then dout
+    float* s_xy = s_out + MT;                      // [MT][2]
+    float* s_red = s_xy + 2 * MT;                  // [NT] float4 scratch for the final reductions
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int bidx = blockIdx.x;
+    latent_bias<HID>(a, bidx, s_zc, s_z, tid);
+
+    // persistent accumulators
+    f32x4 accW[NL][HID / 16];
+    float accb[NL];
+    #pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        accb[l] = 0.f;
+        #pragma unroll
+        for (int c = 0; c < HID / 16; ++c) accW[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float4 aWo[G::SPT], aWc0[G::SPT], aWc1[G::SPT], aZc[G::SPT];
+    #pragma unroll
+    for (int i = 0; i < G::SPT; ++i) {
+        aWo[i] = make_float4(0, 0, 0, 0); aWc0[i] = aWo[i]; aWc1[i] = aWo[i]; aZc[i] = aWo[i];
+    }
+    float abo = 0.f;
+
+    for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
+        // ---- recompute forward for the tile
+        coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, tid);
+        __syncthreads();
+        #pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, H[l], H[l + 1],
+                                  a.skip ? H[0] : nullptr, wave, lane);
+            __syncthreads();
+        }
+        // ---- output layer backward: dout, dWo, dbo, ga_NL (in place over H[NL])
+        if (tid < MT) {
+            const int q = pix0 + tid;
+            s_out[tid] = q < a.n ? a.dxrec[(size_t)bidx * a.n + q] : 0.f;
+        }
+        __syncthreads();
+        if (tid < MT) abo += s_out[tid];
+        #pragma unroll
+        for (int i = 0; i < G::SPT; ++i) {
+            const int s = tid + i * G::NT;
+            const int kg = s / MT, pp = s - kg * MT;
+            const float d = s_out[pp];
+            float4 h = amx_ld4(H[NL] + (size_t)s * 4);
+            const float4 w = amx_ld4(a.Wo + kg * 4);
+            aWo[i].x = fmaf(d, h.x, aWo[i].x); aWo[i].y = fmaf(d, h.y, aWo[i].y);
+            aWo[i].z = fmaf(d, h.z, aWo[i].z); aWo[i].w = fmaf(d, h.w, aWo[i].w);
+            float4 gh = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+            if (a.skip) {
+                const float4 r = amx_ld4(H[0] + (size_t)s * 4);
+                amx_st4(GR + (size_t)s * 4, gh);                        // g_res = gh_NL
+                h.x -= r.x; h.y -= r.y; h.z -= r.z; h.w -= r.w;         // t = h - residual
+            }
+            gh.x *= 1.f - h.x * h.x; gh.y *= 1.f - h.y * h.y; gh.z *= 1.f - h.z * h.z; gh.w *= 1.f - h.w * h.w;
+            amx_st4(H[NL] + (size_t)s * 4, gh);
+        }
+        __syncthreads();
+        // ---- hidden layers, last to first
+        #pragma unroll
+        for (int l = NL - 1; l >= 0; --l) {
+            const float* ga = H[l + 1];          // gradient w.r.t. the pre-activation of layer l
+            const float* hin = H[l];             // that layer's input activations
+            // wgrad: dW[f][k] += sum_pix ga[pix][f] * hin[pix][k];  A[i=f][kd=pix], B[kd=pix][j=k]
+            #pragma unroll 4
+            for (int s4 = 0; s4 < MT / 4; ++s4) {
+                const int pix = 4 * s4 + g;
+                const int f = 16 * wave + p;
+                const float av = ga[((size_t)(f >> 2) * MT + pix) * 4 + (f & 3)];
+                accb[l] += av;
+                #pragma unroll
+                for (int c = 0; c < HID / 16; ++c) {
+                    const int k = 16 * c + p;
+                    const float bv = hin[((size_t)(k >> 2) * MT + pix) * 4 + (k & 3)];
+                    accW[l][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accW[l][c], 0, 0, 0);
+                }
+            }
+            // dgrad: gh[k][pix] = sum_f W[f][k] ga[pix][f]  (A = W^T fragments, B = ga image)
+            float4 areg[HID / 16];
+            const float* Wt = a.Wt + (size_t)l * HID * HID;
+            #pragma unroll
+            for (int c = 0; c < HID / 16; ++c) areg[c] = amx_ld4(Wt + (size_t)(16 * wave + p) * HID + 16 * c + 4 * g);
+            f32x4 acc[G::PT];
+            #pragma unroll
+            for (int t = 0; t < G::PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            #pragma unroll
+            for (int c = 0; c < HID / 16; ++c) {
+                #pragma unroll
+                for (int t = 0; t < G::PT; ++t) {
+                    const float4 bq = amx_ld4(ga + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq.w, acc[t], 0, 0, 0);
+                }
+            }
+            __syncthreads();                     // every wave is done reading hin = H[l] and ga
+            // turn gh_{l} (grad w.r.t. h_l, the layer's INPUT) into the pre-activation gradient of the
+            // layer below and store it in place over H[l]
+            #pragma unroll
+            for (int t = 0; t < G::PT; ++t) {
+                const size_t o = ((size_t)(4 * wave + g) * MT + 16 * t + p) * 4;
+                float4 gh = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                float4 h = amx_ld4(H[l] + o);
+                if (a.skip) {
+                    float4 gr = amx_ld4(GR + o);
+                    if (l > 0) {
+                        gr.x += gh.x; gr.y += gh.y; gr.z += gh.z; gr.w += gh.w;     // g_res += gh_l
+                        amx_st4(GR + o, gr);
+                        const float4 r = amx_ld4(H[0] + o);
+                        h.x -= r.x; h.y -= r.y; h.z -= r.z; h.w -= r.w;
+                        gh.x *= 1.f - h.x * h.x; gh.y *= 1.f - h.y * h.y;
+                        gh.z *= 1.f - h.z * h.z; gh.w *= 1.f - h.w * h.w;
+                    } else {                     // h0 has no tanh with skip: ga_0 = gh_0 + g_res
+                        gh.x += gr.x; gh.y += gr.y; gh.z += gr.z; gh.w += gr.w;
+                    }
+                } else {
+                    gh.x *= 1.f - h.x * h.x; gh.y *= 1.f - h.y * h.y;
+                    gh.z *= 1.f - h.z * h.z; gh.w *= 1.f - h.w * h.w;
+                }
+                amx_st4(H[l] + o, gh);
+            }
+            __syncthreads();
+        }
+        // ---- coordinate layer backward from ga_0 = H[0]
+        float* s_g = H[1];                       // scratch [KG][MT][2] (H[1] is free now; NL >= 1)
+        #pragma unroll
+        for (int i = 0; i < G::SPT; ++i) {
+            const int s = tid + i * G::NT;
+            const int kg = s / MT, pp = s - kg * MT;
+            const float4 ga0 = amx_ld4(H[0] + (size_t)s * 4);
+            const float xx = s_xy[2 * pp], yy = s_xy[2 * pp + 1];
+            const bool ok = pix0 + pp < a.n;
+            if (ok) {
+                aWc0[i].x = fmaf(ga0.x, xx, aWc0[i].x); aWc0[i].y = fmaf(ga0.y, xx, aWc0[i].y);
+                aWc0[i].z = fmaf(ga0.z, xx, aWc0[i].z); aWc0[i].w = fmaf(ga0.w, xx, aWc0[i].w);
+                aWc1[i].x = fmaf(ga0.x, yy, aWc1[i].x); aWc1[i].y = fmaf(ga0.y, yy, aWc1[i].y);
+                aWc1[i].z = fmaf(ga0.z, yy, aWc1[i].z); aWc1[i].w = fmaf(ga0.w, yy, aWc1[i].w);
+                aZc[i].x += ga0.x; aZc[i].y += ga0.y; aZc[i].z += ga0.z; aZc[i].w += ga0.w;
+            }
+            const int f = kg * 4;
+            float gx = ga0.x * a.Wc[2 * f + 0] + ga0.y * a.Wc[2 * f + 2] + ga0.z * a.Wc[2 * f + 4] + ga0.w * a.Wc[2 * f + 6];
+            float gy = ga0.x * a.Wc[2 * f + 1] + ga0.y * a.Wc[2 * f + 3] + ga0.z * a.Wc[2 * f + 5] + ga0.w * a.Wc[2 * f + 7];
+            s_g[((size_t)kg * MT + pp) * 2 + 0] = ok ? gx : 0.f;
+            s_g[((size_t)kg * MT + pp) * 2 + 1] = ok ? gy : 0.f;
+        }
+        __syncthreads();
+        if (tid < 2 * MT) {
+            const int pp = tid >> 1, comp = tid & 1;
+            float t = 0.f;
+            for (int kg = 0; kg < G::KG; ++kg) t += s_g[((size_t)kg * MT + pp) * 2 + comp];
+            if (pix0 + pp < a.n) a.dcoords[((size_t)bidx * a.n + pix0 + pp) * 2 + comp] = t;
+        }
+        __syncthreads();
+    }
+
+    // ---- per-sample partial rows
+    #pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        #pragma unroll
+        for (int c = 0; c < HID / 16; ++c)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r)          // D[row = f = 16w+4g+r][col = k = 16c+p]
+                a.pW[(((size_t)bidx * NL + l) * HID + 16 * wave + 4 * g + r) * HID + 16 * c + p] = accW[l][c][r];
+        float sb = accb[l];
+        sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
+        if (g == 0) a.pb[((size_t)bidx * NL + l) * HID + 16 * wave + p] = sb;
+    }
+    // slot-mapped accumulators: threads with equal tid / MT share the feature group; reduce over pixels
+    float4* red4 = reinterpret_cast<float4*>(s_red);
+    #pragma unroll
+    for (int i = 0; i < G::SPT; ++i) {
+        const int kg = tid / MT + i * G::TPP;
+        #pragma unroll
+        for (int which = 0; which < 4; ++which) {
+            const float4 v = which == 0 ? aWo[i] : which == 1 ? aWc0[i] : which == 2 ? aWc1[i] : aZc[i];
+            __syncthreads();
+            red4[tid] = v;
+            __syncthreads();
+            if (tid % MT == 0) {
+                float4 t = make_float4(0, 0, 0, 0);
+                for (int q = 0; q < MT; ++q) { const float4 u = red4[tid + q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+                const int f = kg * 4;
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+                for (int e = 0; e < 4; ++e) {
+                    if (which == 0) a.pWo[(size_t)bidx * HID + f + e] = tv[e];
+                    else if (which == 1) a.pWc[((size_t)bidx * HID + f + e) * 2 + 0] = tv[e];
+                    else if (which == 2) a.pWc[((size_t)bidx * HID + f + e) * 2 + 1] = tv[e];
+                    else { a.pbc[(size_t)bidx * HID + f + e] = tv[e]; s_zc[f + e] = tv[e]; }
+                }
+            }
+        }
+    }
+    // dbo
+    __syncthreads();
+    s_red[tid] = tid < MT ? abo : 0.f;
+    __syncthreads();
+    if (tid == 0) { float t = 0.f; for (int q = 0; q < MT; ++q) t += s_red[q]; a.pbo[bidx] = t; }
+    // dWz[f][l] = dzc[f] * z[l];  dz[l] = sum_f Wz[f][l] dzc[f]     (s_zc now holds dzc)
+    __syncthreads();
+    if (tid < HID)
+        for (int l = 0; l < a.L; ++l) a.pWz[((size_t)bidx * HID + tid) * a.L + l] = s_zc[tid] * s_z[l];
+    if (tid < a.L) {
+        float t = 0.f;
+        for (int f = 0; f < HID; ++f) t = fmaf(a.Wz[f * a.L + tid], s_zc[f], t);
+        a.dz[(size_t)bidx * a.L + tid] = t;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int HID, int MT>
+static size_t fwd_lds(int skip) {
+    using G = Geo<HID, MT>;
+    return ((size_t)G::BUF * (skip ? 3 : 2) + HID + MAXL + G::TPP * MT + MT) * sizeof(float);
+}
+template <int HID, int MT, int NL>
+static size_t bwd_lds(int skip) {
+    using G = Geo<HID, MT>;
+    return ((size_t)G::BUF * (NL + 1 + (skip ? 1 : 0)) + HID + MAXL + G::TPP * MT + MT + 2 * MT + 4 * G::NT) * sizeof(float);
+}
+
+template <int HID, int MT>
+static int launch_fwd(const RDecArgs& a, hipStream_t s) {
+    const size_t lds = fwd_lds<HID, MT>(a.skip);
+    if (lds > 160 * 1024) return -20;
+#ifndef AMX_EMU
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_fwd_kernel<HID, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+#endif
+    AMX_LAUNCH((rdecoder_fwd_kernel<HID, MT>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int HID, int MT, int NL>
+static int launch_bwd(const RDecArgs& a, hipStream_t s) {
+    const size_t lds = bwd_lds<HID, MT, NL>(a.skip);
+    if (lds > 160 * 1024) return -20;
+#ifndef AMX_EMU
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_bwd_kernel<HID, MT, NL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+#endif
+    AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+static int check_common(const RDecArgs& a, int hid) {
+    if (!a.coords || !a.z || !a.Wc || !a.bc || !a.Wz || !a.W || !a.b || !a.Wo || !a.bo) return -1;
+    if (a.B <= 0 || a.n <= 0 || a.L < 1 || a.L > MAXL || a.NL < 1 || a.NL > 3) return -2;
+    if (hid != 32 && hid != 64 && hid != 128) return -3;
+    return 0;
+}
+
+extern "C" int amx_rdecoder_fwd(const float* coords, const float* z, const float* Wc, const float* bc,
+                                const float* Wz, const float* W, const float* b, const float* Wo,
+                                const float* bo, float* xrec, int B, int n, int L, int hid, int NL, int skip,
+                                void* stream) {
+    RDecArgs a = {};
+    a.coords = coords; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.b = b; a.Wo = Wo; a.bo = bo;
+    a.xrec = xrec; a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip;
+    const int rc = check_common(a, hid);
+    if (rc) return rc;
+    if (!xrec) AMX_BADARG(4);
+    hipStream_t s = (hipStream_t)stream;
+    if (hid == 32) return launch_fwd<32, 128>(a, s);
+    if (hid == 64) return launch_fwd<64, 128>(a, s);
+    return skip ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
+}
+
+extern "C" int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const float* bc,
+                                const float* Wz, const float* W, const float* Wt, const float* b,
+                                const float* Wo, const float* bo, const float* dxrec, float* dcoords,
+                                float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc, float* pbc,
+                                float* pWz, int B, int n, int L, int hid, int NL, int skip, void* stream) {
+    RDecArgs a = {};
+    a.coords = coords; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.Wt = Wt; a.b = b; a.Wo = Wo; a.bo = bo;
+    a.dxrec = dxrec; a.dcoords = dcoords; a.dz = dz;
+    a.pW = pW; a.pb = pb; a.pWo = pWo; a.pbo = pbo; a.pWc = pWc; a.pbc = pbc; a.pWz = pWz;
+    a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip;
+    const int rc = check_common(a, hid);
+    if (rc) return rc;
+    if (!Wt || !dxrec || !dcoords || !dz || !pW || !pb || !pWo || !pbo || !pWc || !pbc || !pWz) AMX_BADARG(4);
+    hipStream_t s = (hipStream_t)stream;
+#define RD_BWD(HID_, MT_)                                               \
+    if (NL == 1) return launch_bwd<HID_, MT_, 1>(a, s);                 \
+    if (NL == 2) return launch_bwd<HID_, MT_, 2>(a, s);                 \
+    return launch_bwd<HID_, MT_, 3>(a, s);
+    if (hid == 32) { RD_BWD(32, 64) }
+    if (hid == 64) { RD_BWD(64, 64) }
+    if (NL + 1 + (skip ? 1 : 0) <= 4) { RD_BWD(128, 64) }
+    RD_BWD(128, 32)
+#undef RD_BWD
+}

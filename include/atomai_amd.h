@@ -106,6 +106,17 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
 
+/* ---- rVAE spatial decoder (rDecoderNet + coord_latent, atomai/nets/ed.py:583-687): per-pixel MLP with all
+ * hidden activations kept in LDS; backward recomputes per tile and emits per-sample partial rows. */
+int amx_rdecoder_fwd(const float* coords, const float* z, const float* Wc, const float* bc, const float* Wz,
+                     const float* W, const float* b, const float* Wo, const float* bo, float* xrec, int B,
+                     int n, int L, int hid, int NL, int skip, void* stream);
+int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const float* bc, const float* Wz,
+                     const float* W, const float* Wt, const float* b, const float* Wo, const float* bo,
+                     const float* dxrec, float* dcoords, float* dz, float* pW, float* pb, float* pWo,
+                     float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L, int hid, int NL,
+                     int skip, void* stream);
+
 /* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
 int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, double bc1, double bc2, float gscale, void* stream);

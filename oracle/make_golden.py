@@ -217,9 +217,12 @@ def make_vae(aoi):
             m.encoder_net.to(dt), m.decoder_net.to(dt)
             if hasattr(m, "x_coord"):
                 m.x_coord = m.x_coord.to(dt)
-            m.kdict_.update(fit_kw)
-            if "rotation_prior" in fit_kw:
-                m.phi_prior = fit_kw["rotation_prior"]
+            # what rVAE.fit / VAE.fit set up before the epoch loop (rvae.py:191-200, vae.py:722-731)
+            if hasattr(m, "translation"):
+                m.dx_prior = fit_kw.get("translation_prior", 0.1)
+                m.kdict_["phi_prior"] = fit_kw.get("rotation_prior", 0.1)
+            if "capacity" in fit_kw:
+                m.kdict_["capacity"] = fit_kw["capacity"]
             m.loss = "mse"
             m.compile_trainer((x, None), None, batch_size=B)
             state = {"i": 0}

@@ -139,5 +139,7 @@ def test_kernel_level_large_shapes():
         got = [n.grad_nchw for n in ins] + [tape.param_grads[id(p)][1] for p in
                                             (conv.weight, conv.bias, bn.weight, bn.bias)]
         for a, b in zip(got, grads):
-            sc = float(b.abs().max())
-            assert float((a.view_as(b) - b).abs().max()) / sc < 2e-3, (B, H, C0, C1, Co, a.shape)
+            # relative L2: both sides are fp32, and an element whose pre-activation rounds to the other side
+            # of the LeakyReLU kink changes single entries by O(1%) in either implementation
+            rel = float((a.view_as(b) - b).norm() / b.norm())
+            assert rel < 1e-3, (B, H, C0, C1, Co, a.shape, rel)
