@@ -221,11 +221,8 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         #pragma unroll
         for (int c = 0; c < HID / 16; ++c) accW[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float4 aWo[G::SPT], aWc0[G::SPT], aWc1[G::SPT], aZc[G::SPT];
-    #pragma unroll
-    for (int i = 0; i < G::SPT; ++i) {
-        aWo[i] = make_float4(0, 0, 0, 0); aWc0[i] = aWo[i]; aWc1[i] = aWo[i]; aZc[i] = aWo[i];
-    }
+    // per-feature accumulators owned by thread f = tid < HID (kept out of the MFMA waves' register budget)
+    float aWo = 0.f, aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
     float abo = 0.f;
 
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
@@ -245,6 +242,12 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         }
         __syncthreads();
         if (tid < MT) abo += s_out[tid];
+        if (tid < HID) {                         // dWo[f] += sum_p dout[p] * h_NL[p][f]
+            const float* hf = H[NL] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
+            #pragma unroll 8
+            for (int pp = 0; pp < MT; ++pp) aWo = fmaf(s_out[pp], hf[pp * 4], aWo);
+        }
+        __syncthreads();
         #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
             const int s = tid + i * G::NT;
@@ -252,8 +255,6 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             const float d = s_out[pp];
             float4 h = amx_ld4(H[NL] + (size_t)s * 4);
             const float4 w = amx_ld4(a.Wo + kg * 4);
-            aWo[i].x = fmaf(d, h.x, aWo[i].x); aWo[i].y = fmaf(d, h.y, aWo[i].y);
-            aWo[i].z = fmaf(d, h.z, aWo[i].z); aWo[i].w = fmaf(d, h.w, aWo[i].w);
             float4 gh = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
             if (a.skip) {
                 const float4 r = amx_ld4(H[0] + (size_t)s * 4);
@@ -337,20 +338,22 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             const int s = tid + i * G::NT;
             const int kg = s / MT, pp = s - kg * MT;
             const float4 ga0 = amx_ld4(H[0] + (size_t)s * 4);
-            const float xx = s_xy[2 * pp], yy = s_xy[2 * pp + 1];
             const bool ok = pix0 + pp < a.n;
-            if (ok) {
-                aWc0[i].x = fmaf(ga0.x, xx, aWc0[i].x); aWc0[i].y = fmaf(ga0.y, xx, aWc0[i].y);
-                aWc0[i].z = fmaf(ga0.z, xx, aWc0[i].z); aWc0[i].w = fmaf(ga0.w, xx, aWc0[i].w);
-                aWc1[i].x = fmaf(ga0.x, yy, aWc1[i].x); aWc1[i].y = fmaf(ga0.y, yy, aWc1[i].y);
-                aWc1[i].z = fmaf(ga0.z, yy, aWc1[i].z); aWc1[i].w = fmaf(ga0.w, yy, aWc1[i].w);
-                aZc[i].x += ga0.x; aZc[i].y += ga0.y; aZc[i].z += ga0.z; aZc[i].w += ga0.w;
-            }
             const int f = kg * 4;
             float gx = ga0.x * a.Wc[2 * f + 0] + ga0.y * a.Wc[2 * f + 2] + ga0.z * a.Wc[2 * f + 4] + ga0.w * a.Wc[2 * f + 6];
             float gy = ga0.x * a.Wc[2 * f + 1] + ga0.y * a.Wc[2 * f + 3] + ga0.z * a.Wc[2 * f + 5] + ga0.w * a.Wc[2 * f + 7];
             s_g[((size_t)kg * MT + pp) * 2 + 0] = ok ? gx : 0.f;
             s_g[((size_t)kg * MT + pp) * 2 + 1] = ok ? gy : 0.f;
+        }
+        if (tid < HID) {                         // dWc[f][:] += sum_p ga0[p][f] * (x', y');  dzc[f] += sum_p ga0
+            const float* gf = H[0] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
+            const int np = a.n - pix0 < MT ? a.n - pix0 : MT;
+            for (int pp = 0; pp < np; ++pp) {
+                const float gv = gf[pp * 4];
+                aWc0 = fmaf(gv, s_xy[2 * pp], aWc0);
+                aWc1 = fmaf(gv, s_xy[2 * pp + 1], aWc1);
+                aZc += gv;
+            }
         }
         __syncthreads();
         if (tid < 2 * MT) {
@@ -374,30 +377,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         sb += __shfl_xor(sb, 16); sb += __shfl_xor(sb, 32);
         if (g == 0) a.pb[((size_t)bidx * NL + l) * HID + 16 * wave + p] = sb;
     }
-    // slot-mapped accumulators: threads with equal tid / MT share the feature group; reduce over pixels
-    float4* red4 = reinterpret_cast<float4*>(s_red);
-    #pragma unroll
-    for (int i = 0; i < G::SPT; ++i) {
-        const int kg = tid / MT + i * G::TPP;
-        #pragma unroll
-        for (int which = 0; which < 4; ++which) {
-            const float4 v = which == 0 ? aWo[i] : which == 1 ? aWc0[i] : which == 2 ? aWc1[i] : aZc[i];
-            __syncthreads();
-            red4[tid] = v;
-            __syncthreads();
-            if (tid % MT == 0) {
-                float4 t = make_float4(0, 0, 0, 0);
-                for (int q = 0; q < MT; ++q) { const float4 u = red4[tid + q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-                const int f = kg * 4;
-                const float tv[4] = {t.x, t.y, t.z, t.w};
-                for (int e = 0; e < 4; ++e) {
-                    if (which == 0) a.pWo[(size_t)bidx * HID + f + e] = tv[e];
-                    else if (which == 1) a.pWc[((size_t)bidx * HID + f + e) * 2 + 0] = tv[e];
-                    else if (which == 2) a.pWc[((size_t)bidx * HID + f + e) * 2 + 1] = tv[e];
-                    else { a.pbc[(size_t)bidx * HID + f + e] = tv[e]; s_zc[f + e] = tv[e]; }
-                }
-            }
-        }
+    __syncthreads();
+    if (tid < HID) {
+        a.pWo[(size_t)bidx * HID + tid] = aWo;
+        a.pWc[((size_t)bidx * HID + tid) * 2 + 0] = aWc0;
+        a.pWc[((size_t)bidx * HID + tid) * 2 + 1] = aWc1;
+        a.pbc[(size_t)bidx * HID + tid] = aZc;
+        s_zc[tid] = aZc;                         // dzc, consumed below for dWz / dz
     }
     // dbo
     __syncthreads();

@@ -1,3 +1,4 @@
+from .dgm import VAE, BaseVAE, rVAE
 from .segmentor import Segmentor
 
-__all__ = ["Segmentor"]
+__all__ = ["Segmentor", "BaseVAE", "VAE", "rVAE"]

@@ -1,0 +1,65 @@
+"""rVAE: rotationally (and translationally) invariant VAE (reference: atomai/models/dgm/rvae.py:22-219)."""
+from copy import deepcopy as dc
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from ...losses_metrics import rvae_loss
+from ...utils import set_train_rng
+from ...utils.coords import transform_coordinates
+from .vae import BaseVAE
+
+
+class rVAE(BaseVAE):
+    """``rVAE(in_dim, latent_dim=2, translation=True, seed=0, **kwargs)`` with the spatial decoder on the fused
+    HIP kernels.  z = (angle, [dx, dy], content...)."""
+
+    def __init__(self, in_dim: int = None, latent_dim: int = 2, nb_classes: int = 0, translation: bool = True,
+                 seed: int = 0, **kwargs) -> None:
+        coord = 3 if translation else 1
+        super().__init__(in_dim, latent_dim, nb_classes, coord, **kwargs)
+        set_train_rng(seed)
+        self.translation = translation
+        self.dx_prior = None
+        self.phi_prior = None
+        self.kdict_ = dc(kwargs)
+        self.kdict_["num_iter"] = 0
+        self.loss = "mse"
+
+    def elbo_fn(self, x, x_reconstr, *args, **kwargs) -> torch.Tensor:
+        return rvae_loss(self.loss, self.in_dim, x, x_reconstr, *args, **kwargs)
+
+    def forward_compute_elbo(self, x: torch.Tensor, y: Optional[torch.Tensor] = None,
+                             mode: str = "train") -> torch.Tensor:
+        """Same dataflow as rvae.py:110-147: encoder -> reparameterise -> split (phi, dx, z) -> rotate/translate
+        the coordinate grid -> spatial decoder -> ELBO."""
+        x_coord_ = self.x_coord.expand(x.size(0), *self.x_coord.size())
+        with torch.set_grad_enabled(mode != "eval"):
+            z_mean, z_logsd = self.encoder_net(x)
+            if mode != "eval":
+                self.kdict_["num_iter"] += 1
+            z = self.reparameterize(z_mean, torch.exp(z_logsd))
+            phi = z[:, 0]
+            if self.translation:
+                dx = (z[:, 1:3] * self.dx_prior).unsqueeze(1)
+                z = z[:, 3:]
+            else:
+                dx = 0
+                z = z[:, 1:]
+            x_coord_ = transform_coordinates(x_coord_, phi, dx)
+            x_reconstr = self.decoder_net(x_coord_, z)
+            return self.elbo_fn(x, x_reconstr, z_mean, z_logsd, **self.kdict_)
+
+    def fit(self, X_train, y_train=None, X_test=None, y_test=None, loss: str = "mse", **kwargs) -> None:
+        self._check_inputs(X_train, y_train, X_test, y_test)
+        self.dx_prior = kwargs.get("translation_prior", 0.1)
+        self.kdict_["phi_prior"] = kwargs.get("rotation_prior", 0.1)
+        for k, v in kwargs.items():
+            if k in ["capacity"]:
+                self.kdict_[k] = v
+        self.compile_trainer((X_train, y_train), (X_test, y_test), **kwargs)
+        self.loss = loss
+        if kwargs.get("recording", False):
+            raise NotImplementedError("manifold recording (matplotlib/torchvision tooling) is out of scope")
+        self._fit_loop()

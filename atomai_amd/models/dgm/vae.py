@@ -1,0 +1,142 @@
+"""BaseVAE / VAE (reference: atomai/models/dgm/vae.py:28-221, 594-747)."""
+from copy import deepcopy as dc
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from ...losses_metrics import vae_loss
+from ...nets import init_VAE_nets
+from ...trainers import viBaseTrainer
+from ...utils import set_train_rng
+from ...utils.coords import imcoordgrid
+
+
+class BaseVAE(viBaseTrainer):
+    """Encoder/decoder object shared by the VAE family (vae.py:28-221)."""
+
+    def __init__(self, in_dim: Tuple[int], latent_dim: int, nb_classes: int = 0, coord: int = 0,
+                 discrete_dim: Optional[List] = None, seed: int = 0, **kwargs) -> None:
+        super().__init__()
+        msg = ("You must specify the input dimensions and pass them as a tuple. For images, specify "
+               "(height, width) or (height, width, channels) if multiple channels. For spectra, specify (length,)")
+        if in_dim is None or not isinstance(in_dim, (tuple, list)):
+            raise AssertionError(msg)
+        if isinstance(in_dim, tuple) and not isinstance(in_dim[0], int):
+            raise AssertionError(msg)
+        if nb_classes:
+            raise NotImplementedError("class-conditioned VAEs are outside this build's hot path")
+        set_train_rng(seed)              # NB: the nets are always drawn under BaseVAE's own seed (default 0)
+        self.in_dim = in_dim
+        self.z_dim = latent_dim
+        self.discrete_dim = discrete_dim
+        if coord:
+            if len(in_dim) not in (2, 3):
+                raise NotImplementedError("VAE with rotation and translational invariance are available "
+                                          "only for 2D image data")
+            self.z_dim = self.z_dim + coord
+            self.x_coord = imcoordgrid(in_dim).to(self.device)
+        self.nb_classes = nb_classes
+        encoder_net, decoder_net, self.metadict = init_VAE_nets(in_dim, latent_dim, coord, discrete_dim,
+                                                                nb_classes, **kwargs)
+        self.set_model(encoder_net, decoder_net)
+        self.sigmoid_out = self.metadict["sigmoid_out"]
+        self.coord = coord
+
+    def encode_(self, x_new, **kwargs) -> np.ndarray:
+        """Encoder forward in ``num_batches`` chunks -> concatenated (z_mean | z_logsd) array."""
+        if isinstance(x_new, np.ndarray):
+            x_new = torch.from_numpy(x_new).float()
+        if x_new.ndim == len(self.in_dim):
+            x_new = x_new.unsqueeze(0)
+        x_new = x_new.to(self.device)
+        num_batches = kwargs.get("num_batches", 10)
+        bs = max(1, len(x_new) // num_batches)
+        self.encoder_net.eval()
+        out = []
+        with torch.no_grad():
+            for i in range(0, len(x_new), bs):
+                out.append(torch.cat(self.encoder_net(x_new[i:i + bs]), -1).cpu().numpy())
+        return np.concatenate(out)
+
+    def encode(self, x_new, **kwargs) -> Tuple[np.ndarray]:
+        z = self.encode_(x_new, **kwargs)
+        return z[:, :self.z_dim], z[:, self.z_dim:]
+
+    def decode(self, z_sample, y=None) -> np.ndarray:
+        """Maps latent point(s) to data space with the trained generative model (vae.py:178-221)."""
+        if y is not None:
+            raise NotImplementedError("class-conditioned decoding is outside this build's hot path")
+        if isinstance(z_sample, np.ndarray):
+            z_sample = torch.from_numpy(z_sample).float()
+        if z_sample.dim() == 1:
+            z_sample = z_sample[None, ...]
+        z_sample = z_sample.to(self.device)
+        self.decoder_net.to(self.device).eval()
+        with torch.no_grad():
+            if self.coord:
+                x_coord = self.x_coord.expand(z_sample.size(0), *self.x_coord.size()).contiguous()
+                x_decoded = self.decoder_net(x_coord, z_sample)
+            else:
+                x_decoded = self.decoder_net(z_sample)
+        if self.sigmoid_out:
+            x_decoded = torch.sigmoid(x_decoded)
+        return x_decoded.cpu().numpy()
+
+    def _check_inputs(self, X_train, y_train=None, X_test=None, y_test=None) -> None:
+        if self.in_dim != X_train.shape[1:]:
+            raise RuntimeError("The values of input dimensions you specified do not match "
+                               "the training data dimensions")
+        if X_test is not None and self.in_dim != X_test.shape[1:]:
+            raise RuntimeError("The values of input dimensions you specified do not match "
+                               "the test data dimensions")
+        if y_train is not None or y_test is not None:
+            raise NotImplementedError("class-conditioned VAEs are outside this build's hot path")
+
+    def update_metadict(self):
+        self.metadict["num_epochs"] = self.current_epoch
+        self.metadict["num_iter"] = self.kdict_["num_iter"]
+
+    def _fit_loop(self):
+        for e in range(self.training_cycles):
+            self.current_epoch = e
+            self.loss_history["train_loss"].append(self.train_epoch())
+            if self.test_iterator is not None:
+                self.loss_history["test_loss"].append(self.evaluate_model())
+            self.print_statistics(e)
+            self.update_metadict()
+            self.save_model(self.filename)
+
+
+class VAE(BaseVAE):
+    """Plain variational autoencoder (vae.py:594-747)."""
+
+    def __init__(self, in_dim: int = None, latent_dim: int = 2, nb_classes: int = 0, seed: int = 0,
+                 **kwargs) -> None:
+        super().__init__(in_dim, latent_dim, nb_classes, 0, **kwargs)
+        set_train_rng(seed)
+        self.kdict_ = dc(kwargs)
+        self.kdict_["num_iter"] = 0
+        self.loss = "mse"
+
+    def elbo_fn(self, x, x_reconstr, *args, **kwargs) -> torch.Tensor:
+        return vae_loss(self.loss, self.in_dim, x, x_reconstr, *args, **kwargs)
+
+    def forward_compute_elbo(self, x: torch.Tensor, y=None, mode: str = "train") -> torch.Tensor:
+        x = x.to(self.device)
+        with torch.set_grad_enabled(mode != "eval"):
+            z_mean, z_logsd = self.encoder_net(x)
+            if mode != "eval":
+                self.kdict_["num_iter"] += 1
+            z = self.reparameterize(z_mean, torch.exp(z_logsd))
+            x_reconstr = self.decoder_net(z)
+            return self.elbo_fn(x, x_reconstr, z_mean, z_logsd, **self.kdict_)
+
+    def fit(self, X_train, y_train=None, X_test=None, y_test=None, loss: str = "mse", **kwargs) -> None:
+        self._check_inputs(X_train, y_train, X_test, y_test)
+        for k, v in kwargs.items():
+            if k in ["capacity"]:
+                self.kdict_[k] = v
+        self.compile_trainer((X_train, y_train), (X_test, y_test), **kwargs)
+        self.loss = loss
+        self._fit_loop()

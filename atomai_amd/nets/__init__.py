@@ -1,4 +1,6 @@
 from .blocks import ConvBlock, DilatedBlock, UpsampleBlock
+from .ed import coord_latent, fcDecoderNet, fcEncoderNet, init_VAE_nets, rDecoderNet
 from .fcnn import Unet, dilnet, init_fcnn_model
 
-__all__ = ["ConvBlock", "UpsampleBlock", "DilatedBlock", "Unet", "dilnet", "init_fcnn_model"]
+__all__ = ["ConvBlock", "UpsampleBlock", "DilatedBlock", "Unet", "dilnet", "init_fcnn_model",
+           "fcEncoderNet", "fcDecoderNet", "rDecoderNet", "coord_latent", "init_VAE_nets"]

@@ -1,0 +1,199 @@
+"""VAE encoder / decoder networks (reference: atomai/nets/ed.py:292-343, 530-687, 725-790).
+
+* ``fcEncoderNet`` / ``fcDecoderNet`` are plain dense layers on (B x features) matrices: they stay stock
+  ``nn.Linear`` modules, i.e. library GEMMs (rocBLAS/hipBLASLt through PyTorch-ROCm) — they are <1 % of the
+  rVAE step's FLOPs.
+* ``rDecoderNet`` — the per-pixel spatial decoder where the step spends its time — runs the fused HIP
+  kernels of csrc/rdecoder.hip (all hidden activations stay in LDS, forward and backward).
+Module trees / state-dict keys / RNG-order initialisation are those of the reference.
+"""
+from typing import Dict, List, Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+class fcEncoderNet(nn.Module):
+    """flatten -> [Linear -> Tanh] x num_layers -> (fc11, fc12) (ed.py:292-343)."""
+
+    def __init__(self, in_dim: Tuple[int], latent_dim: int = 2, num_layers: int = 2, hidden_dim: int = 32,
+                 **kwargs: bool) -> None:
+        super().__init__()
+        dense = []
+        for i in range(num_layers):
+            input_dim = int(np.prod(in_dim)) if i == 0 else hidden_dim
+            dense.extend([nn.Linear(input_dim, hidden_dim), nn.Tanh()])
+        self.dense = nn.Sequential(*dense)
+        self.reshape_ = hidden_dim
+        self.fc11 = nn.Linear(self.reshape_, latent_dim)
+        self.fc12 = nn.Linear(self.reshape_, latent_dim)
+        self._out = nn.Softplus() if kwargs.get("softplus_out") else lambda x: x
+
+    def forward(self, x: torch.Tensor):
+        x = x.reshape(-1, int(np.prod(x.size()[1:])))
+        x = self.dense(x).reshape(-1, self.reshape_)
+        return self.fc11(x), self._out(self.fc12(x))
+
+
+class fcDecoderNet(nn.Module):
+    """[Linear -> Tanh] x num_layers -> Linear(hidden, prod(out_dim)) (ed.py:530-580)."""
+
+    def __init__(self, out_dim: Tuple[int], latent_dim: int, num_layers: int = 2, hidden_dim: int = 32) -> None:
+        super().__init__()
+        if len(out_dim) not in (1, 2, 3):
+            raise ValueError("The output dimensions must be (length,) for 1D data and "
+                             "(height, width) or (height, width, channel) for 2D data")
+        c = out_dim[-1] if len(out_dim) > 2 else 1
+        decoder = []
+        for i in range(num_layers):
+            hidden_dim_ = latent_dim if i == 0 else hidden_dim
+            decoder.extend([nn.Linear(hidden_dim_, hidden_dim), nn.Tanh()])
+        self.decoder = nn.Sequential(*decoder)
+        self.out = nn.Linear(hidden_dim, int(np.prod(out_dim)))
+        self.out_dim = (c, *out_dim[:2])
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        h = self.out(self.decoder(z)).reshape(-1, *self.out_dim)
+        return h.squeeze(1) if h.size(1) == 1 else h.permute(0, 2, 3, 1)
+
+
+class coord_latent(nn.Module):
+    """Parameter container of the decoder's first layer: Linear(2, out) on coordinates + bias-free
+    Linear(latent, out) on z (ed.py:645-687).  Its arithmetic is fused into the rDecoderNet kernels."""
+
+    def __init__(self, latent_dim: int, out_dim: int, activation: bool = False) -> None:
+        super().__init__()
+        self.fc_coord = nn.Linear(2, out_dim)
+        self.fc_latent = nn.Linear(latent_dim, out_dim, bias=False)
+        self.activation = nn.Tanh() if activation else None
+
+
+class _RDecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x_coord, z, *params):
+        B, n = x_coord.shape[:2]
+        hid, NL, Ldim = net.hidden_dim, net.num_layers, z.shape[1]
+        Wc, bc, Wz = params[0], params[1], params[2]
+        Ws, bs = params[3:3 + 2 * NL:2], params[4:4 + 2 * NL:2]
+        Wo, bo = params[3 + 2 * NL], params[4 + 2 * NL]
+        W = torch.stack([w.detach() for w in Ws]).contiguous()
+        b = torch.stack([v.detach() for v in bs]).contiguous()
+        coords = x_coord.detach().contiguous()
+        zz = z.detach().contiguous()
+        xrec = torch.empty(B, n, dtype=torch.float32, device=coords.device)
+        sp = L.stream_ptr(coords)
+        L.call("amx_rdecoder_fwd", L.ptr(coords), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
+               L.ptr(Wz.detach().contiguous()), L.ptr(W), L.ptr(b), L.ptr(Wo.detach().reshape(-1)),
+               L.ptr(bo.detach()), L.ptr(xrec), B, n, Ldim, hid, NL, int(net.skip), sp)
+        ctx.net = net
+        ctx.save_for_backward(coords, zz, W, b, *[p.detach() for p in (Wc, bc, Wz, Wo, bo)])
+        return xrec
+
+    @staticmethod
+    def backward(ctx, dxrec):
+        net = ctx.net
+        coords, zz, W, b, Wc, bc, Wz, Wo, bo = ctx.saved_tensors
+        B, n = coords.shape[:2]
+        hid, NL, Ldim = net.hidden_dim, net.num_layers, zz.shape[1]
+        dev = coords.device
+        Wt = W.transpose(1, 2).contiguous()
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dcoords, dz = e(B, n, 2), e(B, Ldim)
+        pW, pb, pWo, pbo = e(B, NL * hid * hid), e(B, NL * hid), e(B, hid), e(B, 1)
+        pWc, pbc, pWz = e(B, hid * 2), e(B, hid), e(B, hid * Ldim)
+        sp = L.stream_ptr(coords)
+        L.call("amx_rdecoder_bwd", L.ptr(coords), L.ptr(zz), L.ptr(Wc), L.ptr(bc), L.ptr(Wz.contiguous()),
+               L.ptr(W), L.ptr(Wt), L.ptr(b), L.ptr(Wo.reshape(-1)), L.ptr(bo), L.ptr(dxrec.contiguous()),
+               L.ptr(dcoords), L.ptr(dz), L.ptr(pW), L.ptr(pb), L.ptr(pWo), L.ptr(pbo), L.ptr(pWc),
+               L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), sp)
+
+        def rsum(part, shape):
+            cols = part.shape[1]
+            out = e(cols)
+            rows, src = B, part
+            if rows > 64:
+                nch = 32
+                tmp = e(nch, cols)
+                L.call("amx_reduce_rows_chunked", L.ptr(src), rows, cols, nch, L.ptr(tmp), sp)
+                src, rows = tmp, -(-rows // -(-rows // nch))
+            L.call("amx_reduce_rows_chunked", L.ptr(src), rows, cols, 1, L.ptr(out), sp)
+            return out.view(shape)
+        gW = rsum(pW, (NL, hid, hid))
+        gb = rsum(pb, (NL, hid))
+        grads = [rsum(pWc, (hid, 2)), rsum(pbc, (hid,)), rsum(pWz, (hid, Ldim))]
+        for l in range(NL):
+            grads += [gW[l], gb[l]]
+        grads += [rsum(pWo, (1, hid)), rsum(pbo, (1,))]
+        return (None, dcoords, dz) + tuple(grads)
+
+
+class rDecoderNet(nn.Module):
+    """Spatial decoder with (optional) skip connections (ed.py:583-642) on the fused HIP kernels."""
+
+    def __init__(self, out_dim: Tuple[int], latent_dim: int, num_layers: int, hidden_dim: int,
+                 skip: bool = False) -> None:
+        super().__init__()
+        if len(out_dim) == 2:
+            c = 1
+            self.reshape_ = (out_dim[0], out_dim[1])
+        else:
+            c = out_dim[-1]
+            self.reshape_ = (out_dim[0], out_dim[1], c)
+        self.skip = skip
+        self.coord_latent = coord_latent(latent_dim, hidden_dim, not skip)
+        fc_decoder = []
+        for i in range(num_layers):
+            fc_decoder.extend([nn.Linear(hidden_dim, hidden_dim), nn.Tanh()])
+        self.fc_decoder = nn.Sequential(*fc_decoder)
+        self.out = nn.Linear(hidden_dim, c)
+        self.hidden_dim, self.num_layers, self.channels = hidden_dim, num_layers, c
+
+    def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        if self.channels != 1:
+            raise NotImplementedError("multi-channel spatial decoding is outside this build's hot path")
+        if self.hidden_dim not in (32, 64, 128) or not 1 <= self.num_layers <= 3:
+            raise NotImplementedError("fused rDecoderNet supports hidden_dim in {32,64,128}, 1-3 layers")
+        batch_dim = x_coord.size(0)
+        params = [self.coord_latent.fc_coord.weight, self.coord_latent.fc_coord.bias,
+                  self.coord_latent.fc_latent.weight]
+        for m in self.fc_decoder:
+            if isinstance(m, nn.Linear):
+                params += [m.weight, m.bias]
+        params += [self.out.weight, self.out.bias]
+        h = _RDecoderFn.apply(self, x_coord, z, *params)
+        return h.reshape(batch_dim, *self.reshape_)
+
+
+def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_dim: Optional[List] = None,
+                  nb_classes: int = 0, **kwargs):
+    """Encoder / decoder factory + metadict with the reference's keys (ed.py:725-790)."""
+    conv_e = kwargs.get("conv_encoder", False)
+    conv_d = kwargs.get("conv_decoder", False) if not coord else None
+    numlayers_e = kwargs.get("numlayers_encoder", 2)
+    numlayers_d = kwargs.get("numlayers_decoder", 2)
+    numhidden_e = kwargs.get("numhidden_encoder", 128)
+    numhidden_d = kwargs.get("numhidden_decoder", 128)
+    skip = kwargs.get("skip", False)
+    sigmoid_out = kwargs.get("sigmoid_out", False)
+    softplus_out = kwargs.get("softplus_out")
+    if discrete_dim:
+        raise NotImplementedError("joint (discrete) VAEs are outside the MI355X hot path of this build")
+    if conv_e or conv_d:
+        raise NotImplementedError("convolutional VAE encoders/decoders are the next widening step "
+                                  "(they reuse the ConvBlock kernels)")
+    if not coord:
+        decoder_net = fcDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d)
+    else:
+        decoder_net = rDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d, skip)
+    encoder_net = fcEncoderNet(in_dim, latent_dim + coord, numlayers_e, numhidden_e, softplus_out=softplus_out)
+    meta_state_dict = {"model_type": "vae", "in_dim": in_dim, "latent_dim": latent_dim, "coord": coord,
+                       "conv_encoder": conv_e, "numlayers_encoder": numlayers_e,
+                       "numlayers_decoder": numlayers_d, "numhidden_encoder": numhidden_e,
+                       "numhidden_decoder": numhidden_d, "skip": skip, "nb_classes": nb_classes,
+                       "discrete_dim": discrete_dim, "sigmoid_out": sigmoid_out, "softplus_out": softplus_out}
+    if not coord:
+        meta_state_dict["conv_decoder"] = conv_d
+    return encoder_net, decoder_net, meta_state_dict

@@ -1,3 +1,4 @@
 from .trainer import BaseTrainer, SegTrainer
+from .vitrainer import viBaseTrainer
 
-__all__ = ["BaseTrainer", "SegTrainer"]
+__all__ = ["BaseTrainer", "SegTrainer", "viBaseTrainer"]

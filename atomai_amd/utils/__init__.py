@@ -1,3 +1,4 @@
+from .coords import grid2xy, imcoordgrid, transform_coordinates
 from .img import img_pad
 from .nn import (Hook, average_weights, get_downsample_factor, get_nb_classes, gpu_usage_map, mock_forward,
                  reset_bnorm, set_train_rng, weights_init)

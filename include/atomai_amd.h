@@ -117,6 +117,13 @@ int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const
                      float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L, int hid, int NL,
                      int skip, void* stream);
 
+/* ---- ELBO terms of vae_loss / rvae_loss with 'mse' (atomai/losses_metrics/vi_losses.py:13-137), fwd and bwd */
+int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd, int B, int n,
+                       int Z, int rot, float phi_prior, float* recon, float* klz, float* klrot, void* stream);
+int amx_elbo_terms_bwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
+                       const float* g_recon, const float* g_klz, const float* g_klrot, int B, int n, int Z,
+                       int rot, float phi_prior, float* dxrec, float* dmean, float* dlogsd, void* stream);
+
 /* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
 int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, double bc1, double bc2, float gscale, void* stream);

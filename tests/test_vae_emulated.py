@@ -1,0 +1,58 @@
+"""`not gpu` tier for the VAE / rVAE path: kernel sources on the CPU SIMT emulator vs the reference goldens."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import _vae_checks as V  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator():
+    if torch.cuda.is_available():
+        pytest.skip("emulator tier is for GPU-less hosts")
+    import emu_backend
+    emu_backend.use_emulator()
+
+
+@pytest.mark.parametrize("name", list(V.CASES))
+def test_elbo_grads_adam(name):
+    V.check_vae_case(name, "cpu")
+
+
+@pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (12, 12)), (128, 3, 1, (8, 8))])
+def test_rdecoder_shapes(hid, nl, skip, hw):
+    """Other decoder widths/depths, a pixel count that is not a multiple of the tile, skip connections."""
+    from collections import OrderedDict
+    from oracle import vae_oracle as vo
+    from atomai_amd.nets import rDecoderNet
+    torch.manual_seed(0)
+    B = 2
+    net = rDecoderNet(hw, 2, nl, hid, bool(skip))
+    P = OrderedDict((k, v.double().clone().requires_grad_(True)) for k, v in net.state_dict().items())
+    grid = vo.imcoordgrid(hw)
+    coords = vo.transform_coordinates(grid.expand(B, *grid.shape), torch.randn(B), torch.randn(B, 1, 2) * 0.1)
+    coords = coords.contiguous().requires_grad_(True)
+    z = torch.randn(B, 2, requires_grad=True)
+    c2, z2 = coords.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
+    y, yr = net(coords, z), vo.r_decoder(P, c2, z2, hw, nl, bool(skip))
+    assert float((y.detach().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < V.REL_TOL
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr.backward(gy.double())
+    for a, b in [(coords.grad, c2.grad), (z.grad, z2.grad)] + [(p.grad, P[k].grad) for k, p in net.named_parameters()]:
+        assert float((a.double() - b).abs().max() / b.abs().max()) < V.REL_TOL
+
+
+def test_rvae_fit_api(tmp_path):
+    import atomai_amd as aoi
+    X = np.random.RandomState(0).rand(8, 8, 8).astype(np.float32)
+    m = aoi.models.rVAE((8, 8), latent_dim=2, numhidden_encoder=32, numhidden_decoder=32)
+    m.fit(X, training_cycles=2, batch_size=4, filename=str(tmp_path / "rv"))
+    assert len(m.loss_history["train_loss"]) == 2
+    ck = torch.load(str(tmp_path / "rv.tar"), weights_only=False)
+    assert {"encoder", "decoder", "optimizer", "num_iter"} <= set(ck.keys())
+    assert m.decode(np.array([0.0, 0.0], dtype=np.float32)).shape == (1, 8, 8)

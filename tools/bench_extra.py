@@ -1,0 +1,101 @@
+"""Secondary workloads of BASELINE.json (configs[2..4]) — one JSON line each, written to gpurun_out/.
+   python tools/bench_extra.py rvae|predict|dkl
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import atomai_amd as aoi
+from atomai_amd import _lib as L
+
+PEAK = 157.3
+
+
+def timed_calls(names):
+    recs, orig = [], L.call
+
+    def call(name, *a):
+        if name not in names:
+            return orig(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = orig(name, *a); e1.record()
+        recs.append((name, e0, e1))
+        return r
+    L.call = call
+    import atomai_amd.nets.ed as ed, atomai_amd.engine as eng
+    ed.L.call = call; eng.L.call = call
+    return recs
+
+
+def bench_rvae(steps=10, warmup=3, B=512):
+    rs = np.random.RandomState(0)
+    X = rs.rand(B * 2, 64, 64).astype(np.float32)
+    m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
+    m.dx_prior, m.kdict_["phi_prior"] = 0.1, 0.1
+    m.compile_trainer((X, None), None, batch_size=B)
+    xs = [torch.from_numpy(X[i * B:(i + 1) * B]).cuda() for i in range(2)]
+    recs = timed_calls({"amx_rdecoder_fwd", "amx_rdecoder_bwd"})
+
+    def step(i):
+        m.optim.zero_grad()
+        elbo = m.forward_compute_elbo(xs[i % 2])
+        (-elbo).backward()
+        m.optim.step()
+        return elbo.item()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize(); recs.clear()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rows = B * 64 * 64
+    fl_fwd = rows * 2 * 2 * 128 * 128.0
+    tf = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_rdecoder_fwd") / steps
+    tb = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_rdecoder_bwd") / steps
+    out = {"metric": "rVAE training patches/sec (64x64, bs=512, latent_dim=2)", "value": round(B / dt, 1),
+           "unit": "patches/s", "ms_per_step": round(dt * 1e3, 3), "n_gpus": 1, "dtype": "f32", "elbo": last,
+           "roofline": {"bound": "mfma", "kernel": "rdecoder_bwd_kernel<128,64,2>",
+                        "achieved": round(3 * fl_fwd / (tb * 1e-3) / 1e12, 2), "peak": PEAK, "unit": "TFLOP/s",
+                        "frac": round(3 * fl_fwd / (tb * 1e-3) / 1e12 / PEAK, 4), "ms": round(tb, 3)},
+           "roofline_fwd": {"kernel": "rdecoder_fwd_kernel<128,128>", "achieved": round(fl_fwd / (tf * 1e-3) / 1e12, 2),
+                            "frac": round(fl_fwd / (tf * 1e-3) / 1e12 / PEAK, 4), "ms": round(tf, 3)}}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def bench_predict(frames=64, hw=1024):
+    """configs[2] on a bounded stack: dilnet nb_classes=1 predict over `frames` 1024x1024 frames."""
+    torch.manual_seed(1)
+    net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
+    rs = np.random.RandomState(0)
+    stack = rs.rand(frames, hw, hw).astype(np.float32)
+    p = aoi.predictors.SegPredictor(net, use_gpu=True, nb_classes=1, downsampling=2, verbose=False)
+    p.run(stack[:8], compute_coords=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = p.run(stack, compute_coords=False)
+    dt = time.perf_counter() - t0
+    x = torch.from_numpy(stack[:8, None]).cuda()
+    from atomai_amd.nets.fcnn import predict_proba
+    net.eval()
+    for _ in range(2): predict_proba(net, x)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(5): predict_proba(net, x)
+    torch.cuda.synchronize(); dk = (time.perf_counter() - t1) / 5 / 8
+    res = {"metric": "dilnet predict frames/sec (1024x1024, nb_classes=1), end-to-end incl. H2D/D2H",
+           "value": round(frames / dt, 2), "unit": "frames/s", "frames": frames,
+           "device_only_ms_per_frame": round(dk * 1e3, 3),
+           "device_tflops": round(91.62e9 / dk / 1e12, 2), "device_frac_of_mfma_peak": round(91.62e9 / dk / 1e12 / PEAK, 4),
+           "out_shape": list(out.shape)}
+    print(json.dumps(res), flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["rvae", "predict"]
+    os.makedirs("gpurun_out", exist_ok=True)
+    res = {}
+    for w in what:
+        res[w] = {"rvae": bench_rvae, "predict": bench_predict}[w]()
+    json.dump(res, open("gpurun_out/bench_extra.json", "w"), indent=1)
