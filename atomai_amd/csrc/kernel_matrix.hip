@@ -1,0 +1,260 @@
+// kernel_matrix.hip — dense, tiled covariance evaluation for deep-kernel-learning GP regression.
+//
+//   RBF-ARD      k(x,x') = s2 * exp(-1/2 sum_d ((x_d - x'_d)/l_d)^2)
+//   Matern-5/2   k(x,x') = s2 * (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r),  r = ||(x - x')/l||
+// evaluated on the feature extractor's embeddings (reference: ScaleKernel(RBFKernel(ard)) /
+// MaternKernel inside gpytorch, selected at atomai/nets/gp.py:41-46, 95-106; the arithmetic lives in the
+// un-vendored dependency gpytorch>=1.9.1 — closed forms restated from its documentation).
+//
+// Three entry points, all for fp32 and fp64 (dklGPR defaults to double precision, gptrainer.py:172-173):
+//   amx_kernel_matrix      K[N][M] (+ noise on the diagonal)          HBM-write bound: 16 B/lane coalesced rows
+//   amx_kernel_matvec      Y = K(X1,X2) V without materialising K     (predictive means / CG-type solvers)
+//   amx_kernel_matrix_bwd  given G = dL/dK (symmetric, X1 == X2): dX, d(1/l), d(s2) by recomputing K tile-wise;
+//                          per-workgroup partial rows, wave-level shuffles, deterministic.
+#include "amx_device.h"
+
+#define KM_MAXD 16
+#define KM_ROWS 32            // rows of K per workgroup
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<double> { static constexpr int N = 2; };
+
+template <typename T> __device__ __forceinline__ T km_exp(T x);
+template <> __device__ __forceinline__ float km_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double km_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T km_sqrt(T x);
+template <> __device__ __forceinline__ float km_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double km_sqrt<double>(double x) { return sqrt(x); }
+
+// value and radial factor:  k = s2 * f(r2);  returns also w with  dk/d(diff_d) = -w * s_d^2 * diff_d
+template <typename T>
+__device__ __forceinline__ T km_eval(T r2, T s2, int kind, T* w) {
+    if (kind == 0) {
+        const T k = s2 * km_exp<T>(T(-0.5) * r2);
+        *w = k;
+        return k;
+    }
+    const T sq5 = T(2.23606797749978969641);
+    const T r = km_sqrt<T>(r2);
+    const T e = km_exp<T>(-sq5 * r);
+    *w = s2 * T(5.0 / 3.0) * (T(1) + sq5 * r) * e;
+    return s2 * (T(1) + sq5 * r + T(5.0 / 3.0) * r2) * e;
+}
+
+// ------------------------------------------------------------------ K = k(X1, X2) [+ noise * I]
+template <typename T>
+__global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict__ X1, const T* __restrict__ X2,
+                                                            const T* __restrict__ inv_ls, T s2, int kind,
+                                                            T noise, int N, int M, int D, T* __restrict__ K) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int COLS = 64 * V;                         // columns per workgroup
+    __shared__ T s_x1[KM_ROWS * KM_MAXD];
+    __shared__ T s_x2[KM_MAXD * COLS];                   // [d][col]
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.y * KM_ROWS, col0 = blockIdx.x * COLS;
+    for (int i = tid; i < KM_ROWS * D; i += 256) {
+        const int r = i / D, d = i - r * D;
+        s_x1[i] = row0 + r < N ? X1[(size_t)(row0 + r) * D + d] * inv_ls[d] : T(0);
+    }
+    for (int i = tid; i < COLS * D; i += 256) {
+        const int c = i / D, d = i - c * D;
+        s_x2[d * COLS + c] = col0 + c < M ? X2[(size_t)(col0 + c) * D + d] * inv_ls[d] : T(0);
+    }
+    __syncthreads();
+    const int cg = tid & 63, rg = tid >> 6;              // 64 column groups x 4 row groups
+    #pragma unroll 2
+    for (int rr = 0; rr < KM_ROWS / 4; ++rr) {
+        const int r = rg * (KM_ROWS / 4) + rr;
+        const int gi = row0 + r;
+        if (gi >= N) break;
+        T out[V];
+        #pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = cg * V + v;
+            T r2 = T(0);
+            for (int d = 0; d < D; ++d) {
+                const T df = s_x1[r * D + d] - s_x2[d * COLS + c];
+                r2 += df * df;
+            }
+            T w;
+            T k = km_eval<T>(r2, s2, kind, &w);
+            if (gi == col0 + c) k += noise;
+            out[v] = k;
+        }
+        const int gc = col0 + cg * V;
+        T* dst = K + (size_t)gi * M + gc;
+        if (gc + V <= M && ((M * sizeof(T)) % 16 == 0)) {
+            if (V == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<float4*>(out);
+            else { dst[0] = out[0]; dst[1] = out[1]; }
+        } else {
+            #pragma unroll
+            for (int v = 0; v < V; ++v) if (gc + v < M) dst[v] = out[v];
+        }
+    }
+}
+
+template <typename T>
+static int launch_km(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, double noise,
+                     int N, int M, int D, void* K, hipStream_t st) {
+    constexpr int COLS = 64 * Vec16<T>::N;
+    dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KM_ROWS));
+    AMX_LAUNCH(kernel_matrix_kernel<T>, grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
+               (T)s2, kind, (T)noise, N, M, D, (T*)K);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int amx_kernel_matrix(const void* X1, const void* X2, const void* inv_ls, double outputscale,
+                                 int kind, double noise, int N, int M, int D, int is_double, void* K,
+                                 void* stream) {
+    if (!X1 || !X2 || !inv_ls || !K) AMX_BADARG(1);
+    if (N <= 0 || M <= 0 || D <= 0 || D > KM_MAXD || (kind != 0 && kind != 1)) AMX_BADARG(2);
+    hipStream_t st = (hipStream_t)stream;
+    return is_double ? launch_km<double>(X1, X2, inv_ls, outputscale, kind, noise, N, M, D, K, st)
+                     : launch_km<float>(X1, X2, inv_ls, outputscale, kind, noise, N, M, D, K, st);
+}
+
+// ------------------------------------------------------------------ Y[N][R] = K(X1, X2) V[M][R]
+#define KM_MAXR 4
+template <typename T>
+__global__ __launch_bounds__(256) void kernel_matvec_kernel(const T* __restrict__ X1, const T* __restrict__ X2,
+                                                            const T* __restrict__ inv_ls, T s2, int kind, int N,
+                                                            int M, int D, int R, const T* __restrict__ Vv,
+                                                            T* __restrict__ Y) {
+    // one wave per row: lanes stride over the columns, then a wave-level reduction
+    __shared__ T s_x1[4 * KM_MAXD];
+    __shared__ T s_t[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gi = blockIdx.x * 4 + wave;
+    if (lane < D && gi < N) s_x1[wave * KM_MAXD + lane] = X1[(size_t)gi * D + lane] * inv_ls[lane];
+    __syncthreads();
+    T acc[KM_MAXR];
+    #pragma unroll
+    for (int q = 0; q < KM_MAXR; ++q) acc[q] = T(0);
+    if (gi < N)
+        for (int c = lane; c < M; c += 64) {
+            T r2 = T(0);
+            for (int d = 0; d < D; ++d) {
+                const T df = s_x1[wave * KM_MAXD + d] - X2[(size_t)c * D + d] * inv_ls[d];
+                r2 += df * df;
+            }
+            T w;
+            const T k = km_eval<T>(r2, s2, kind, &w);
+            #pragma unroll
+            for (int q = 0; q < KM_MAXR; ++q) if (q < R) acc[q] += k * Vv[(size_t)c * R + q];
+        }
+    #pragma unroll
+    for (int q = 0; q < KM_MAXR; ++q) {
+        if (q >= R) break;
+        // per-wave tree through LDS: identical code for fp32 and fp64, fixed order -> deterministic
+        s_t[tid] = acc[q];
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) { if (lane < o) s_t[tid] += s_t[tid + o]; __syncthreads(); }
+        if (lane == 0 && gi < N) Y[(size_t)gi * R + q] = s_t[tid];
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int launch_mv(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, int N, int M, int D,
+                     int R, const void* V, void* Y, hipStream_t st) {
+    AMX_LAUNCH(kernel_matvec_kernel<T>, dim3(amx_ceil_div(N, 4)), dim3(256), 0, st, (const T*)X1, (const T*)X2,
+               (const T*)inv_ls, (T)s2, kind, N, M, D, R, (const T*)V, (T*)Y);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int amx_kernel_matvec(const void* X1, const void* X2, const void* inv_ls, double outputscale, int kind,
+                                 int N, int M, int D, int R, int is_double, const void* V, void* Y, void* stream) {
+    if (!X1 || !X2 || !inv_ls || !V || !Y) AMX_BADARG(1);
+    if (N <= 0 || M <= 0 || D <= 0 || D > KM_MAXD || R < 1 || R > KM_MAXR || (kind != 0 && kind != 1)) AMX_BADARG(2);
+    hipStream_t st = (hipStream_t)stream;
+    return is_double ? launch_mv<double>(X1, X2, inv_ls, outputscale, kind, N, M, D, R, V, Y, st)
+                     : launch_mv<float>(X1, X2, inv_ls, outputscale, kind, N, M, D, R, V, Y, st);
+}
+
+// ------------------------------------------------------------------ backward (X1 == X2, G symmetric)
+// dX[i][d]    = 2 * sum_j G_ij * dk_ij/dx_id        = -2 s_d^2 sum_j G_ij w_ij (x_id - x_jd)
+// dinv_ls[d]  = sum_ij G_ij * dk_ij/ds_d            = -s_d sum_ij G_ij w_ij (x_id - x_jd)^2      (s = 1/l)
+// ds2         = sum_ij G_ij k_ij / s2                                                             (noise-free k)
+// One wave per row i; partial rows [N/4 blocks][D + 1] for (dinv_ls, ds2), reduced by amx_reduce_rows-style host call.
+template <typename T>
+__global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restrict__ X, const T* __restrict__ inv_ls,
+                                                                T s2, int kind, int N, int D,
+                                                                const T* __restrict__ G, T* __restrict__ dX,
+                                                                T* __restrict__ part) {
+    __shared__ T s_t[256];
+    __shared__ T s_acc[4][KM_MAXD + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gi = blockIdx.x * 4 + wave;
+    T xi[KM_MAXD], sl[KM_MAXD];
+    #pragma unroll
+    for (int d = 0; d < KM_MAXD; ++d) { xi[d] = T(0); sl[d] = T(0); }
+    for (int d = 0; d < D; ++d) { sl[d] = inv_ls[d]; if (gi < N) xi[d] = X[(size_t)gi * D + d]; }
+    T ax[KM_MAXD], al[KM_MAXD], as2 = T(0);
+    #pragma unroll
+    for (int d = 0; d < KM_MAXD; ++d) { ax[d] = T(0); al[d] = T(0); }
+    if (gi < N)
+        for (int c = lane; c < N; c += 64) {
+            T df[KM_MAXD];
+            T r2 = T(0);
+            #pragma unroll
+            for (int d = 0; d < KM_MAXD; ++d) {
+                if (d >= D) break;
+                df[d] = xi[d] - X[(size_t)c * D + d];
+                const T u = df[d] * sl[d];
+                r2 += u * u;
+            }
+            T w;
+            const T k = km_eval<T>(r2, s2, kind, &w);
+            const T g = G[(size_t)gi * N + c];
+            as2 += g * k;
+            const T gw = g * w;
+            #pragma unroll
+            for (int d = 0; d < KM_MAXD; ++d) {
+                if (d >= D) break;
+                ax[d] += gw * df[d];
+                al[d] += gw * df[d] * df[d];
+            }
+        }
+    // wave reductions through LDS (works for fp32 and fp64 alike), fixed order -> deterministic
+    for (int q = 0; q < 2 * D + 1; ++q) {
+        T v = q < D ? ax[0] : (q < 2 * D ? al[0] : as2);
+        #pragma unroll
+        for (int d = 1; d < KM_MAXD; ++d) {
+            if (q == d) v = ax[d];
+            if (q == D + d && d < D) v = al[d];
+        }
+        s_t[tid] = v;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) { if (lane < o) s_t[tid] += s_t[tid + o]; __syncthreads(); }
+        if (lane == 0) {
+            const T tot = s_t[tid];
+            if (q < D) { if (gi < N) dX[(size_t)gi * D + q] = T(-2) * sl[q] * sl[q] * tot; }
+            else if (q < 2 * D) s_acc[wave][q - D] = gi < N ? -sl[q - D] * tot : T(0);
+            else s_acc[wave][D] = gi < N ? tot / s2 : T(0);
+        }
+        __syncthreads();
+    }
+    if (tid <= D) part[(size_t)blockIdx.x * (D + 1) + tid] = s_acc[0][tid] + s_acc[1][tid] + s_acc[2][tid] + s_acc[3][tid];
+}
+
+template <typename T>
+static int launch_kb(const void* X, const void* inv_ls, double s2, int kind, int N, int D, const void* G, void* dX,
+                     void* part, hipStream_t st) {
+    AMX_LAUNCH(kernel_matrix_bwd_kernel<T>, dim3(amx_ceil_div(N, 4)), dim3(256), 0, st, (const T*)X,
+               (const T*)inv_ls, (T)s2, kind, N, D, (const T*)G, (T*)dX, (T*)part);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// part: [ceil(N/4)][D+1] partial rows of (d inv_ls[0..D), d outputscale)
+extern "C" int amx_kernel_matrix_bwd(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
+                                     int is_double, const void* G, void* dX, void* part, void* stream) {
+    if (!X || !inv_ls || !G || !dX || !part) AMX_BADARG(1);
+    if (N <= 0 || D <= 0 || D > KM_MAXD || (kind != 0 && kind != 1)) AMX_BADARG(2);
+    hipStream_t st = (hipStream_t)stream;
+    return is_double ? launch_kb<double>(X, inv_ls, outputscale, kind, N, D, G, dX, part, st)
+                     : launch_kb<float>(X, inv_ls, outputscale, kind, N, D, G, dX, part, st);
+}

@@ -124,6 +124,16 @@ int amx_elbo_terms_bwd(const float* x, const float* xrec, const float* zmean, co
                        const float* g_recon, const float* g_klz, const float* g_klrot, int B, int n, int Z,
                        int rot, float phi_prior, float* dxrec, float* dmean, float* dlogsd, void* stream);
 
+/* ---- DKL covariance evaluation: ScaleKernel(RBFKernel(ard)) / MaternKernel(2.5) on the embeddings
+ * (selected at atomai/nets/gp.py:41-46,95-106; arithmetic in gpytorch).  kind 0 = RBF, 1 = Matern-5/2;
+ * inv_ls = 1/lengthscale per dim; is_double selects fp64 buffers. */
+int amx_kernel_matrix(const void* X1, const void* X2, const void* inv_ls, double outputscale, int kind,
+                      double noise, int N, int M, int D, int is_double, void* K, void* stream);
+int amx_kernel_matvec(const void* X1, const void* X2, const void* inv_ls, double outputscale, int kind, int N,
+                      int M, int D, int R, int is_double, const void* V, void* Y, void* stream);
+int amx_kernel_matrix_bwd(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
+                          int is_double, const void* G, void* dX, void* part, void* stream);
+
 /* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
 int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, double bc1, double bc2, float gscale, void* stream);
