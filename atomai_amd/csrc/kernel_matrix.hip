@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restr
         T v = q < D ? ax[0] : (q < 2 * D ? al[0] : as2);
         #pragma unroll
         for (int d = 1; d < KM_MAXD; ++d) {
-            if (q == d) v = ax[d];
+            if (q < D && q == d) v = ax[d];
             if (q == D + d && d < D) v = al[d];
         }
         s_t[tid] = v;

@@ -1,4 +1,5 @@
 from .dgm import VAE, BaseVAE, rVAE
+from .dklgp import dklGPR
 from .segmentor import Segmentor
 
-__all__ = ["Segmentor", "BaseVAE", "VAE", "rVAE"]
+__all__ = ["Segmentor", "BaseVAE", "VAE", "rVAE", "dklGPR"]

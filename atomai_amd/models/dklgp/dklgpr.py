@@ -1,0 +1,71 @@
+"""dklGPR: deep kernel learning GP regression (reference: atomai/models/dklgp/dklgpr.py:23-241)."""
+from typing import Tuple, Union
+
+import numpy as np
+import torch
+
+from ...trainers.gptrainer import dklGPTrainer
+
+
+class dklGPR(dklGPTrainer):
+    """``dklGPR(indim, embedim=2, shared_embedding_space=True, precision='double', ...)``"""
+
+    def __init__(self, indim: int, embedim: int = 2, shared_embedding_space: bool = True, **kwargs) -> None:
+        super().__init__(indim, embedim, shared_embedding_space, **kwargs)
+
+    def fit(self, X, y, training_cycles: int = 1, **kwargs) -> None:
+        _ = self.run(X, y, training_cycles, **kwargs)
+
+    def fit_ensemble(self, *args, **kwargs):
+        raise NotImplementedError("ensembles of DKL models are outside this build's scope")
+
+    def _compute_posterior(self, X: torch.Tensor, full_cov: bool = False):
+        self.gp_model.eval()
+        return self.gp_model.posterior(X.to(self.device), full_cov)
+
+    def _draw(self, X, num_samples):
+        mean, cov = self._compute_posterior(X, full_cov=True)
+        n = cov.shape[-1]
+        jitter = 1e-6 * cov.diagonal(dim1=-2, dim2=-1).mean(-1).clamp_min(1e-12)
+        Lc = torch.linalg.cholesky(cov + jitter[:, None, None] * torch.eye(n, dtype=cov.dtype, device=cov.device))
+        eps = torch.randn(num_samples, cov.shape[0], n, 1, dtype=cov.dtype, device=cov.device)
+        return mean[None] + (Lc[None] @ eps).squeeze(-1)
+
+    def sample_from_posterior(self, X, num_samples: int = 1000) -> np.ndarray:
+        X, _ = self.set_data(X)
+        return self._draw(X, num_samples).cpu().numpy()
+
+    def thompson(self, X_cand, scalarize_func=None, maximize: bool = True) -> Tuple[np.ndarray, int]:
+        X_cand, _ = self.set_data(X_cand)
+        tsample = self._draw(X_cand, 1)[0]
+        if tsample.ndim > 1 and scalarize_func is not None:
+            tsample = scalarize_func(tsample).unsqueeze(0)
+        idx = tsample.argmax(1) if maximize else tsample.argmin(1)
+        return tsample.cpu().numpy(), idx.cpu().numpy()
+
+    def _predict(self, x_new: torch.Tensor) -> Tuple[torch.Tensor]:
+        mean, var = self._compute_posterior(x_new)
+        return mean.cpu(), var.cpu()
+
+    def predict(self, x_new, **kwargs) -> Tuple[np.ndarray]:
+        """Posterior mean and variance in ``batch_size`` chunks (dklgpr.py:202-217)."""
+        x_new, _ = self.set_data(x_new, device='cpu')
+        bs = kwargs.get("batch_size", len(x_new))
+        means, vars_ = [], []
+        for i in range(0, len(x_new), bs):
+            m, v = self._predict(x_new[i:i + bs])
+            means.append(m)
+            vars_.append(v)
+        return torch.cat(means, 1).numpy().squeeze(), torch.cat(vars_, 1).numpy().squeeze()
+
+    def _embed(self, x_new: torch.Tensor):
+        self.gp_model.eval()
+        with torch.no_grad():
+            return self.gp_model.embed(x_new.to(self.device)).cpu()
+
+    def embed(self, x_new, **kwargs) -> torch.Tensor:
+        """Embeds the input data to the latent space of the (trained) feature extractor (dklgpr.py:231-241)."""
+        x_new, _ = self.set_data(x_new, device='cpu')
+        bs = kwargs.get("batch_size", len(x_new))
+        out = [self._embed(x_new[i:i + bs]) for i in range(0, len(x_new), bs)]
+        return torch.cat(out).numpy()

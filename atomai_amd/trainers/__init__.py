@@ -1,4 +1,5 @@
+from .gptrainer import dklGPTrainer
 from .trainer import BaseTrainer, SegTrainer
 from .vitrainer import viBaseTrainer
 
-__all__ = ["BaseTrainer", "SegTrainer", "viBaseTrainer"]
+__all__ = ["BaseTrainer", "SegTrainer", "viBaseTrainer", "dklGPTrainer"]

@@ -1,0 +1,97 @@
+"""dklGPTrainer: deep-kernel-learning GP training loop (reference: atomai/trainers/gptrainer.py:144-349).
+Shared-embedding path (``compile_trainer``); the per-output independent-network variant
+(``compile_multi_model_trainer``) is out of this build's scope."""
+from typing import Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+
+from ..nets.gp import GPRegressionModel, fcFeatureExtractor
+
+
+class dklGPTrainer:
+    def __init__(self, indim: int, embedim: int = 2, shared_embedding_space: bool = True, **kwargs) -> None:
+        seed = kwargs.get("seed", 42)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+        self.dimdict = {"input_dim": indim, "embedim": embedim}
+        self.device = kwargs.get("device", 'cuda:0' if torch.cuda.is_available() else 'cpu')
+        precision = kwargs.get("precision", "double")
+        # explicit dtype/device instead of the reference's global torch.set_default_tensor_type
+        self.dtype = torch.float32 if precision == "single" else torch.float64
+        self.correlated_output = shared_embedding_space
+        self.ensemble = False
+        self.gp_model = None
+        self.likelihood = None
+        self.compiled = False
+        self.train_loss = []
+
+    def _set_data(self, x, device: str = None) -> torch.Tensor:
+        dev = device if device else self.device
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        elif not isinstance(x, torch.Tensor):
+            raise TypeError("Pass data as ndarray or torch tensor object")
+        return x.to(self.dtype).to(dev)
+
+    def set_data(self, x, y=None, device: str = None) -> Tuple[torch.Tensor]:
+        x = self._set_data(x, device)
+        if y is not None:
+            y = y[None] if y.ndim == 1 else y
+            y = self._set_data(y, device)
+        return x, y
+
+    def compile_multi_model_trainer(self, *args, **kwargs):
+        raise NotImplementedError("independent per-output networks / ensembles are outside this build's scope")
+
+    def compile_trainer(self, X, y, training_cycles: int = 1, **kwargs) -> None:
+        """feature extractor NN + base kernel + Adam(lr=0.01) over kernel, mean, noise (+ NN) parameters."""
+        if not self.correlated_output:
+            raise NotImplementedError("To compile a DKL-GP trainer for independent outputs use "
+                                      "compile_multi_model_trainer(*args, **kwargs)")
+        X, y = self.set_data(X, y)
+        input_dim, embedim = self.dimdict["input_dim"], self.dimdict["embedim"]
+        feature_net = kwargs.get("feature_extractor", fcFeatureExtractor)
+        feature_extractor = feature_net(input_dim, embedim).to(self.dtype).to(self.device)
+        freeze = kwargs.get("freeze_weights", False)
+        if freeze:
+            for p in feature_extractor.parameters():
+                p.requires_grad = False
+        self.gp_model = GPRegressionModel(X, y, feature_extractor, embedim, kwargs.get("base_kernel", "rbf"))
+        self.gp_model.to(self.device)
+        self.likelihood = self.gp_model          # the Gaussian noise lives in the same module (raw_noise)
+        self.gp_model.train()
+        m = self.gp_model
+        groups = [{'params': [m.raw_lengthscale, m.raw_outputscale]}, {'params': [m.mean_constant]},
+                  {'params': [m.raw_noise]}]
+        if not freeze:
+            groups.append({'params': list(m.feature_extractor.parameters())})
+        self.optimizer = torch.optim.Adam(groups, lr=kwargs.get("lr", 0.01))
+        self.training_cycles = training_cycles
+        self.compiled = True
+
+    def train_step(self) -> None:
+        self.optimizer.zero_grad()
+        loss = -self.gp_model.mll()
+        loss.backward()
+        self.optimizer.step()
+        self.train_loss.append(loss.item())
+
+    def run(self, X=None, y=None, training_cycles: int = 1, **kwargs):
+        if not self.compiled:
+            self.compile_trainer(X, y, training_cycles, **kwargs)
+        for e in range(self.training_cycles):
+            self.train_step()
+            if e == 0 or (e + 1) % kwargs.get("print_loss", 10) == 0 or e == self.training_cycles - 1:
+                self.print_statistics(e)
+        return self.gp_model
+
+    def print_statistics(self, e):
+        print('Epoch {}/{} ...'.format(e + 1, self.training_cycles),
+              'Training loss: {}'.format(np.around(self.train_loss[-1], 4)))
+
+    def save_weights(self, filename: str) -> None:
+        """Saves the feature extractor weights only, as the reference does (gptrainer.py:347-349)."""
+        torch.save(self.gp_model.feature_extractor.state_dict(), filename)

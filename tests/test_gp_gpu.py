@@ -1,0 +1,45 @@
+"""`gpu` tier for the DKL covariance path."""
+import numpy as np
+import pytest
+import torch
+
+import _gp_checks as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("kind", ["rbf", "matern"])
+def test_kernel_matrix_and_matvec(dtype, kind):
+    G.check_kernel_matrix("cuda", dtype, kind, N=700, M=450, D=3)
+    G.check_kernel_matrix("cuda", dtype, kind, N=333, M=1260, D=8)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern"])
+def test_kernel_backward_and_mll(kind):
+    G.check_mll_and_grads("cuda", kind, N=600, D=2)
+
+
+def test_dklgpr_api():
+    G.check_dklgpr_api()
+
+
+def test_config5_covariance_properties():
+    """BASELINE.json configs[4] size (N = 16384 embedded points, RBF): size-independent properties of the tiled
+    builder — symmetry, unit-scaled diagonal, agreement of K @ v with the matrix-free mat-vec, row checksums vs
+    the fp64 build."""
+    from atomai_amd.nets.gp import kernel_matrix, kernel_matvec
+    N, D = 16384, 2
+    rs = np.random.RandomState(0)
+    Z = torch.from_numpy(rs.uniform(-1, 1, (N, D)).astype(np.float32)).cuda()
+    ls = torch.full((D,), float(np.log(2.0)), device="cuda")            # softplus(0)
+    s2 = float(np.log(2.0))
+    K = kernel_matrix(Z, Z, ls, s2, 0)
+    assert K.shape == (N, N)
+    assert float((K - K.T).abs().max()) == 0.0
+    assert float((torch.diagonal(K) - s2).abs().max()) < 1e-6
+    v = torch.from_numpy(rs.randn(N, 2).astype(np.float32)).cuda()
+    y1, y2 = K @ v, kernel_matvec(Z, Z, ls, s2, v, 0)
+    assert float((y1 - y2).abs().max() / y1.abs().max()) < 1e-4
+    K64 = kernel_matrix(Z.double(), Z.double(), ls.double(), s2, 0)
+    assert float((K.double().sum(1) - K64.sum(1)).abs().max() / K64.sum(1).abs().max()) < 1e-5
