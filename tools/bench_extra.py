@@ -92,10 +92,52 @@ def bench_predict(frames=64, hw=1024):
     return res
 
 
+def bench_dkl(N=16384, D=2):
+    """configs[4]: RBF covariance on N=16384 embedded points — HBM-write bound (4*N^2 bytes)."""
+    from atomai_amd.nets.gp import kernel_matrix, kernel_matvec, convFeatureExtractor
+    rs = np.random.RandomState(0)
+    Z = torch.from_numpy(rs.uniform(-1, 1, (N, D)).astype(np.float32)).cuda()
+    ls = torch.full((D,), float(np.log(2.0)), device="cuda")
+    s2 = float(np.log(2.0))
+    res = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        z, l = Z.to(dt), ls.to(dt)
+        for _ in range(3): K = kernel_matrix(z, z, l, s2, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): K = kernel_matrix(z, z, l, s2, 0)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        byt = N * N * K.element_size() + N * D * K.element_size()
+        res[name] = {"ms": round(ms, 4), "GBps": round(byt / ms / 1e6, 1), "frac_of_8TBps": round(byt / ms / 1e6 / 8000, 4)}
+        del K
+    v = torch.randn(N, 1, device="cuda")
+    for _ in range(2): kernel_matvec(Z, Z, ls, s2, v, 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): kernel_matvec(Z, Z, ls, s2, v, 0)
+    e1.record(); torch.cuda.synchronize()
+    res["matvec_f32_ms"] = round(e0.elapsed_time(e1) / 5, 4)
+    fe = convFeatureExtractor(256, 2).cuda().eval()
+    P = torch.randn(N, 256, device="cuda")
+    with torch.no_grad():
+        for _ in range(2): fe(P)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): fe(P)
+        torch.cuda.synchronize()
+    res["conv_extractor_16384x16x16_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    out = {"metric": "DKL RBF covariance build, N=16384, D=2", "value": res["f32"]["ms"], "unit": "ms",
+           "higher_is_better": False,
+           "roofline": {"bound": "hbm", "achieved": res["f32"]["GBps"], "peak": 8000, "unit": "GB/s",
+                        "frac": res["f32"]["frac_of_8TBps"], "traffic": None}, "detail": res}
+    print(json.dumps(out), flush=True)
+    return out
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["rvae", "predict"]
     os.makedirs("gpurun_out", exist_ok=True)
     res = {}
     for w in what:
-        res[w] = {"rvae": bench_rvae, "predict": bench_predict}[w]()
+        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl}[w]()
     json.dump(res, open("gpurun_out/bench_extra.json", "w"), indent=1)
