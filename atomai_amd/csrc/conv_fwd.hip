@@ -27,6 +27,7 @@
 //     two-pass (mean, M2) reduction per workgroup: wave shuffles -> LDS -> one partial row per
 //     tile; bn.hip merges the rows with Chan's formula in fp64 (deterministic, no atomics).
 #include "amx_device.h"
+#include <cstdlib>
 
 #define TILE 16          // output tile is TILE x TILE pixels
 #define KG 4             // k-groups (of 4 channels) per chunk -> 16 channels per chunk
@@ -49,7 +50,7 @@ struct ConvFwdArgs {
     int tiles_x, tiles_y;
 };
 
-template <int TAPS, int NT, int MAXHALO>
+template <int TAPS, int NT, int MAXHALO, bool DBUF>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     constexpr int NB = NT * 16;
     constexpr int MAXI = TILE + 2 * MAXHALO;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int IW = TILE + 2 * halo, IH = IW;
     const int plane = amx_round_up(IH * IW, 16);                 // slots (16 B) per k-group plane
-    float* s_in = smem;                                          // [KG][plane][4]
-    float* s_w = smem + KG * plane * 4;                          // [TAPS][KG][NB][4]
-    float* s_red = s_w;                                          // reused after the K loop
+    // one stage = input image [KG][plane][4] + weight image [TAPS][KG][NB][4]; two stages when DBUF
+    const int stage_floats = KG * plane * 4 + TAPS * KG * NB * 4;
+    float* s_red = smem;                                         // reused after the K loop
 
     int t = blockIdx.x;
     const int tx = t % a.tiles_x; t /= a.tiles_x;
@@ -119,7 +120,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
     };
 
-    auto stage_to_lds = [&]() {
+    auto stage_to_lds = [&](int stage) {
+        float* s_in = smem + (size_t)stage * stage_floats;
+        float* s_w = s_in + KG * plane * 4;
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
             const int pix = (tid + i * 256) >> 2;
@@ -145,14 +148,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         #pragma unroll
         for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue_loads(0);
-    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        stage_to_lds();
-        __syncthreads();
-        if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
-
+    auto compute_taps = [&](int stage, int tap0, int tap1) {
+        const float* s_in = smem + (size_t)stage * stage_floats;
+        const float* s_w = s_in + KG * plane * 4;
         #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap < tap0 || tap >= tap1) continue;
             const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
             const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
             float4 af[4], bf[NT];
@@ -164,17 +165,41 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             #pragma unroll
             for (int q = 0; q < NT; ++q)
                 bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
-            #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                #pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bf[q].x, acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bf[q].y, acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bf[q].z, acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bf[q].w, acc[m][q], 0, 0, 0);
-                }
+            // k-subgroup outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32 MFMA has a
+            // 40-cycle dependent latency vs a 32-cycle issue interval)
+            #define AMX_CONV_MFMA(C)                                                                    \
+                _Pragma("unroll") for (int m = 0; m < 4; ++m)                                           \
+                    _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
+            AMX_CONV_MFMA(x) AMX_CONV_MFMA(y) AMX_CONV_MFMA(z) AMX_CONV_MFMA(w)
+            #undef AMX_CONV_MFMA
         }
+    };
+
+    issue_loads(0);
+    if (DBUF) {
+        // Software pipeline over two LDS stages: the global loads of chunk c+1 are issued before, and their
+        // LDS image is written in the middle of, the MFMA stream of chunk c -> ONE barrier per chunk and no
+        // staging gap in the matrix pipe.
+        stage_to_lds(0);
         __syncthreads();
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            const int cur = chunk & 1;
+            const bool more = chunk + 1 < a.nchunk;
+            if (more) issue_loads(chunk + 1);
+            compute_taps(cur, 0, (TAPS + 1) / 2);
+            if (more) stage_to_lds(cur ^ 1);
+            compute_taps(cur, (TAPS + 1) / 2, TAPS);
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            stage_to_lds(0);
+            __syncthreads();
+            if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
+            compute_taps(0, 0, TAPS);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias + LeakyReLU (+addend), store, statistics ----
@@ -262,25 +287,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     }
 }
 
-template <int TAPS, int NT, int MAXHALO>
+template <int TAPS, int NT, int MAXHALO, bool DBUF>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int I = TILE + 2 * halo;
     const int plane = amx_round_up(I * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
     if (lds_w < (size_t)4 * NT * 16 * sizeof(float)) lds_w = (size_t)4 * NT * 16 * sizeof(float);
-    const size_t lds = (size_t)KG * plane * 4 * sizeof(float) + lds_w;
+    const size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
     dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -312,20 +337,28 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, TILE);
     if (Y0s + Y1s < cout) AMX_BADARG(8);
     hipStream_t s = (hipStream_t)stream;
-    const int nt = a.cop >= 64 ? 4 : (a.cop > 32 ? 4 : (a.cop > 16 ? 2 : 1));
-    if (taps == 1) {
-        if (nt == 1) return launch_conv_fwd<1, 1, 0>(a, s);
-        if (nt == 2) return launch_conv_fwd<1, 2, 0>(a, s);
-        return launch_conv_fwd<1, 4, 0>(a, s);
+    // NT (16-cout tiles per workgroup): wide tiles amortise the input image over more MFMAs but need deep K
+    // (several chunks) to amortise their prologue/epilogue at one workgroup per CU.
+    int nt = a.cop > 32 ? ((a.nchunk >= 3 || a.cop > 64) ? 4 : 2) : (a.cop > 16 ? 2 : 1);
+    if (const char* e = getenv("AMX_CONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt = v; }
+    bool dbuf = false;   // measured slower than single-stage + co-resident workgroups (profiles/r01_conv_variants.md)
+    if (const char* e = getenv("AMX_CONV_DBUF")) dbuf = atoi(e) != 0;
+#define CONV_DISPATCH(T, H_)                                                            \
+    if (dbuf) {                                                                         \
+        if (nt == 1) return launch_conv_fwd<T, 1, H_, true>(a, s);                      \
+        if (nt == 2) return launch_conv_fwd<T, 2, H_, true>(a, s);                      \
+        return launch_conv_fwd<T, 4, H_, true>(a, s);                                   \
+    } else {                                                                            \
+        if (nt == 1) return launch_conv_fwd<T, 1, H_, false>(a, s);                     \
+        if (nt == 2) return launch_conv_fwd<T, 2, H_, false>(a, s);                     \
+        return launch_conv_fwd<T, 4, H_, false>(a, s);                                  \
     }
-    if (dil == 1) {
-        if (nt == 1) return launch_conv_fwd<9, 1, 1>(a, s);
-        if (nt == 2) return launch_conv_fwd<9, 2, 1>(a, s);
-        return launch_conv_fwd<9, 4, 1>(a, s);
-    }
-    if (nt == 1) return launch_conv_fwd<9, 1, 6>(a, s);
-    if (nt == 2) return launch_conv_fwd<9, 2, 6>(a, s);
-    return launch_conv_fwd<9, 4, 6>(a, s);
+    if (taps == 1) { CONV_DISPATCH(1, 0) }
+    if (dil == 1) { CONV_DISPATCH(9, 1) }
+#undef CONV_DISPATCH
+    if (nt == 1) return launch_conv_fwd<9, 1, 6, false>(a, s);
+    if (nt == 2) return launch_conv_fwd<9, 2, 6, false>(a, s);
+    return launch_conv_fwd<9, 4, 6, false>(a, s);
 }
 
 // Number of float partial-statistics rows amx_conv2d_fwd writes: rows x 2 x round_up(cout,16).

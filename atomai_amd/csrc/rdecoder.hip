@@ -101,14 +101,19 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
     for (int t = 0; t < G::PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     #pragma unroll
     for (int c = 0; c < HID / 16; ++c) {
+        float4 bq[G::PT];
         #pragma unroll
-        for (int t = 0; t < G::PT; ++t) {
-            const float4 bq = amx_ld4(src + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq.w, acc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(src + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+        // k-subgroup outermost so that consecutive MFMAs target different accumulators (40-cycle dependent
+        // latency vs 32-cycle issue of v_mfma_f32_16x16x4_f32)
+        #pragma unroll
+        for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq[t].x, acc[t], 0, 0, 0);
+        #pragma unroll
+        for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq[t].y, acc[t], 0, 0, 0);
+        #pragma unroll
+        for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq[t].z, acc[t], 0, 0, 0);
+        #pragma unroll
+        for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq[t].w, acc[t], 0, 0, 0);
     }
     // D'[row = feature 16*wave + 4g + r][col = pixel 16t + p]
     const float4 bias = amx_ld4(bl + 16 * wave + 4 * g);
@@ -294,14 +299,17 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             for (int t = 0; t < G::PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             #pragma unroll
             for (int c = 0; c < HID / 16; ++c) {
+                float4 bq[G::PT];
                 #pragma unroll
-                for (int t = 0; t < G::PT; ++t) {
-                    const float4 bq = amx_ld4(ga + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq.w, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(ga + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+                #pragma unroll
+                for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq[t].x, acc[t], 0, 0, 0);
+                #pragma unroll
+                for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].y, bq[t].y, acc[t], 0, 0, 0);
+                #pragma unroll
+                for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].z, bq[t].z, acc[t], 0, 0, 0);
+                #pragma unroll
+                for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq[t].w, acc[t], 0, 0, 0);
             }
             __syncthreads();                     // every wave is done reading hin = H[l] and ga
             // turn gh_{l} (grad w.r.t. h_l, the layer's INPUT) into the pre-activation gradient of the

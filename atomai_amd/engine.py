@@ -187,7 +187,7 @@ class ConvNode(_Node):
                 mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
                 nrows = self.rows
                 if nrows > 512:          # two-stage merge: coalesced chunk merge first, then per channel
-                    nch = 128
+                    nch = min(1024, nrows // 32)
                     merged = _empty((nch, 3, cop), y)
                     L.call("amx_bn_stats_merge", L.ptr(stats), nrows, cop, stat_mode, N, H, W,
                            self.rows_pix, nch, L.ptr(merged), _sp(y))
@@ -248,6 +248,24 @@ class ConvNode(_Node):
             tape.add_param_grad(self.conv.bias, db)
         w = self.conv.weight
         dw = grad_buffer(w, a)
+        # The weight gradient (MFMA-bound) has no consumer inside backward: run it on the tape's side stream so
+        # that it overlaps the HBM-bound BatchNorm-backward / pooling kernels of the layers below.
+        with tape.side(a, keep=(dpre, dy, a)):
+            self._wgrad(tape, dpre, dw, a)
+        if self.x_plain is not None:
+            return
+        s0 = self.srcs[0]
+        s1 = self.srcs[1] if len(self.srcs) > 1 else None
+        N, H, W = s0.N, s0.H, s0.W
+        C0, C0s = s0.C, s0.Cs
+        C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
+        cos = out.Cs
+        self._dgrad(tape, dpre, s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp)
+
+    def _wgrad(self, tape, dpre, dw, a) -> None:
+        w = self.conv.weight
+        cos = self.out.Cs
+        sp = _sp(a)
         if self.x_plain is not None:
             x = self.x_plain
             N, _, H, W = x.shape
@@ -270,7 +288,7 @@ class ConvNode(_Node):
                L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), cos, L.ptr(part), N, H, W, self.cout,
                self.taps, self.dil, sp)
         if wrows > 64:                   # two-stage: coalesced chunk sums first
-            nch = 32
+            nch = 32 if wrows < 1024 else 128
             ncols = self.taps * ci_pad * co_pad
             part2 = _empty((nch, ncols), a)
             L.call("amx_reduce_rows_chunked", L.ptr(part), wrows, ncols, nch, L.ptr(part2), sp)
@@ -278,7 +296,10 @@ class ConvNode(_Node):
         L.call("amx_wgrad_reduce", L.ptr(part), wrows, self.taps, ci_pad, co_pad, C0, C0s, C1, self.cout,
                L.ptr(dw), sp)
         tape.add_param_grad(w, dw)
+
+    def _dgrad(self, tape, dpre, s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp) -> None:
         # ---- data gradient(s): forward conv of dpre with the flipped / transposed weight image
+        w = self.conv.weight
         need0 = s0.needs_grad
         need1 = bool(s1 and s1.needs_grad)
         if not (need0 or need1):
@@ -458,12 +479,49 @@ class PxNode(_Node):
 
 
 # ====================================================================================== tape
+class _SideCtx:
+    """Runs the enclosed launches on the tape's side stream, ordered after everything issued so far on the main
+    stream; tensors in `keep` stay referenced until the streams are joined at the end of backward."""
+
+    def __init__(self, tape, like, keep):
+        self.tape, self.like, self.keep = tape, like, keep
+        self.ctx = None
+
+    def __enter__(self):
+        t = self.tape
+        if not (self.like.is_cuda and t.use_side_stream):
+            return self
+        dev = self.like.device
+        if t.side_stream is None:
+            t.side_stream = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        t.side_stream.wait_event(ev)
+        t.keepalive.extend(self.keep)
+        self.ctx = torch.cuda.stream(t.side_stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class Tape:
+    use_side_stream = True
+
     def __init__(self, training: bool, need_grad: bool):
         self.training = training
         self.need_grad = need_grad
         self.nodes: List[_Node] = []
         self.param_grads: Dict[int, tuple] = {}
+        self.side_stream = None
+        self.keepalive: list = []
+
+    def side(self, like: torch.Tensor, keep=()):
+        return _SideCtx(self, like, keep)
 
     # ---- graph construction (each call launches the forward kernels immediately)
     def _push(self, node):
@@ -521,3 +579,11 @@ class Tape:
         for node in reversed(self.nodes):
             node.backward(self)
         self.nodes = []
+        if self.side_stream is not None:          # join: gradients written on the side stream are now visible
+            ev = torch.cuda.Event()
+            ev.record(self.side_stream)
+            torch.cuda.current_stream(self.side_stream.device).wait_event(ev)
+            for t in self.keepalive:
+                if t is not None:
+                    t.record_stream(self.side_stream)
+        self.keepalive = []
