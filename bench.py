@@ -152,7 +152,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ksteps = 0
-    if timer and rank == 0:
+    if timer:                      # every rank takes part (the step contains the gradient all-reduce)
         # Per-kernel HIP-event pass, in the same run right after the timed region: the step normally overlaps
         # the weight-gradient kernels with HBM-bound kernels on a second stream, which makes per-launch event
         # durations meaningless, so this pass serialises everything on one stream (it does not enter `value`).
@@ -191,8 +191,12 @@ def main():
         conv = summ.get("amx_conv2d_fwd")
         if conv:
             ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12
+            traffic = None                   # HBM bytes per launch from the committed rocprofv3 PMC pass
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc))["conv_fwd_family"]["hbm_MB_per_launch"] * 1e6
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic,
                                "kernel": "conv_fwd_kernel<TAPS,NT,HALO> (amx_conv2d_fwd: all forward + dgrad "
                                          "launches of the step)",
                                "launches_per_step": conv["calls"] // ksteps,
