@@ -38,14 +38,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         if (tid == 0) { scale[c] = 0.f; shift[c] = 0.f; save_mean[c] = 0.f; save_invstd[c] = 0.f; }
         return;
     }
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int th = (mode == 0 && rows_pix > 0) ? rows_pix : 16;      // conv tile height (mode 0)
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + th - 1) / th;
     const long P = (long)N * H * W;
     const int planes = mode == 2 ? 3 : 2;
     auto row_count = [&](int r) -> double {
         if (mode == 2) return (double)stats[((size_t)r * 3 + 2) * cop + c];
         if (mode == 0) {
             const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
-            const int vx = min(16, W - tx * 16), vy = min(16, H - ty * 16);
+            const int vx = min(16, W - tx * 16), vy = min(th, H - ty * th);
             return (double)(vx * vy);
         }
         const long left = P - (long)r * rows_pix;
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
                                                             float* __restrict__ out) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= cop) return;
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    const int th = (mode == 0 && rows_pix > 0) ? rows_pix : 16;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + th - 1) / th;
     const long P = (long)N * H * W;
     const int r0 = blockIdx.y * chunk;
     const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
         double nr;
         if (mode == 0) {
             const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
-            nr = (double)(min(16, W - tx * 16) * min(16, H - ty * 16));
+            nr = (double)(min(16, W - tx * 16) * min(th, H - ty * th));
         } else {
             const long left = P - (long)r * rows_pix;
             nr = (double)(left < rows_pix ? left : rows_pix);

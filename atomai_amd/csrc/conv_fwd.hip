@@ -48,13 +48,15 @@ struct ConvFwdArgs {
     int dil;             // dilation (== halo) for 9 taps; ignored for 1 tap
     float slope;         // LeakyReLU negative slope; 1.0f == no activation
     int tiles_x, tiles_y;
+    int th;              // tile height in pixels (16 or 32)
 };
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF>
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+    constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
     constexpr int MAXI = TILE + 2 * MAXHALO;
-    constexpr int XLD = (MAXI * MAXI * KG + 255) / 256;          // float4 loads per thread (input)
+    constexpr int XLD = ((TH + 2 * MAXHALO) * MAXI * KG + 255) / 256;          // float4 loads per thread (input)
     constexpr int WLD = (TAPS * KG * NB + 255) / 256;            // float4 loads per thread (weights)
     AMX_DYN_SMEM(float, smem);
 
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
     const int halo = (TAPS == 9) ? a.dil : 0;
-    const int IW = TILE + 2 * halo, IH = IW;
+    const int IW = TILE + 2 * halo, IH = TH + 2 * halo;
     const int plane = amx_round_up(IH * IW, 16);                 // slots (16 B) per k-group plane
     // one stage = input image [KG][plane][4] + weight image [TAPS][KG][NB][4]; two stages when DBUF
     const int stage_floats = KG * plane * 4 + TAPS * KG * NB * 4;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
     const int n0 = blockIdx.y * NB;                              // first cout of this workgroup
-    const int gy0 = ty * TILE - halo, gx0 = tx * TILE - halo;
+    const int gy0 = ty * TH - halo, gx0 = tx * TILE - halo;
 
     // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
     const int my_kg = tid & (KG - 1);
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
     };
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MTW][NT];
     #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MTW; ++m)
         #pragma unroll
         for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -156,10 +158,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             if (tap < tap0 || tap >= tap1) continue;
             const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
             const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
-            float4 af[4], bf[NT];
+            float4 af[MTW], bf[NT];
             #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int slot = (wave * 4 + m + halo + dy) * IW + (p + halo + dx);
+            for (int m = 0; m < MTW; ++m) {
+                const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
                 af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
             }
             #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             // k-subgroup outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32 MFMA has a
             // 40-cycle dependent latency vs a 32-cycle issue interval)
             #define AMX_CONV_MFMA(C)                                                                    \
-                _Pragma("unroll") for (int m = 0; m < 4; ++m)                                           \
+                _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
                     _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
                         acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
             AMX_CONV_MFMA(x) AMX_CONV_MFMA(y) AMX_CONV_MFMA(z) AMX_CONV_MFMA(w)
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
 
     // ---- epilogue: bias + LeakyReLU (+addend), store, statistics ----
     // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
-    const int oy0 = ty * TILE + wave * 4, ox0 = tx * TILE + 4 * g;
+    const int oy0 = ty * TH + wave * MTW, ox0 = tx * TILE + 4 * g;
     const int ctot = a.Y0s + a.Y1s;
     float lsum[NT];
     #pragma unroll
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         else if (co < ctot) { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
         lsum[q] = 0.f;
         #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MTW; ++m)
             #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = oy0 + m, ox = ox0 + r;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     }
     if (!a.stats) return;
 
-    const int vy = min(TILE, a.H - ty * TILE), vx = min(TILE, a.W - tx * TILE);
+    const int vy = min(TH, a.H - ty * TH), vx = min(TILE, a.W - tx * TILE);
     const float inv_cnt = 1.0f / (float)(vy * vx);
     // pass 1: per-cout sum over the tile -> mean
     #pragma unroll
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         const float mu = mean[q] * inv_cnt;
         float s2 = 0.f;
         #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MTW; ++m)
             #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
@@ -287,11 +289,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     }
 }
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF>
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int I = TILE + 2 * halo;
-    const int plane = amx_round_up(I * I, 16);
+    const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
     if (lds_w < (size_t)4 * NT * 16 * sizeof(float)) lds_w = (size_t)4 * NT * 16 * sizeof(float);
     const size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
@@ -299,15 +301,35 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
+}
+
+struct ConvPlan { int nt, th; };
+
+// Tile plan, from the per-shape measurements in profiles/r01_conv_variants.md: this kernel is fastest with MANY
+// small co-resident workgroups (they hide each other's prologue / staging / epilogue), so the default tile is
+// 8 rows x 16 pixels x 32 couts; only deep-K wide layers (Cin >= 128, Cout >= 64) pay for 16 rows x 64 couts.
+// Rejected by measurement: 32-row tiles (-25 %), 4-row tiles (-5 %), a two-stage LDS pipeline (-5..25 %),
+// occupancy forced through __launch_bounds__ (spills, -20..60 %).
+static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
+    ConvPlan pl;
+    const int cop = amx_round_up(cout, 16);
+    const int nchunk = amx_ceil_div(Cin_s, 4 * KG);
+    const bool small = taps == 9 && dil == 1;               // variants with 8-row tiles exist for plain 3x3
+    if (cop <= 16) { pl.nt = 1; pl.th = 16; }
+    else if (cop >= 64 && (nchunk >= 8 || !small)) { pl.nt = 4; pl.th = 16; }
+    else { pl.nt = 2; pl.th = small ? 8 : 16; }
+    if (const char* e = getenv("AMX_CONV_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && v * 16 <= cop) pl.nt = v; }
+    if (const char* e = getenv("AMX_CONV_TH")) { const int v = atoi(e); if (v == 16 || (v == 8 && small)) pl.th = v; }
+    return pl;
 }
 
 // C ABI — see include/atomai_amd.h for the contract.
@@ -334,34 +356,39 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     a.cop = amx_round_up(cout, 16);
     a.nchunk = amx_ceil_div(C0s + C1s, 4 * KG);
     a.dil = dil; a.slope = slope;
-    a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, TILE);
     if (Y0s + Y1s < cout) AMX_BADARG(8);
     hipStream_t s = (hipStream_t)stream;
-    // NT (16-cout tiles per workgroup): wide tiles amortise the input image over more MFMAs but need deep K
-    // (several chunks) to amortise their prologue/epilogue at one workgroup per CU.
-    int nt = a.cop > 32 ? ((a.nchunk >= 3 || a.cop > 64) ? 4 : 2) : (a.cop > 16 ? 2 : 1);
-    if (const char* e = getenv("AMX_CONV_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt = v; }
-    bool dbuf = false;   // measured slower than single-stage + co-resident workgroups (profiles/r01_conv_variants.md)
-    if (const char* e = getenv("AMX_CONV_DBUF")) dbuf = atoi(e) != 0;
-#define CONV_DISPATCH(T, H_)                                                            \
-    if (dbuf) {                                                                         \
-        if (nt == 1) return launch_conv_fwd<T, 1, H_, true>(a, s);                      \
-        if (nt == 2) return launch_conv_fwd<T, 2, H_, true>(a, s);                      \
-        return launch_conv_fwd<T, 4, H_, true>(a, s);                                   \
-    } else {                                                                            \
-        if (nt == 1) return launch_conv_fwd<T, 1, H_, false>(a, s);                     \
-        if (nt == 2) return launch_conv_fwd<T, 2, H_, false>(a, s);                     \
-        return launch_conv_fwd<T, 4, H_, false>(a, s);                                  \
+    const ConvPlan pl = plan_conv(C0s + C1s, cout, taps, dil, H);
+    const int nt = pl.nt;
+    a.th = pl.th;
+    a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
+    // (the two-stage LDS pipeline, DBUF = true, was measured slower for every layer shape and is not instantiated:
+    //  profiles/r01_conv_variants.md)
+    if (taps == 1) {
+        if (nt == 1) return launch_conv_fwd<1, 1, 0, false, 4>(a, s);
+        if (nt == 2) return launch_conv_fwd<1, 2, 0, false, 4>(a, s);
+        return launch_conv_fwd<1, 4, 0, false, 4>(a, s);
     }
-    if (taps == 1) { CONV_DISPATCH(1, 0) }
-    if (dil == 1) { CONV_DISPATCH(9, 1) }
-#undef CONV_DISPATCH
-    if (nt == 1) return launch_conv_fwd<9, 1, 6, false>(a, s);
-    if (nt == 2) return launch_conv_fwd<9, 2, 6, false>(a, s);
-    return launch_conv_fwd<9, 4, 6, false>(a, s);
+    if (dil == 1) {
+        if (pl.th == 8) {
+            if (nt == 1) return launch_conv_fwd<9, 1, 1, false, 2>(a, s);
+            if (nt == 2) return launch_conv_fwd<9, 2, 1, false, 2>(a, s);
+            return launch_conv_fwd<9, 4, 1, false, 2>(a, s);
+        }
+        if (nt == 1) return launch_conv_fwd<9, 1, 1, false, 4>(a, s);
+        if (nt == 2) return launch_conv_fwd<9, 2, 1, false, 4>(a, s);
+        return launch_conv_fwd<9, 4, 1, false, 4>(a, s);
+    }
+    if (nt == 1) return launch_conv_fwd<9, 1, 6, false, 4>(a, s);
+    if (nt == 2) return launch_conv_fwd<9, 2, 6, false, 4>(a, s);
+    return launch_conv_fwd<9, 4, 6, false, 4>(a, s);
 }
 
-// Number of float partial-statistics rows amx_conv2d_fwd writes: rows x 2 x round_up(cout,16).
-extern "C" int amx_conv2d_num_tiles(int N, int H, int W) {
-    return amx_ceil_div(W, TILE) * amx_ceil_div(H, TILE) * N;
+// Tile height (16 or 32) amx_conv2d_fwd will use for this layer, and the number of partial-statistics rows
+// (tiles) it then writes: rows x 2 x round_up(cout,16).
+extern "C" int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H) {
+    return plan_conv(Cin_s, cout, taps, dil, H).th;
+}
+extern "C" int amx_conv2d_num_tiles(int N, int H, int W, int th) {
+    return amx_ceil_div(W, TILE) * amx_ceil_div(H, th) * N;
 }

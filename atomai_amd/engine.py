@@ -169,8 +169,9 @@ class ConvNode(_Node):
             wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 0)
             bias = b.detach() if b is not None else None
             y = _empty((N, H, W, cos), s0.t)
-            self.rows = L.load().amx_conv2d_num_tiles(N, H, W)
-            self.rows_pix = 0
+            th = L.load().amx_conv2d_tile_h(C0s + C1s, self.cout, self.taps, self.dil, H)
+            self.rows = L.load().amx_conv2d_num_tiles(N, H, W, th)
+            self.rows_pix = th                               # mode 0: the conv tile height
             stats = _empty((self.rows, 2, cop), s0.t) if training_bn else None
             L.call("amx_conv2d_fwd", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
                    L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),

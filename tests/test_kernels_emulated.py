@@ -83,3 +83,11 @@ def test_conv_layer_wide_channels(cin, cout, H, N):
     assert float((x1.grad.double() - x2.grad).abs().max() / x2.grad.abs().max()) < 1e-4
     for (k, p), (_, p2) in zip(m.block.named_parameters(), ref.named_parameters()):
         assert float((p.grad.double() - p2.grad).abs().max() / p2.grad.abs().max()) < 1e-4, k
+
+
+@pytest.mark.parametrize("cin,cout,H", [(16, 32, 40), (32, 16, 36)])
+def test_conv_layer_16_row_tiles(cin, cout, H, monkeypatch):
+    """The 16-row tile variant forced where the plan would pick 8 rows, with image heights that are not a
+    multiple of either tile."""
+    monkeypatch.setenv("AMX_CONV_TH", "16")
+    test_conv_layer_wide_channels(cin, cout, H, 1)

@@ -34,7 +34,7 @@ def run(N, H, W, C0, C1, Cout, taps, dil=1, slope=0.01, check=True, iters=10, st
     cop = (Cout + 15) // 16 * 16
     bias = torch.zeros(cop, device=dev); bias[:Cout] = b
     y = torch.empty(N, H, W, Cos, device=dev)
-    nt = L.load().amx_conv2d_num_tiles(N, H, W)
+    nt = L.load().amx_conv2d_num_tiles(N, H, W, 16)
     stats = torch.empty(nt, 2, cop, device=dev) if stats_on else None
     def go():
         L.call("amx_conv2d_fwd", L.ptr(X0), L.ptr(sc), L.ptr(sh), C0s, L.ptr(X1), None, None, C1s,

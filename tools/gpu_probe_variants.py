@@ -14,7 +14,7 @@ def run(N, H, C0, C1, Cout, iters=20):
     L.call("amx_pack_weights", L.ptr(w), L.ptr(wpk), Cout, C0, C0, C1, C1, 9, 0, L.stream_ptr(w))
     cop = (Cout + 15) // 16 * 16
     bias = torch.zeros(Cout, device=dev); y = torch.empty(N, H, H, Cout, device=dev)
-    stats = torch.empty(L.load().amx_conv2d_num_tiles(N, H, H), 2, cop, device=dev)
+    stats = torch.empty(L.load().amx_conv2d_num_tiles(N, H, H, 4), 2, cop, device=dev)
     def go():
         L.call("amx_conv2d_fwd", L.ptr(X0), L.ptr(sc), L.ptr(sh), C0, L.ptr(X1), None, None, C1, L.ptr(wpk), L.ptr(bias),
                None, L.ptr(y), Cout, None, 0, L.ptr(stats), N, H, H, Cout, 9, 1, 0.01, L.stream_ptr(y))
@@ -29,13 +29,14 @@ def run(N, H, C0, C1, Cout, iters=20):
 shapes = [(256, 16, 0, 32), (256, 32, 0, 32), (128, 32, 0, 64), (128, 64, 0, 64), (64, 64, 0, 128), (64, 128, 0, 128),
           (128, 64, 64, 64), (256, 32, 32, 32), (512, 16, 16, 16), (512, 16, 0, 32), (256, 32, 0, 64), (128, 64, 0, 128)]
 res = {}
-for dbuf in os.environ.get("PROBE_DBUF", "0").split(","):
+for th in ("8", "4"):
     for nt in ("1", "2", "4"):
-        os.environ["AMX_CONV_DBUF"] = dbuf; os.environ["AMX_CONV_NT"] = nt
+        os.environ["AMX_CONV_TH"] = th; os.environ["AMX_CONV_NT"] = nt
+        if th == "4" and nt == "1": continue
         for sh_ in shapes:
             if int(nt) * 16 > (sh_[3] + 15) // 16 * 16: continue
             ms, fr = run(32, *sh_)
-            res[f"dbuf{dbuf}_nt{nt}_{sh_}"] = (round(ms, 4), round(fr, 3))
+            res[f"th{th}_nt{nt}_{sh_}"] = (round(ms, 4), round(fr, 3))
 for sh_ in shapes:
     row = {k.split('_(')[0]: v for k, v in res.items() if k.endswith(str(sh_))}
     print(sh_, row, flush=True)
