@@ -15,8 +15,8 @@
 // amx_wgrad_reduce (conv1.hip) sums in fp64 -> deterministic, no float atomics.
 #include "amx_device.h"
 
+#include <cstdlib>
 #define TW 16
-#define TH 8
 
 struct WgradArgs {
     const float* x0; const float* sc0; const float* sh0; int C0s;
@@ -30,7 +30,7 @@ struct WgradArgs {
     int co_blocks;
 };
 
-template <int TAPS, int NT, int WM, int MAXHALO>
+template <int TAPS, int NT, int WM, int MAXHALO, int TH>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int CIB = 16 * WM;
     constexpr int CG = CIB / 4;                                   // float4 groups per pixel (x)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
 }
 
-template <int TAPS, int NT, int WM, int MAXHALO>
+template <int TAPS, int NT, int WM, int MAXHALO, int TH>
 static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     constexpr int CIB = 16 * WM;
     constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;
@@ -189,18 +189,18 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TAPS, NT, WM, MAXHALO>,
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TAPS, NT, WM, MAXHALO, TH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((wgrad_kernel<TAPS, NT, WM, MAXHALO>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((wgrad_kernel<TAPS, NT, WM, MAXHALO, TH>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
 
-struct WgradPlan { int NT, WM, WN, WK, ksplit, rows, ci_pad, co_pad; };
+struct WgradPlan { int NT, WM, WN, WK, ksplit, rows, ci_pad, co_pad, th; };
 
 static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, int dil) {
     WgradPlan pl;
@@ -215,7 +215,12 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     while (pl.WN * 2 <= rem && pl.WN * 2 <= co_tiles && 16 * pl.NT * pl.WN * 2 <= 64) pl.WN *= 2;
     pl.WK = rem / pl.WN;
     const int blocks = amx_ceil_div(pl.ci_pad, 16 * pl.WM) * amx_ceil_div(pl.co_pad, 16 * pl.NT * pl.WN);
-    const int ntiles = amx_ceil_div(W, TW) * amx_ceil_div(H, TH) * N;
+    // 4-row tiles: smaller LDS / register footprint -> more co-resident workgroups (+10..20 % measured,
+    // profiles/r01_conv_variants.md); the narrow NT == 1 case prefers 8 rows
+    pl.th = (taps == 9 && dil == 1 && pl.NT == 2) ? 4 : 8;
+    if (const char* e = getenv("AMX_WGRAD_TH")) { const int v = atoi(e); if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }
+    if (pl.WK > pl.th) pl.WK = pl.th;
+    const int ntiles = amx_ceil_div(W, TW) * amx_ceil_div(H, pl.th) * N;
     int ks = amx_ceil_div(1024, blocks);
     if (ks > ntiles) ks = ntiles;
     if (ks < 1) ks = 1;
@@ -247,22 +252,25 @@ extern "C" int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* 
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     a.ci_pad = pl.ci_pad; a.co_pad = pl.co_pad;
     a.WN = pl.WN; a.WK = pl.WK; a.ksplit = pl.ksplit;
-    a.tiles_x = amx_ceil_div(W, TW); a.tiles_y = amx_ceil_div(H, TH);
+    a.tiles_x = amx_ceil_div(W, TW); a.tiles_y = amx_ceil_div(H, pl.th);
     a.co_blocks = amx_ceil_div(pl.co_pad, 16 * pl.NT * pl.WN);
     hipStream_t s = (hipStream_t)stream;
-#define WG_DISPATCH(T, H_)                                                         \
+#define WG_DISPATCH(T, H_, TH_)                                                   \
     if (pl.NT == 1) {                                                              \
-        if (pl.WM == 1) return launch_wgrad<T, 1, 1, H_>(a, s);                     \
-        if (pl.WM == 2) return launch_wgrad<T, 1, 2, H_>(a, s);                     \
-        return launch_wgrad<T, 1, 4, H_>(a, s);                                     \
+        if (pl.WM == 1) return launch_wgrad<T, 1, 1, H_, TH_>(a, s);                \
+        if (pl.WM == 2) return launch_wgrad<T, 1, 2, H_, TH_>(a, s);                \
+        return launch_wgrad<T, 1, 4, H_, TH_>(a, s);                                \
     } else {                                                                       \
-        if (pl.WM == 1) return launch_wgrad<T, 2, 1, H_>(a, s);                     \
-        if (pl.WM == 2) return launch_wgrad<T, 2, 2, H_>(a, s);                     \
-        return launch_wgrad<T, 2, 4, H_>(a, s);                                     \
+        if (pl.WM == 1) return launch_wgrad<T, 2, 1, H_, TH_>(a, s);                \
+        if (pl.WM == 2) return launch_wgrad<T, 2, 2, H_, TH_>(a, s);                \
+        return launch_wgrad<T, 2, 4, H_, TH_>(a, s);                                \
     }
-    if (taps == 1) { WG_DISPATCH(1, 0) }
-    if (dil == 1) { WG_DISPATCH(9, 1) }
-    if (pl.NT == 1) return launch_wgrad<9, 1, 1, 6>(a, s);
-    return launch_wgrad<9, 2, 1, 6>(a, s);
+    if (taps == 1) { WG_DISPATCH(1, 0, 8) }
+    if (dil == 1) {
+        if (pl.th == 4) { WG_DISPATCH(9, 1, 4) }
+        WG_DISPATCH(9, 1, 8)
+    }
+    if (pl.NT == 1) return launch_wgrad<9, 1, 1, 6, 8>(a, s);
+    return launch_wgrad<9, 2, 1, 6, 8>(a, s);
 #undef WG_DISPATCH
 }

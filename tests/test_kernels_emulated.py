@@ -91,3 +91,9 @@ def test_conv_layer_16_row_tiles(cin, cout, H, monkeypatch):
     multiple of either tile."""
     monkeypatch.setenv("AMX_CONV_TH", "16")
     test_conv_layer_wide_channels(cin, cout, H, 1)
+
+
+@pytest.mark.parametrize("cin,cout,H", [(64, 32, 20), (16, 16, 36)])
+def test_wgrad_4_row_tiles(cin, cout, H, monkeypatch):
+    monkeypatch.setenv("AMX_WGRAD_TH", "4")
+    test_conv_layer_wide_channels(cin, cout, H, 1)
