@@ -202,7 +202,7 @@ extern "C" int amx_bn_bwd_reduce(const float* dy, const float* a, long npix, int
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
-    const float* __restrict__ part, int rows, int Cs, int C, double inv_n,
+    const float* __restrict__ part, int rows, int stride, int Cs, int C, double inv_n,
     const float* __restrict__ gamma, const float* __restrict__ save_mean,
     const float* __restrict__ save_invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3) {
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     if (c >= C) { if (tid == 0) { k1[c] = 0.f; k2[c] = 0.f; k3[c] = 0.f; } return; }
     double a1 = 0.0, a2 = 0.0;
     for (int r = tid; r < rows; r += 256) {
-        a1 += (double)part[((size_t)r * 2) * Cs + c];
-        a2 += (double)part[((size_t)r * 2 + 1) * Cs + c];
+        a1 += (double)part[((size_t)r * 2) * stride + c];
+        a2 += (double)part[((size_t)r * 2 + 1) * stride + c];
     }
     r1[tid] = a1; r2[tid] = a2; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -230,13 +230,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     }
 }
 
-extern "C" int amx_bn_bwd_finalize(const float* part, int rows, int Cs, int C, long npix,
+extern "C" int amx_bn_bwd_finalize(const float* part, int rows, int stride, int Cs, int C, long npix,
                                    const float* gamma, const float* save_mean,
                                    const float* save_invstd, float* dgamma, float* dbeta, float* k1,
                                    float* k2, float* k3, void* stream) {
     if (!part || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !k1 || !k2 || !k3)
         AMX_BADARG(1);
-    AMX_LAUNCH(bn_bwd_finalize_kernel, dim3(Cs), dim3(256), 0, (hipStream_t)stream, part, rows, Cs, C,
+    if (stride < C) AMX_BADARG(2);
+    AMX_LAUNCH(bn_bwd_finalize_kernel, dim3(Cs), dim3(256), 0, (hipStream_t)stream, part, rows, stride, Cs, C,
                1.0 / (double)npix, gamma, save_mean, save_invstd, dgamma, dbeta, k1, k2, k3);
     AMX_CHECK_LAUNCH();
     return 0;

@@ -111,11 +111,16 @@ extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, 
     return 0;
 }
 
-// dW[co][0][t] = sum_p dpre[p][co] * x[p + tap t];  partial rows part[blk][9][Cs]
+// dW[co][0][t] = sum_p dpre[p][co] * x[p + tap t];  partial rows part[blk][9][Cs] (+ row 9 = sum_p dpre when
+// aux != nullptr: dpre = lrelu'(a) * (k1*dy + k2*a + k3) is then formed on load and the bias gradient comes along)
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ dpre,
+                                                          const float* __restrict__ aux,
+                                                          const float* __restrict__ k1,
+                                                          const float* __restrict__ k2,
+                                                          const float* __restrict__ k3, float bslope,
                                                           float* __restrict__ part, int N, int H, int W,
-                                                          int Cs, int dil, int ppb) {
+                                                          int Cs, int dil, int ppb, int nrow) {
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
@@ -124,9 +129,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const long npix = (long)N * H * W;
     const long p0 = (long)blockIdx.x * ppb;
     const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
-    float4 acc[9];
+    float4 acc[10];
     #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = make_float4(0, 0, 0, 0);
+    for (int t = 0; t < 10; ++t) acc[t] = make_float4(0, 0, 0, 0);
+    float4 c1 = make_float4(1, 1, 1, 1), c2 = make_float4(0, 0, 0, 0), c3 = c2;
+    if (active && aux && k1) { c1 = amx_ld4(k1 + cg * 4); c2 = amx_ld4(k2 + cg * 4); c3 = amx_ld4(k3 + cg * 4); }
     if (active)
         for (long p = p0 + pl; p < p1; p += PL) {
             const int xx = (int)(p % W);
@@ -134,7 +141,15 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             const int yy = (int)(r % H);
             const long nimg = r / H;
             const float* img = x + (size_t)nimg * H * W;
-            const float4 g = amx_ld4(dpre + (size_t)p * Cs + cg * 4);
+            float4 g = amx_ld4(dpre + (size_t)p * Cs + cg * 4);
+            if (aux) {
+                const float4 t = amx_ld4(aux + (size_t)p * Cs + cg * 4);
+                g.x = (t.x > 0.f ? 1.f : bslope) * fmaf(c1.x, g.x, fmaf(c2.x, t.x, c3.x));
+                g.y = (t.y > 0.f ? 1.f : bslope) * fmaf(c1.y, g.y, fmaf(c2.y, t.y, c3.y));
+                g.z = (t.z > 0.f ? 1.f : bslope) * fmaf(c1.z, g.z, fmaf(c2.z, t.z, c3.z));
+                g.w = (t.w > 0.f ? 1.f : bslope) * fmaf(c1.w, g.w, fmaf(c2.w, t.w, c3.w));
+            }
+            acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
             #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
@@ -145,13 +160,14 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             }
         }
     #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 10; ++t) {
+        if (t >= nrow) break;
         if (active) amx_st4(s + ((size_t)pl * Cs + cg * 4), acc[t]);
         __syncthreads();
         for (int c = tid; c < Cs; c += 256) {
             float a = 0.f;
             for (int q = 0; q < PL; ++q) a += s[(size_t)q * Cs + c];
-            part[((size_t)blockIdx.x * 9 + t) * Cs + c] = a;
+            part[((size_t)blockIdx.x * nrow + t) * Cs + c] = a;
         }
         __syncthreads();
     }
@@ -164,7 +180,23 @@ extern "C" int amx_conv1_wgrad(const float* x, const float* dpre, float* part, i
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
     const int PL = 256 / (Cs / 4);
     AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)PL * Cs * sizeof(float),
-               (hipStream_t)stream, x, dpre, part, N, H, W, Cs, dil, rows_pix);
+               (hipStream_t)stream, x, dpre, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+               (const float*)nullptr, 1.f, part, N, H, W, Cs, dil, rows_pix, 9);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// fused variant: part is [rows][10][Cs]; tap rows 0..8 as above, row 9 = sum of dpre (bias gradient)
+extern "C" int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, const float* k1,
+                                     const float* k2, const float* k3, float bslope, float* part, int N, int H,
+                                     int W, int Cs, int dil, int rows, int rows_pix, void* stream) {
+    if (!x || !dy || !aux || !part || (Cs & 3) || Cs <= 0 || Cs > 256 || dil < 1) AMX_BADARG(1);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(2);
+    const long npix = (long)N * H * W;
+    if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(3);
+    const int PL = 256 / (Cs / 4);
+    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)PL * Cs * sizeof(float),
+               (hipStream_t)stream, x, dy, aux, k1, k2, k3, bslope, part, N, H, W, Cs, dil, rows_pix, 10);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -41,6 +41,14 @@ struct ConvFwdArgs {
     float* y;  int Y0s;  // first  output: stored channels Y0s, receives couts [0, Y0s)
     float* y1; int Y1s;  // second output (dgrad of a concat) receives couts [Y0s, Y0s+Y1s), or nullptr
     float* stats;        // [tiles][2][cop] (sum, M2) or nullptr
+    // ---- backward fusions (dgrad use of this kernel)
+    const float* aux0;   // activation a of the layer whose gradient src0 (= dy) is: the loader forms
+                         // dpre = lrelu'(a) * (k1*dy + k2*a + k3) on the fly (BatchNorm + LeakyReLU backward)
+    const float* k1; const float* k2; const float* k3;   // [C0s] or nullptr (== 1, 0, 0)
+    float bslope;        // LeakyReLU slope of that layer
+    const float* ea0;    // activation aligned with output y  (or nullptr): epilogue emits per-tile
+    const float* ea1;    // activation aligned with output y1 (or nullptr): (sum dy, sum dy*a) -> bstats
+    float* bstats;       // [tiles][2][cop] or nullptr
     int N, H, W;
     int cout;            // real number of output channels
     int cop;             // cout rounded up to 16
@@ -51,7 +59,7 @@ struct ConvFwdArgs {
     int th;              // tile height in pixels (16 or 32)
 };
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW>
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
@@ -94,7 +102,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
 
     float4 xr[XLD];
     float4 wr[WLD];
-    float4 r_sc, r_sh;
+    float4 r_sc, r_sh, r_k3;
+    int r_ch = -1;                                               // FUSED: channel of this thread's group in src0
 
     auto issue_loads = [&](int chunk) {
         const int ch = (chunk * KG + my_kg) * 4;                 // channel in the concatenated space
@@ -104,7 +113,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         else if (ch - a.C0s < a.C1s) { src = a.x1; sc = a.sc1; sh = a.sh1; Cs = a.C1s; c = ch - a.C0s; }
         r_sc = make_float4(1.f, 1.f, 1.f, 1.f);
         r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        r_k3 = r_sh;
         if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
+        if (FUSED) {
+            r_ch = src == a.x0 ? c : -1;
+            if (r_ch >= 0 && a.k1) { r_sc = amx_ld4(a.k1 + c); r_sh = amx_ld4(a.k2 + c); r_k3 = amx_ld4(a.k3 + c); }
+        }
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
             xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,7 +144,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             const int pix = (tid + i * 256) >> 2;
             if (pix < nslots) {
                 float4 v = xr[i];
-                if (x_off[i] >= 0) {                             // padding stays exactly zero
+                if (FUSED && a.aux0) {                           // dpre = lrelu'(a) * (k1*dy + k2*a + k3)
+                    // the saved activation is fetched here (not prefetched): keeps the register footprint, and
+                    // with it the number of co-resident workgroups, equal to the plain kernel's
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (x_off[i] >= 0 && r_ch >= 0) t = amx_ld4(a.aux0 + (size_t)x_off[i] * a.C0s + r_ch);
+                    v.x = (t.x > 0.f ? 1.f : a.bslope) * fmaf(r_sc.x, v.x, fmaf(r_sh.x, t.x, r_k3.x));
+                    v.y = (t.y > 0.f ? 1.f : a.bslope) * fmaf(r_sc.y, v.y, fmaf(r_sh.y, t.y, r_k3.y));
+                    v.z = (t.z > 0.f ? 1.f : a.bslope) * fmaf(r_sc.z, v.z, fmaf(r_sh.z, t.z, r_k3.z));
+                    v.w = (t.w > 0.f ? 1.f : a.bslope) * fmaf(r_sc.w, v.w, fmaf(r_sh.w, t.w, r_k3.w));
+                    if (x_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (x_off[i] >= 0) {                      // padding stays exactly zero
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
                     v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
                 }
@@ -208,10 +232,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
     const int oy0 = ty * TH + wave * MTW, ox0 = tx * TILE + 4 * g;
     const int ctot = a.Y0s + a.Y1s;
-    float lsum[NT];
+    float lsum[NT], lsum2[NT];
     #pragma unroll
     for (int q = 0; q < NT; ++q) {
         const int co = n0 + q * 16 + p;
+        lsum2[q] = 0.f;
         const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
         float* dst = nullptr; int Cd = 0, cd = 0;
         if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; }
@@ -230,11 +255,35 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
                     if (a.addend && dst == a.y) v += a.addend[o];
                     dst[o] = v;
                     lsum[q] += v;
+                    if (FUSED && a.bstats) {
+                        const float* ea = dst == a.y ? a.ea0 : a.ea1;
+                        if (ea) lsum2[q] = fmaf(v, ea[o], lsum2[q]);
+                    }
                 } else {
                     v = 0.f;
                 }
                 acc[m][q][r] = v;
             }
+    }
+    if (FUSED && a.bstats) {
+        // backward statistics of the source layers' BatchNorm: per-tile (sum dy, sum dy*a) per channel
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            float s1 = lsum[q], s2 = lsum2[q];
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (g == 0) { s_red[wave * NB + q * 16 + p] = s1; s_red[(4 + wave) * NB + q * 16 + p] = s2; }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int which = tid / NB, c = tid - which * NB;
+            const int co = n0 + c;
+            if (co < a.cop) {
+                const float* r = s_red + which * 4 * NB;
+                a.bstats[((size_t)blockIdx.x * 2 + which) * a.cop + co] = r[c] + r[NB + c] + r[2 * NB + c] + r[3 * NB + c];
+            }
+        }
+        return;
     }
     if (!a.stats) return;
 
@@ -289,25 +338,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     }
 }
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW>
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int I = TILE + 2 * halo;
     const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
-    if (lds_w < (size_t)4 * NT * 16 * sizeof(float)) lds_w = (size_t)4 * NT * 16 * sizeof(float);
+    if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
     const size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
     dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -333,12 +382,13 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
 }
 
 // C ABI — see include/atomai_amd.h for the contract.
-extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
-                              const float* x1, const float* sc1, const float* sh1, int C1s,
-                              const float* wpk, const float* bias, const float* addend,
-                              float* y, int Y0s, float* y1, int Y1s, float* stats,
-                              int N, int H, int W, int cout, int taps, int dil, float slope,
-                              void* stream) {
+static int conv2d_common(const float* x0, const float* sc0, const float* sh0, int C0s,
+                         const float* x1, const float* sc1, const float* sh1, int C1s,
+                         const float* wpk, const float* bias, const float* addend,
+                         float* y, int Y0s, float* y1, int Y1s, float* stats,
+                         int N, int H, int W, int cout, int taps, int dil, float slope,
+                         const float* aux0, const float* k1, const float* k2, const float* k3, float bslope,
+                         const float* ea0, const float* ea1, float* bstats, void* stream) {
     if (!x0 || !wpk || !y) AMX_BADARG(1);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
     if ((C0s & 3) || (C1s & 3) || (Y0s & 3) || (Y1s & 3) || C0s <= 0) AMX_BADARG(3);
@@ -351,6 +401,10 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
     a.wpk = wpk; a.bias = bias; a.addend = addend;
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
+    a.aux0 = aux0; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.bslope = bslope;
+    a.ea0 = ea0; a.ea1 = ea1; a.bstats = bstats;
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(9);
+    if (bstats && stats) AMX_BADARG(10);
     a.N = N; a.H = H; a.W = W;
     a.cout = cout;
     a.cop = amx_round_up(cout, 16);
@@ -364,24 +418,50 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     // (the two-stage LDS pipeline, DBUF = true, was measured slower for every layer shape and is not instantiated:
     //  profiles/r01_conv_variants.md)
+    const bool fz = aux0 != nullptr || bstats != nullptr;
+#define CONV_GO(T, N_, H_, M_) return fz ? launch_conv_fwd<T, N_, H_, false, M_, true>(a, s) \
+                                         : launch_conv_fwd<T, N_, H_, false, M_, false>(a, s)
     if (taps == 1) {
-        if (nt == 1) return launch_conv_fwd<1, 1, 0, false, 4>(a, s);
-        if (nt == 2) return launch_conv_fwd<1, 2, 0, false, 4>(a, s);
-        return launch_conv_fwd<1, 4, 0, false, 4>(a, s);
+        if (nt == 1) CONV_GO(1, 1, 0, 4);
+        if (nt == 2) CONV_GO(1, 2, 0, 4);
+        CONV_GO(1, 4, 0, 4);
     }
     if (dil == 1) {
         if (pl.th == 8) {
-            if (nt == 1) return launch_conv_fwd<9, 1, 1, false, 2>(a, s);
-            if (nt == 2) return launch_conv_fwd<9, 2, 1, false, 2>(a, s);
-            return launch_conv_fwd<9, 4, 1, false, 2>(a, s);
+            if (nt == 1) CONV_GO(9, 1, 1, 2);
+            if (nt == 2) CONV_GO(9, 2, 1, 2);
+            CONV_GO(9, 4, 1, 2);
         }
-        if (nt == 1) return launch_conv_fwd<9, 1, 1, false, 4>(a, s);
-        if (nt == 2) return launch_conv_fwd<9, 2, 1, false, 4>(a, s);
-        return launch_conv_fwd<9, 4, 1, false, 4>(a, s);
+        if (nt == 1) CONV_GO(9, 1, 1, 4);
+        if (nt == 2) CONV_GO(9, 2, 1, 4);
+        CONV_GO(9, 4, 1, 4);
     }
-    if (nt == 1) return launch_conv_fwd<9, 1, 6, false, 4>(a, s);
-    if (nt == 2) return launch_conv_fwd<9, 2, 6, false, 4>(a, s);
-    return launch_conv_fwd<9, 4, 6, false, 4>(a, s);
+    if (nt == 1) CONV_GO(9, 1, 6, 4);
+    if (nt == 2) CONV_GO(9, 2, 6, 4);
+    CONV_GO(9, 4, 6, 4);
+#undef CONV_GO
+}
+
+extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
+                              const float* x1, const float* sc1, const float* sh1, int C1s,
+                              const float* wpk, const float* bias, const float* addend,
+                              float* y, int Y0s, float* y1, int Y1s, float* stats,
+                              int N, int H, int W, int cout, int taps, int dil, float slope,
+                              void* stream) {
+    return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, addend, y, Y0s, y1, Y1s, stats, N, H, W,
+                         cout, taps, dil, slope, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr, nullptr,
+                         stream);
+}
+
+// Data gradient with the BatchNorm/LeakyReLU backward of the layer fused into the loader (dy, a -> dpre) and the
+// backward statistics of the SOURCE layers fused into the epilogue (see the struct comments).
+extern "C" int amx_conv2d_dgrad(const float* dy, const float* aux, const float* k1, const float* k2,
+                                const float* k3, float bslope, int Cs, const float* wpk, const float* addend,
+                                float* y, int Y0s, float* y1, int Y1s, const float* ea0, const float* ea1,
+                                float* bstats, int N, int H, int W, int taps, int dil, void* stream) {
+    return conv2d_common(dy, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, addend, y, Y0s, y1,
+                         Y1s, nullptr, N, H, W, Y0s + Y1s, taps, dil, 1.f, aux, k1, k2, k3, bslope, ea0, ea1, bstats,
+                         stream);
 }
 
 // Tile height (16 or 32) amx_conv2d_fwd will use for this layer, and the number of partial-statistics rows

@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ shift,
                                                      const float* __restrict__ w, float* __restrict__ dxn,
                                                      float* __restrict__ part, float* __restrict__ partb,
+                                                     float* __restrict__ bstats,
                                                      long npix, long HW, int C, int Cs, int K, int ppb) {
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
     const bool active = pl < PL;
-    AMX_DYN_SMEM(float, s);                       // [PL][K][Cs] + [PL][K]
+    AMX_DYN_SMEM(float, s);                       // [PL][K][Cs] + [PL][K] + [2][PL][Cs]
+    float4 bs1 = make_float4(0, 0, 0, 0), bs2 = make_float4(0, 0, 0, 0);   // sum dxn, sum dxn * a (raw)
     float4 dw[MAXCLS];
     float db[MAXCLS];
     #pragma unroll
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
         for (long p = p0 + pl; p < p1; p += PL) {
             const long n = p / HW, hw = p - n * HW;
             float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
+            const float4 raw = v;
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
             v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
             float4 d = make_float4(0, 0, 0, 0);
@@ -149,6 +152,9 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
                 db[k] += g;
             }
             amx_st4(dxn + (size_t)p * Cs + cg * 4, d);
+            bs1.x += d.x; bs1.y += d.y; bs1.z += d.z; bs1.w += d.w;
+            bs2.x = fmaf(d.x, raw.x, bs2.x); bs2.y = fmaf(d.y, raw.y, bs2.y);
+            bs2.z = fmaf(d.z, raw.z, bs2.z); bs2.w = fmaf(d.w, raw.w, bs2.w);
         }
         #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) {
@@ -156,6 +162,10 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
             amx_st4(s + ((size_t)(pl * K + k) * Cs + cg * 4), dw[k]);
             if (cg == 0) s[(size_t)PL * K * Cs + pl * K + k] = db[k];
         }
+        float* sb = s + (size_t)PL * K * Cs + (size_t)PL * K;
+        sb = sb + ((4 - ((size_t)(sb - s) & 3)) & 3);            // keep float4 alignment
+        amx_st4(sb + ((size_t)pl * Cs + cg * 4), bs1);
+        amx_st4(sb + ((size_t)(PL + pl) * Cs + cg * 4), bs2);
     }
     __syncthreads();
     for (int i = tid; i < K * Cs; i += 256) {
@@ -168,11 +178,21 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
         for (int q = 0; q < PL; ++q) acc += s[(size_t)PL * K * Cs + q * K + tid];
         partb[(size_t)blockIdx.x * K + tid] = acc;
     }
+    if (bstats) {
+        const float* sb = s + (size_t)PL * K * Cs + (size_t)PL * K;
+        sb = sb + ((4 - ((size_t)(sb - s) & 3)) & 3);
+        for (int i = tid; i < 2 * Cs; i += 256) {
+            const int which = i / Cs, c = i - which * Cs;
+            float acc = 0.f;
+            for (int q = 0; q < PL; ++q) acc += sb[(size_t)(which * PL + q) * Cs + c];
+            bstats[((size_t)blockIdx.x * 2 + which) * Cs + c] = acc;
+        }
+    }
 }
 
 extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, const float* shift,
-                          const float* w, float* dxn, float* part, float* partb, int N, int H, int W,
-                          int C, int Cs, int K, int rows, int rows_pix, void* stream) {
+                          const float* w, float* dxn, float* part, float* partb, float* bstats, int N, int H,
+                          int W, int C, int Cs, int K, int rows, int rows_pix, void* stream) {
     if (!dl || !a || !w || !dxn || !part || !partb || (Cs & 3) || C <= 0 || Cs < C || Cs > 256)
         AMX_BADARG(1);
     if (K < 1 || K > MAXCLS) AMX_BADARG(2);
@@ -180,9 +200,9 @@ extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, c
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(4);
     const int PL = 256 / (Cs / 4);
-    const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K) * sizeof(float);
+    const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K + 4 + (size_t)2 * PL * Cs) * sizeof(float);
     AMX_LAUNCH(px_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, dl, a, scale, shift, w, dxn,
-               part, partb, npix, (long)H * W, C, Cs, K, rows_pix);
+               part, partb, bstats, npix, (long)H * W, C, Cs, K, rows_pix);
     AMX_CHECK_LAUNCH();
     return 0;
 }

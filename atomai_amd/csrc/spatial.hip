@@ -55,10 +55,13 @@ extern "C" int amx_pool2x2_fwd(const float* a, const float* scale, const float* 
 
 // Backward: dy[full res] = skip_grad (optional) + route(g) where the gradient of each 2x2 window goes
 // to its FIRST maximum in scan order (torch semantics); the arg-max is recomputed from a + affine.
-__global__ void pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
+// bstats (optional): [gridDim.x][2][4G] per-block (sum dy, sum dy*a) of the producer layer's BatchNorm backward;
+// requires (gridDim.x * 256) % G == 0 so that a thread keeps its channel group.
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                 const float* __restrict__ skip, float* __restrict__ dy, int N, int H,
-                                int W, int G) {
+                                int W, int G, float* __restrict__ bstats) {
+    float4 bs1 = make_float4(0, 0, 0, 0), bs2 = make_float4(0, 0, 0, 0);
     const int Ho = H >> 1, Wo = W >> 1;
     const int Hc = (H + 1) >> 1, Wc = (W + 1) >> 1;      // also cover an odd last row/col (skip only)
     const size_t total = (size_t)N * Hc * Wc * G;
@@ -71,15 +74,17 @@ __global__ void pool_bwd_kernel(const float* __restrict__ g, const float* __rest
         const bool inwin = (yo < Ho) && (xo < Wo);
         float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
         if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
-        float4 v[4];
+        float4 v[4], raw[4];
         bool ok[4];
         #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int y = 2 * yo + (k >> 1), x = 2 * xo + (k & 1);
             ok[k] = (y < H) && (x < W);
             v[k] = make_float4(0, 0, 0, 0);
-            if (ok[k] && inwin) {
+            raw[k] = v[k];
+            if (ok[k] && (inwin || bstats)) {
                 float4 t = amx_ld4(a + (((size_t)n * H + y) * W + x) * G * 4 + cg * 4);
+                raw[k] = t;
                 t.x = fmaf(t.x, sc.x, sh.x); t.y = fmaf(t.y, sc.y, sh.y);
                 t.z = fmaf(t.z, sc.z, sh.z); t.w = fmaf(t.w, sc.w, sh.w);
                 v[k] = t;
@@ -110,17 +115,42 @@ __global__ void pool_bwd_kernel(const float* __restrict__ g, const float* __rest
                 out.z += az == k ? gg.z : 0.f; out.w += aw == k ? gg.w : 0.f;
             }
             amx_st4(dy + o, out);
+            bs1.x += out.x; bs1.y += out.y; bs1.z += out.z; bs1.w += out.w;
+            bs2.x = fmaf(out.x, raw[k].x, bs2.x); bs2.y = fmaf(out.y, raw[k].y, bs2.y);
+            bs2.z = fmaf(out.z, raw[k].z, bs2.z); bs2.w = fmaf(out.w, raw[k].w, bs2.w);
         }
+    }
+    if (!bstats) return;
+    __shared__ float4 red[2][256];
+    const int tid = threadIdx.x;
+    red[0][tid] = bs1; red[1][tid] = bs2;
+    __syncthreads();
+    if (tid < 2 * G) {                           // thread (which, cg): fixed-order sum over the block's threads of cg
+        const int which = tid / G, cgq = tid - which * G;
+        float4 t = make_float4(0, 0, 0, 0);
+        for (int q = cgq; q < 256; q += G) { const float4 u = red[which][q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        amx_st4(bstats + ((size_t)blockIdx.x * 2 + which) * (G * 4) + cgq * 4, t);
     }
 }
 
+static int pool_bwd_blocks(size_t total) {
+    size_t nb = (total + 255) / 256;
+    return (int)(nb < 2048 ? nb : 2048);
+}
+
+extern "C" int amx_pool2x2_bwd_rows(int N, int H, int W, int Cs) {
+    return pool_bwd_blocks((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cs / 4));
+}
+
 extern "C" int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const float* shift,
-                               const float* skip, float* dy, int N, int H, int W, int Cs, void* stream) {
+                               const float* skip, float* dy, float* bstats, int N, int H, int W, int Cs,
+                               void* stream) {
     if (!g || !a || !dy || (Cs & 3) || Cs <= 0 || H < 2 || W < 2) AMX_BADARG(1);
     if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(2);
+    if (bstats && (256 % (Cs / 4)) != 0) AMX_BADARG(3);
     const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (Cs / 4);
-    AMX_LAUNCH(pool_bwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, g, a, scale, shift,
-               skip, dy, N, H, W, Cs / 4);
+    AMX_LAUNCH(pool_bwd_kernel, dim3(pool_bwd_blocks(total)), dim3(256), 0, (hipStream_t)stream, g, a, scale,
+               shift, skip, dy, N, H, W, Cs / 4, bstats);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -21,7 +21,10 @@
 struct WgradArgs {
     const float* x0; const float* sc0; const float* sh0; int C0s;
     const float* x1; const float* sc1; const float* sh1; int C1s;
-    const float* dpre; int Dos;      // stored channels of dpre
+    const float* dpre; int Dos;      // stored channels of dpre (or of dy when aux != nullptr)
+    const float* aux;                // activation a: dpre = lrelu'(a) * (k1*dy + k2*a + k3) formed while loading
+    const float* k1; const float* k2; const float* k3; float bslope;
+    float* bpart;                    // [ksplit][co_pad] per-workgroup sums of dpre (bias gradient) or nullptr
     float* part;                     // [rows][taps][ci_pad][co_pad]
     int N, H, W, dil;
     int ci_pad, co_pad;              // multiples of 16
@@ -70,6 +73,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     float4 xr[XLD];
     float4 dr[DLD_MAX];
     unsigned xvalid = 0;
+    float4 bsum = make_float4(0, 0, 0, 0);   // bias-gradient partial of this thread's channel group (ci-block 0)
+    long d_off[DLD_MAX];                     // element offsets of the dy values held in dr (or -1)
 
     auto issue = [&](int tile) {
         int t = tile;
@@ -94,13 +99,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < DLD_MAX; ++i) {
             const int idx = tid + i * 256;
             dr[i] = make_float4(0, 0, 0, 0);
+            d_off[i] = -1;
             if (idx < nd4) {
                 const int pix = idx / DG, dg = idx - pix * DG;
                 const int iy = pix / TW, ix = pix - iy * TW;
                 const int gy = ty * TH + iy, gx = tx * TW + ix;
                 const int c = co0 + dg * 4;
-                if (gy < a.H && gx < a.W && c < a.Dos)
-                    dr[i] = amx_ld4(a.dpre + ((size_t)(n * a.H + gy) * a.W + gx) * a.Dos + c);
+                if (gy < a.H && gx < a.W && c < a.Dos) {
+                    const size_t o = ((size_t)(n * a.H + gy) * a.W + gx) * a.Dos + c;
+                    dr[i] = amx_ld4(a.dpre + o);
+                    d_off[i] = (long)o;
+                }
             }
         }
     };
@@ -122,7 +131,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const int idx = tid + i * 256;
             if (idx < nd4) {
                 const int pix = idx / DG, dg = idx - pix * DG;
-                amx_st4(s_d + (size_t)pix * SD + dg * 4, dr[i]);
+                float4 v = dr[i];
+                if (a.aux) {
+                    // dpre = lrelu'(a) * (k1*dy + k2*a + k3); a is fetched here rather than prefetched so that the
+                    // register footprint (hence the number of co-resident workgroups) stays that of the plain kernel
+                    if (d_off[i] >= 0) {
+                        const int c = co0 + dg * 4;
+                        float4 c1 = make_float4(1, 1, 1, 1), c2 = make_float4(0, 0, 0, 0), c3 = c2;
+                        if (a.k1) { c1 = amx_ld4(a.k1 + c); c2 = amx_ld4(a.k2 + c); c3 = amx_ld4(a.k3 + c); }
+                        const float4 t = amx_ld4(a.aux + d_off[i]);
+                        v.x = (t.x > 0.f ? 1.f : a.bslope) * fmaf(c1.x, v.x, fmaf(c2.x, t.x, c3.x));
+                        v.y = (t.y > 0.f ? 1.f : a.bslope) * fmaf(c1.y, v.y, fmaf(c2.y, t.y, c3.y));
+                        v.z = (t.z > 0.f ? 1.f : a.bslope) * fmaf(c1.z, v.z, fmaf(c2.z, t.z, c3.z));
+                        v.w = (t.w > 0.f ? 1.f : a.bslope) * fmaf(c1.w, v.w, fmaf(c2.w, t.w, c3.w));
+                    } else {
+                        v = make_float4(0, 0, 0, 0);
+                    }
+                }
+                if (a.bpart && cb == 0) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+                amx_st4(s_d + (size_t)pix * SD + dg * 4, v);
             }
         }
     };
@@ -161,6 +188,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         __syncthreads();
     }
 
+    if (a.bpart && cb == 0) {
+        // threads with equal tid % DG staged the same channel group: fixed-order sum over them
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(smem);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < DG) {
+            float4 t = make_float4(0, 0, 0, 0);
+            for (int q = tid; q < 256; q += DG) { const float4 u = red[q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            const int c = co0 + tid * 4;
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+            for (int e = 0; e < 4; ++e) if (c + e < a.co_pad) a.bpart[(size_t)blockIdx.x * a.co_pad + c + e] = tv[e];
+        }
+    }
     // D fragment: row (ci) = 4*g + reg, col (co) = p.  Partial row index = blockIdx.x * WK + wk.
     const size_t row = (size_t)blockIdx.x * a.WK + wk;
     #pragma unroll
@@ -229,16 +270,49 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     return pl;
 }
 
+extern "C" int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil) {
+    return plan_wgrad(N, H, W, Cin_s, cout, taps, dil).ksplit;
+}
+
 // rows / floats of the partial buffer amx_conv2d_wgrad needs
 extern "C" int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil) {
     return plan_wgrad(N, H, W, Cin_s, cout, taps, dil).rows;
 }
 
+static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int C0s,
+                        const float* x1, const float* sc1, const float* sh1, int C1s,
+                        const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
+                        int taps, int dil, const float* aux, const float* k1, const float* k2, const float* k3,
+                        float bslope, float* bpart, void* stream);
+
 extern "C" int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* sh0, int C0s,
                                 const float* x1, const float* sc1, const float* sh1, int C1s,
                                 const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
                                 int taps, int dil, void* stream) {
+    return wgrad_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, dpre, Dos, part, N, H, W, cout, taps, dil, nullptr,
+                        nullptr, nullptr, nullptr, 1.f, nullptr, stream);
+}
+
+// Weight gradient with the layer's BatchNorm/LeakyReLU backward fused into the dy loader and the bias gradient's
+// partial sums (bpart: [amx_conv2d_wgrad_ksplit][round_up(cout,16)]) produced on the way.
+extern "C" int amx_conv2d_wgrad_fused(const float* x0, const float* sc0, const float* sh0, int C0s,
+                                      const float* x1, const float* sc1, const float* sh1, int C1s,
+                                      const float* dy, const float* aux, const float* k1, const float* k2,
+                                      const float* k3, float bslope, int Dos, float* part, float* bpart,
+                                      int N, int H, int W, int cout, int taps, int dil, void* stream) {
+    return wgrad_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, dy, Dos, part, N, H, W, cout, taps, dil, aux, k1, k2,
+                        k3, bslope, bpart, stream);
+}
+
+extern "C" int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
+
+static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int C0s,
+                        const float* x1, const float* sc1, const float* sh1, int C1s,
+                        const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
+                        int taps, int dil, const float* aux, const float* k1, const float* k2, const float* k3,
+                        float bslope, float* bpart, void* stream) {
     if (!x0 || !dpre || !part) AMX_BADARG(1);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(7);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
     if ((C0s & 3) || (C1s & 3) || (Dos & 3) || C0s <= 0 || Dos < cout) AMX_BADARG(3);
     if (taps != 1 && taps != 9) AMX_BADARG(4);
@@ -249,6 +323,7 @@ extern "C" int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* 
     a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
     a.dpre = dpre; a.Dos = Dos; a.part = part;
+    a.aux = aux; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.bslope = bslope; a.bpart = bpart;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     a.ci_pad = pl.ci_pad; a.co_pad = pl.co_pad;
     a.WN = pl.WN; a.WK = pl.WK; a.ksplit = pl.ksplit;

@@ -23,6 +23,18 @@ from . import _lib as L
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+import os as _os
+# Backward fusion switches, chosen by measurement:
+#   1: dpre formed in the dgrad loader      4: dpre formed in the wgrad loader
+#   2: BN-backward sums emitted by the pool / px backward kernels that write the final dy
+#   8: BN-backward sums emitted by the dgrad epilogue that writes the final dy
+# Interleaved in-process A/B on MI355X (tools/gpu_fuse_ab.py, U-Net bs 32 512^2, ms/step, min of 3):
+#   0: 22.30   2: 22.11   8: 22.90   10: 22.04   5: 23.35   15: 22.98
+# -> moving the HBM-bound BatchNorm-backward passes INTO the MFMA kernels costs them more (registers ->
+#    fewer co-resident workgroups, exposed load latency) than the removed passes save; only the sums emitted
+#    by the pool / px backward kernels are kept by default.
+FUSE = int(_os.environ.get("AMX_FUSE", "2"))
+
 
 def r4(c: int) -> int:
     return (c + 3) // 4 * 4
@@ -44,7 +56,8 @@ def bump_weight_generation() -> None:
 class Act:
     """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
     per-channel affine of the producing BatchNorm (None == identity)."""
-    __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad")
+    __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad", "producer",
+                 "first_consumer", "bstats")
 
     def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
         self.t = t
@@ -54,6 +67,22 @@ class Act:
         self.grad: Optional[torch.Tensor] = None      # d loss / d (normalised value), NHWC
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
         self.needs_grad = needs_grad
+        self.producer = None                          # ConvNode that wrote `t` (owner of the pending BatchNorm)
+        self.first_consumer = None                    # first node that read this activation in forward order ==
+                                                      # the LAST one to add to `grad` in backward order
+        self.bstats = None                            # (rows tensor, rows, stride, column offset): per-block
+                                                      # (sum dy, sum dy*a) emitted by that last writer
+
+    def consumed_by(self, node) -> None:
+        if self.first_consumer is None:
+            self.first_consumer = node
+
+    def wants_bstats(self, node, training: bool) -> bool:
+        """True if `node` writes the final gradient of this activation and its producer needs BN-backward sums."""
+        p = self.producer
+        bit = 8 if isinstance(node, ConvNode) else 2
+        return (bool(FUSE & bit) and training and p is not None and p.bn is not None and self.gx is None
+                and self.needs_grad and self.first_consumer is node)
 
     @property
     def npix(self) -> int:
@@ -140,7 +169,10 @@ class ConvNode(_Node):
                 "padding must equal dilation ('same' convolution)"
         else:
             assert tuple(conv.padding) == (0, 0)
+        for src in self.srcs:
+            src.consumed_by(self)
         self.out = self._forward(tape)
+        self.out.producer = self
 
     # -------------------------------------------------------------------------------- forward
     def _forward(self, tape) -> Act:
@@ -208,51 +240,77 @@ class ConvNode(_Node):
 
     # -------------------------------------------------------------------------------- backward
     def backward(self, tape) -> None:
+        """BatchNorm + LeakyReLU backward are FUSED into the loaders of the weight- and data-gradient kernels
+        (dpre = lrelu'(a) * (k1*dy + k2*a + k3) is formed on the fly from dy and the saved activation a), and
+        the per-channel sums BatchNorm backward needs (sum dy, sum dy*a) are emitted by whichever kernel wrote
+        the final dy (dgrad / pool / px epilogues).  The standalone reduce / apply kernels remain as the
+        fallback for DilatedBlock's extra-gradient terms."""
         out = self.out
         dy = out.grad if out.grad is not None else out.gx
         if dy is None:
             return                                        # output never used downstream
         a = out.t
         npix, cos = out.npix, out.Cs
-        rows = L.load().amx_rows_for(npix)
         sp = _sp(a)
         has_bias = self.conv.bias is not None
-        bias_part = _empty((rows, cos), a) if has_bias else None
-        training_bn = self.bn is not None and tape.training
         if self.bn is not None and not tape.training:
             raise L.AmxError("backward through eval-mode BatchNorm is not on the hot path")
-        if training_bn:
+        fused = out.gx is None and bool(FUSE & 5)
+        k = None
+        aux = None
+        bias_part = None
+        if self.bn is not None:
             bn = self.bn
-            part = _empty((rows, 2, cos), a)
-            L.call("amx_bn_bwd_reduce", L.ptr(dy), L.ptr(a), npix, cos, L.ptr(part), sp)
+            if out.bstats is not None:
+                part, rows, stride, off = out.bstats
+                part_ptr = part.view(-1)[off:]
+            else:
+                rows = L.load().amx_rows_for(npix)
+                part = _empty((rows, 2, cos), a)
+                L.call("amx_bn_bwd_reduce", L.ptr(dy), L.ptr(a), npix, cos, L.ptr(part), sp)
+                part_ptr, stride = part, cos
             dgamma, dbeta = grad_buffer(bn.weight, a), grad_buffer(bn.bias, a)
             k = _empty((3, cos), a)
-            L.call("amx_bn_bwd_finalize", L.ptr(part), rows, cos, self.cout, npix,
+            L.call("amx_bn_bwd_finalize", L.ptr(part_ptr), rows, stride, cos, self.cout, npix,
                    L.ptr(bn.weight.detach()), L.ptr(self.save_mean), L.ptr(self.save_invstd),
                    L.ptr(dgamma), L.ptr(dbeta), L.ptr(k[0]), L.ptr(k[1]), L.ptr(k[2]), sp)
             tape.add_param_grad(bn.weight, dgamma)
             tape.add_param_grad(bn.bias, dbeta)
+        needs_transform = self.bn is not None or self.slope != 1.0 or out.gx is not None
+        dpre_mat = None
+        if needs_transform and fused and (FUSE & 5) != 5:
+            # experiment mode: one of the two consumers still wants a materialised dpre
+            arows = L.load().amx_rows_for(npix)
+            bias_part = _empty((arows, cos), a) if has_bias else None
+            dpre_mat = _empty(a.shape, a)
+            kk = (L.ptr(k[0]), L.ptr(k[1]), L.ptr(k[2])) if k is not None else (None, None, None)
+            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), *kk, self.slope, npix, cos,
+                   L.ptr(dpre_mat), L.ptr(bias_part), sp)
+        if needs_transform and fused:
+            aux, dpre = a, dy                               # transformed on load inside wgrad / dgrad
+        elif needs_transform:
+            arows = L.load().amx_rows_for(npix)
+            bias_part = _empty((arows, cos), a) if has_bias else None
             dpre = _empty(a.shape, a)
-            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), L.ptr(k[0]), L.ptr(k[1]),
-                   L.ptr(k[2]), self.slope, npix, cos, L.ptr(dpre), L.ptr(bias_part), sp)
-        elif self.slope != 1.0 or out.gx is not None or has_bias:
-            # dpre = gx + lrelu'(a) * (gx + dy)   (no BatchNorm); also yields the bias partial sums
-            inplace = self.slope == 1.0 and out.gx is None
-            dpre = dy if inplace else _empty(a.shape, a)
-            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), None, None, None,
-                   self.slope, npix, cos, L.ptr(dpre), L.ptr(bias_part), sp)
+            kk = (L.ptr(k[0]), L.ptr(k[1]), L.ptr(k[2])) if k is not None else (None, None, None)
+            L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), *kk, self.slope, npix, cos,
+                   L.ptr(dpre), L.ptr(bias_part), sp)
+            k = None
         else:
-            dpre = dy
-        if has_bias:
+            dpre = dy                                       # linear convolution (1x1 of UpsampleBlock)
+        if bias_part is not None:
             db = grad_buffer(self.conv.bias, a)
-            L.call("amx_reduce_rows", L.ptr(bias_part), rows, cos, self.cout, 1.0, L.ptr(db), sp)
+            L.call("amx_reduce_rows", L.ptr(bias_part), bias_part.shape[0], cos, self.cout, 1.0, L.ptr(db), sp)
             tape.add_param_grad(self.conv.bias, db)
+        kptr = (k[0], k[1], k[2]) if k is not None else (None, None, None)
         w = self.conv.weight
         dw = grad_buffer(w, a)
-        # The weight gradient (MFMA-bound) has no consumer inside backward: run it on the tape's side stream so
-        # that it overlaps the HBM-bound BatchNorm-backward / pooling kernels of the layers below.
-        with tape.side(a, keep=(dpre, dy, a)):
-            self._wgrad(tape, dpre, dw, a)
+        want_bias = has_bias and bias_part is None
+        # The weight gradient (MFMA-bound) has no consumer inside backward: side stream.
+        w_in = (dpre, aux, kptr) if (dpre_mat is None or FUSE & 4) else (dpre_mat, None, (None, None, None))
+        d_in = (dpre, aux, kptr) if (dpre_mat is None or FUSE & 1) else (dpre_mat, None, (None, None, None))
+        with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
+            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         if self.x_plain is not None:
             return
         s0 = self.srcs[0]
@@ -260,20 +318,43 @@ class ConvNode(_Node):
         N, H, W = s0.N, s0.H, s0.W
         C0, C0s = s0.C, s0.Cs
         C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
-        cos = out.Cs
-        self._dgrad(tape, dpre, s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp)
+        self._dgrad(tape, d_in[0], d_in[1], d_in[2], s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp)
 
-    def _wgrad(self, tape, dpre, dw, a) -> None:
+    def _wgrad(self, tape, dpre, aux, kptr, dw, a, want_bias) -> None:
         w = self.conv.weight
         cos = self.out.Cs
         sp = _sp(a)
+        k1, k2, k3 = kptr
+
+        def colsum(part2d, rows, ncols):
+            """[rows][ncols] -> [ncols] in (at most) two deterministic stages."""
+            if rows > 64:
+                nch = 32 if rows < 1024 else 128
+                tmp = _empty((nch, ncols), a)
+                L.call("amx_reduce_rows_chunked", L.ptr(part2d), rows, ncols, nch, L.ptr(tmp), sp)
+                part2d, rows = tmp, -(-rows // -(-rows // nch))
+            out1 = _empty((ncols,), a)
+            L.call("amx_reduce_rows_chunked", L.ptr(part2d), rows, ncols, 1, L.ptr(out1), sp)
+            return out1
+
         if self.x_plain is not None:
             x = self.x_plain
             N, _, H, W = x.shape
-            part = _empty((self.rows, 9, cos), a)
-            L.call("amx_conv1_wgrad", L.ptr(x), L.ptr(dpre), L.ptr(part), N, H, W, cos, self.dil,
-                   self.rows, self.rows_pix, sp)
-            L.call("amx_wgrad_reduce", L.ptr(part), self.rows, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
+            if aux is not None:
+                part = _empty((self.rows, 10, cos), a)
+                L.call("amx_conv1_wgrad_fused", L.ptr(x), L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
+                       self.slope, L.ptr(part), N, H, W, cos, self.dil, self.rows, self.rows_pix, sp)
+                tot = colsum(part, self.rows, 10 * cos)
+                L.call("amx_wgrad_reduce", L.ptr(tot), 1, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
+                if want_bias:
+                    db = grad_buffer(self.conv.bias, a)
+                    db.copy_(tot[9 * cos: 9 * cos + self.cout])
+                    tape.add_param_grad(self.conv.bias, db)
+            else:
+                part = _empty((self.rows, 9, cos), a)
+                L.call("amx_conv1_wgrad", L.ptr(x), L.ptr(dpre), L.ptr(part), N, H, W, cos, self.dil,
+                       self.rows, self.rows_pix, sp)
+                L.call("amx_wgrad_reduce", L.ptr(part), self.rows, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
             tape.add_param_grad(w, dw)
             return
         s0 = self.srcs[0]
@@ -284,10 +365,18 @@ class ConvNode(_Node):
         wrows = L.load().amx_conv2d_wgrad_rows(N, H, W, C0s + C1s, self.cout, self.taps, self.dil)
         ci_pad, co_pad = r16(C0s + C1s), r16(self.cout)
         part = _empty((wrows, self.taps, ci_pad, co_pad), a)
-        L.call("amx_conv2d_wgrad", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+        bpart = None
+        if want_bias:
+            ks = L.load().amx_conv2d_wgrad_ksplit(N, H, W, C0s + C1s, self.cout, self.taps, self.dil)
+            bpart = _empty((ks, co_pad), a)
+        L.call("amx_conv2d_wgrad_fused", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
                L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
-               L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), cos, L.ptr(part), N, H, W, self.cout,
-               self.taps, self.dil, sp)
+               L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
+               self.slope, cos, L.ptr(part), L.ptr(bpart), N, H, W, self.cout, self.taps, self.dil, sp)
+        if bpart is not None:
+            db = grad_buffer(self.conv.bias, a)
+            L.call("amx_reduce_rows", L.ptr(bpart), bpart.shape[0], co_pad, self.cout, 1.0, L.ptr(db), sp)
+            tape.add_param_grad(self.conv.bias, db)
         if wrows > 64:                   # two-stage: coalesced chunk sums first
             nch = 32 if wrows < 1024 else 128
             ncols = self.taps * ci_pad * co_pad
@@ -298,9 +387,10 @@ class ConvNode(_Node):
                L.ptr(dw), sp)
         tape.add_param_grad(w, dw)
 
-    def _dgrad(self, tape, dpre, s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp) -> None:
+    def _dgrad(self, tape, dpre, aux, kptr, s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp) -> None:
         # ---- data gradient(s): forward conv of dpre with the flipped / transposed weight image
         w = self.conv.weight
+        k1, k2, k3 = kptr
         need0 = s0.needs_grad
         need1 = bool(s1 and s1.needs_grad)
         if not (need0 or need1):
@@ -323,9 +413,22 @@ class ConvNode(_Node):
             y1 = scratch
         else:
             scratch, y1 = None, tgt[1][0]
-        L.call("amx_conv2d_fwd", L.ptr(dpre), None, None, cos, None, None, None, 0, L.ptr(wpk), None,
-               L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, None, N, H, W, C0s + C1s, self.taps,
-               self.dil, 1.0, sp)
+        # backward statistics for the sources whose final gradient this launch writes
+        ea0 = s0.t if s0.wants_bstats(self, tape.training) else None
+        ea1 = s1.t if (s1 is not None and scratch is None and s1.wants_bstats(self, tape.training)) else None
+        bstats = None
+        if ea0 is not None or ea1 is not None:
+            th = L.load().amx_conv2d_tile_h(cos, C0s + C1s, self.taps, self.dil, H)
+            tiles = L.load().amx_conv2d_num_tiles(N, H, W, th)
+            cop_d = r16(C0s + C1s)
+            bstats = _empty((tiles, 2, cop_d), dpre)
+            if ea0 is not None:
+                s0.bstats = (bstats, tiles, cop_d, 0)
+            if ea1 is not None:
+                s1.bstats = (bstats, tiles, cop_d, C0s)
+        L.call("amx_conv2d_dgrad", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope, cos,
+               L.ptr(wpk), L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, L.ptr(ea0), L.ptr(ea1),
+               L.ptr(bstats), N, H, W, self.taps, self.dil, sp)
         if scratch is not None:
             L.call("amx_add_inplace", L.ptr(tgt[1][0]), L.ptr(scratch), scratch.numel(), sp)
 
@@ -333,6 +436,7 @@ class ConvNode(_Node):
 class PoolNode(_Node):
     def __init__(self, tape, src: Act):
         self.src = src
+        src.consumed_by(self)
         y = _empty((src.N, src.H // 2, src.W // 2, src.Cs), src.t)
         L.call("amx_pool2x2_fwd", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(y), src.N,
                src.H, src.W, src.Cs, _sp(y))
@@ -346,14 +450,20 @@ class PoolNode(_Node):
         if s.grad is None:
             s.grad = _empty(s.t.shape, s.t)
             skip = s.gx
+        bstats = None
+        if s.wants_bstats(self, tape.training) and 256 % (s.Cs // 4) == 0:
+            rows = L.load().amx_pool2x2_bwd_rows(s.N, s.H, s.W, s.Cs)
+            bstats = _empty((rows, 2, s.Cs), g)
+            s.bstats = (bstats, rows, s.Cs, 0)
         L.call("amx_pool2x2_bwd", L.ptr(g), L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift), L.ptr(skip),
-               L.ptr(s.grad), s.N, s.H, s.W, s.Cs, _sp(g))
+               L.ptr(s.grad), L.ptr(bstats), s.N, s.H, s.W, s.Cs, _sp(g))
 
 
 class UpsampleNode(_Node):
     def __init__(self, tape, src: Act, mode: str):
         assert src.scale is None, "upsample expects a materialised (affine-free) activation"
         self.src, self.mode = src, {"bilinear": 0, "nearest": 1}[mode]
+        src.consumed_by(self)
         y = _empty((src.N, 2 * src.H, 2 * src.W, src.Cs), src.t)
         L.call("amx_upsample2x_fwd", L.ptr(src.t), L.ptr(y), src.N, src.H, src.W, src.Cs, self.mode, _sp(y))
         self.out = Act(y, src.C, needs_grad=src.needs_grad)
@@ -372,6 +482,8 @@ class DilatedSumNode(_Node):
 
     def __init__(self, tape, acts: Sequence[Act], slope: float):
         self.acts, self.slope = list(acts), slope
+        for act in self.acts:
+            act.consumed_by(self)
         a0 = acts[0]
         y = _empty(a0.t.shape, a0.t)
         PP = ctypes.c_void_p * 4
@@ -421,6 +533,7 @@ class OutputNode(_Node):
 
     def __init__(self, tape, src: Act):
         self.src = src
+        src.consumed_by(self)
         t = src.t
         if src.scale is not None:
             t = _empty(src.t.shape, src.t)
@@ -445,6 +558,7 @@ class PxNode(_Node):
 
     def __init__(self, tape, src: Act, conv, mode: int = 0):
         self.src, self.conv = src, conv
+        src.consumed_by(self)
         K = conv.weight.shape[0]
         assert conv.weight.shape[1] == src.C and conv.weight.shape[2:] == (1, 1)
         self.K = K
@@ -466,9 +580,13 @@ class PxNode(_Node):
         part = _empty((rows, self.K, s.Cs), s.t)
         partb = _empty((rows, self.K), s.t)
         sp = _sp(dl)
+        bstats = None
+        if s.wants_bstats(self, tape.training) and s.grad is None:
+            bstats = _empty((rows, 2, s.Cs), s.t)
+            s.bstats = (bstats, rows, s.Cs, 0)
         L.call("amx_px_bwd", L.ptr(dl), L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift),
-               L.ptr(self.conv.weight.detach()), L.ptr(dxn), L.ptr(part), L.ptr(partb), s.N, s.H, s.W,
-               s.C, s.Cs, self.K, rows, rows_pix, sp)
+               L.ptr(self.conv.weight.detach()), L.ptr(dxn), L.ptr(part), L.ptr(partb), L.ptr(bstats), s.N, s.H,
+               s.W, s.C, s.Cs, self.K, rows, rows_pix, sp)
         dw = _empty((self.K * s.Cs,), s.t)
         L.call("amx_reduce_rows", L.ptr(part), rows, self.K * s.Cs, self.K * s.Cs, 1.0, L.ptr(dw), sp)
         db = grad_buffer(self.conv.bias, s.t)

@@ -33,6 +33,10 @@ int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
                    const float* wpk, const float* bias, const float* addend,
                    float* y, int Y0s, float* y1, int Y1s, float* stats,
                    int N, int H, int W, int cout, int taps, int dil, float slope, void* stream);
+int amx_conv2d_dgrad(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
+                     float bslope, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
+                     int Y1s, const float* ea0, const float* ea1, float* bstats, int N, int H, int W, int taps,
+                     int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
 
@@ -42,7 +46,13 @@ int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* sh0, int C0
                      const float* x1, const float* sc1, const float* sh1, int C1s,
                      const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
                      int taps, int dil, void* stream);
+int amx_conv2d_wgrad_fused(const float* x0, const float* sc0, const float* sh0, int C0s,
+                           const float* x1, const float* sc1, const float* sh1, int C1s,
+                           const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
+                           float bslope, int Dos, float* part, float* bpart, int N, int H, int W, int cout,
+                           int taps, int dil, void* stream);
 int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
+int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,
                      int C1, int Cout, float* dw, void* stream);
 
@@ -52,6 +62,9 @@ int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, f
                   void* stream);
 int amx_conv1_wgrad(const float* x, const float* dpre, float* part, int N, int H, int W, int Cs,
                     int dil, int rows, int rows_pix, void* stream);
+int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, const float* k1, const float* k2,
+                          const float* k3, float bslope, float* part, int N, int H, int W, int Cs, int dil,
+                          int rows, int rows_pix, void* stream);
 
 /* OIHW -> MFMA weight image (mode 0 forward, 1 dgrad) and NCHW<->NHWC at the module boundary */
 int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C0, int C0s, int C1, int C1s,
@@ -73,7 +86,7 @@ int amx_affine_nhwc(const float* a, const float* scale, const float* shift, floa
 int amx_rows_for(long npix);
 int amx_rows_pix(long npix);
 int amx_bn_bwd_reduce(const float* dy, const float* a, long npix, int Cs, float* part, void* stream);
-int amx_bn_bwd_finalize(const float* part, int rows, int Cs, int C, long npix, const float* gamma,
+int amx_bn_bwd_finalize(const float* part, int rows, int stride, int Cs, int C, long npix, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* k1, float* k2, float* k3, void* stream);
 int amx_bn_bwd_apply(const float* dy, const float* a, const float* gx, const float* k1, const float* k2,
@@ -89,7 +102,8 @@ int amx_reduce_rows_chunked(const float* part, int rows, long ncols, int nchunks
 int amx_pool2x2_fwd(const float* a, const float* scale, const float* shift, float* d, int N, int H, int W,
                     int Cs, void* stream);
 int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const float* shift,
-                    const float* skip, float* dy, int N, int H, int W, int Cs, void* stream);
+                    const float* skip, float* dy, float* bstats, int N, int H, int W, int Cs, void* stream);
+int amx_pool2x2_bwd_rows(int N, int H, int W, int Cs);
 int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode, void* stream);
 int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int w, int Cs, int mode, void* stream);
 int amx_dilated_sum(const float* const* a, const float* const* scale, const float* const* shift, int n,
@@ -101,8 +115,8 @@ int amx_dilated_sum(const float* const* a, const float* const* scale, const floa
 int amx_px_fwd(const float* a, const float* scale, const float* shift, const float* w, const float* b,
                float* out, int N, int H, int W, int C, int Cs, int K, int mode, void* stream);
 int amx_px_bwd(const float* dl, const float* a, const float* scale, const float* shift, const float* w,
-               float* dxn, float* part, float* partb, int N, int H, int W, int C, int Cs, int K, int rows,
-               int rows_pix, void* stream);
+               float* dxn, float* part, float* partb, float* bstats, int N, int H, int W, int C, int Cs, int K,
+               int rows, int rows_pix, void* stream);
 int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits, float* part, int rows,
                    int N, int K, long HW, void* stream);
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,

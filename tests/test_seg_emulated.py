@@ -30,6 +30,16 @@ def test_blocks():
     C.check_blocks("cpu")
 
 
+@pytest.mark.parametrize("mode", [0, 15])
+def test_backward_fusion_modes(mode, monkeypatch):
+    """The optional backward fusions (dpre formed in the dgrad / wgrad loaders, BN-backward sums from the dgrad
+    epilogue) are off by default (measured slower on MI355X) but stay correct."""
+    from atomai_amd import engine
+    monkeypatch.setattr(engine, "FUSE", mode)
+    C.check_net_case("seg_unet_c3_nf4_b2_32", "cpu")
+    C.check_net_case("seg_dilnet_c1_nf5_b2_32", "cpu")
+
+
 def test_predictor():
     C.check_predict(False)
 
