@@ -20,6 +20,7 @@
 //     across all tiles of the sample and are written once as a per-sample partial row (summed by
 //     amx_reduce_rows in fp64 -> deterministic).
 #include "amx_device.h"
+#include <cstdlib>
 
 struct RDecArgs {
     const float* coords;   // [B][n][2] transformed pixel coordinates
@@ -475,9 +476,11 @@ extern "C" int amx_rdecoder_fwd(const float* coords, const float* z, const float
     if (rc) return rc;
     if (!xrec) AMX_BADARG(4);
     hipStream_t s = (hipStream_t)stream;
+    int mt = 64;      // 64-pixel tiles: 66 KB of LDS -> two workgroups per CU (58.8 % vs 53.4 % of MFMA peak measured)
+    if (const char* e = getenv("AMX_RDEC_FWD_MT")) mt = atoi(e);
     if (hid == 32) return launch_fwd<32, 128>(a, s);
     if (hid == 64) return launch_fwd<64, 128>(a, s);
-    return skip ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
+    return (skip || mt == 64) ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
 }
 
 extern "C" int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const float* bc,
@@ -500,7 +503,9 @@ extern "C" int amx_rdecoder_bwd(const float* coords, const float* z, const float
     return launch_bwd<HID_, MT_, 3>(a, s);
     if (hid == 32) { RD_BWD(32, 64) }
     if (hid == 64) { RD_BWD(64, 64) }
-    if (NL + 1 + (skip ? 1 : 0) <= 4) { RD_BWD(128, 64) }
+    int mt = 64;
+    if (const char* e = getenv("AMX_RDEC_BWD_MT")) mt = atoi(e);
+    if (mt == 64 && NL + 1 + (skip ? 1 : 0) <= 4) { RD_BWD(128, 64) }
     RD_BWD(128, 32)
 #undef RD_BWD
 }

@@ -262,7 +262,10 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     if (const char* e = getenv("AMX_WGRAD_TH")) { const int v = atoi(e); if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }
     if (pl.WK > pl.th) pl.WK = pl.th;
     const int ntiles = amx_ceil_div(W, TW) * amx_ceil_div(H, pl.th) * N;
-    int ks = amx_ceil_div(1024, blocks);
+    // split-K workgroups: one per CU is the measured optimum (256: 20.98 ms/step, 512: 21.5, 1024: 21.6, 128: 25.2)
+    int target = 256;
+    if (const char* e = getenv("AMX_WGRAD_WGS")) { const int v = atoi(e); if (v >= 64) target = v; }
+    int ks = amx_ceil_div(target, blocks);
     if (ks > ntiles) ks = ntiles;
     if (ks < 1) ks = 1;
     pl.ksplit = ks;
