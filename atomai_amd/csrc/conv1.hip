@@ -7,17 +7,18 @@
 //                                                   atomai/nets/fcnn.py:66-69, 186-189; blocks.py:61-76
 #include "amx_device.h"
 
-// Per-thread Welford state for 4 channels; merged across the block with Chan's formula.
-struct Wf4 { float4 mean, m2; float n; };
+// Per-thread shifted sums for 4 channels: d = x - K with K = the first value the thread sees, so that
+// M2 = sum d^2 - (sum d)^2 / n is free of catastrophic cancellation; merged across the block with Chan's formula.
+struct Sh4 { float4 K, s1, s2; float n; };
 
-__device__ __forceinline__ void wf_push(Wf4& s, const float4 v) {
+__device__ __forceinline__ void sh_push(Sh4& s, const float4 v) {
+    if (s.n == 0.f) s.K = v;
     s.n += 1.f;
-    const float r = 1.f / s.n;
     float d;
-    d = v.x - s.mean.x; s.mean.x += d * r; s.m2.x = fmaf(d, v.x - s.mean.x, s.m2.x);
-    d = v.y - s.mean.y; s.mean.y += d * r; s.m2.y = fmaf(d, v.y - s.mean.y, s.m2.y);
-    d = v.z - s.mean.z; s.mean.z += d * r; s.m2.z = fmaf(d, v.z - s.mean.z, s.m2.z);
-    d = v.w - s.mean.w; s.mean.w += d * r; s.m2.w = fmaf(d, v.w - s.mean.w, s.m2.w);
+    d = v.x - s.K.x; s.s1.x += d; s.s2.x = fmaf(d, d, s.s2.x);
+    d = v.y - s.K.y; s.s1.y += d; s.s2.y = fmaf(d, d, s.s2.y);
+    d = v.z - s.K.z; s.s1.z += d; s.s2.z = fmaf(d, d, s.s2.z);
+    d = v.w - s.K.w; s.s1.w += d; s.s2.w = fmaf(d, d, s.s2.w);
 }
 
 // x [N][H][W] (single channel), w OIHW [Cout][1][3][3], y NHWC [P][Cs].
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             b4.z = c + 2 < Cout ? bias[c + 2] : 0.f; b4.w = c + 3 < Cout ? bias[c + 3] : 0.f;
         }
     }
-    Wf4 st; st.mean = make_float4(0, 0, 0, 0); st.m2 = st.mean; st.n = 0.f;
+    Sh4 st; st.K = make_float4(0, 0, 0, 0); st.s1 = st.K; st.s2 = st.K; st.n = 0.f;
     if (active)
         for (long p = p0 + pl; p < p1; p += PL) {
             const int xx = (int)(p % W);
@@ -71,12 +72,18 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
             acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
             amx_st4(y + (size_t)p * Cs + cg * 4, acc);
-            wf_push(st, acc);
+            sh_push(st, acc);
         }
     if (!stats) return;
     if (active) {
-        amx_st4(s + ((size_t)(pl * 3 + 0) * Cs + cg * 4), st.mean);
-        amx_st4(s + ((size_t)(pl * 3 + 1) * Cs + cg * 4), st.m2);
+        const float inv = st.n > 0.f ? 1.f / st.n : 0.f;
+        float4 mean, m2;
+        mean.x = st.K.x + st.s1.x * inv; m2.x = st.s2.x - st.s1.x * st.s1.x * inv;
+        mean.y = st.K.y + st.s1.y * inv; m2.y = st.s2.y - st.s1.y * st.s1.y * inv;
+        mean.z = st.K.z + st.s1.z * inv; m2.z = st.s2.z - st.s1.z * st.s1.z * inv;
+        mean.w = st.K.w + st.s1.w * inv; m2.w = st.s2.w - st.s1.w * st.s1.w * inv;
+        amx_st4(s + ((size_t)(pl * 3 + 0) * Cs + cg * 4), mean);
+        amx_st4(s + ((size_t)(pl * 3 + 1) * Cs + cg * 4), m2);
         s[(size_t)(pl * 3 + 2) * Cs + cg * 4] = st.n;
     }
     __syncthreads();

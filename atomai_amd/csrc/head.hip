@@ -10,25 +10,22 @@
 
 // ------------------------------------------------------------------ px forward
 // logits[n][k][h][w] (NCHW, the module's public output) = sum_c xn[p][c] * W[k][c] + b[k],
-// xn = a*scale + shift (BN of the previous block applied on load).  LPP lanes cooperate on a pixel.
+// xn = a*scale + shift (BN of the previous block applied on load).
 // mode 0: raw logits NCHW.  mode 1: probabilities NHWC [P][K] (sigmoid if K == 1 else softmax).
 __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ out,
-                                                     long npix, long HW, int C, int Cs, int K, int LPP,
-                                                     int mode) {
+                                                     long npix, long HW, int C, int Cs, int K, int mode) {
+    // one thread per pixel: the Cs floats of a pixel are contiguous (a wave reads one contiguous 64*Cs*4 B
+    // span), and every class plane is written with unit stride across the wave
     const int G = Cs >> 2;
-    const int tid = threadIdx.x;
-    const int cg = tid % LPP;
-    const int ppb = 256 / LPP;
-    for (long p0 = (long)blockIdx.x * ppb; p0 < npix; p0 += (long)gridDim.x * ppb) {
-        const long p = p0 + tid / LPP;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
         float acc[MAXCLS];
         #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) acc[k] = 0.f;
-        if (p < npix && cg < G) {
+        for (int k = 0; k < MAXCLS; ++k) acc[k] = k < K ? b[k] : 0.f;
+        for (int cg = 0; cg < G; ++cg) {
             float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
             if (scale) {
                 const float4 sc = amx_ld4(scale + cg * 4), sh = amx_ld4(shift + cg * 4);
@@ -46,41 +43,23 @@ __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a
                 }
             }
         }
-        #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) {
-            if (k >= K) break;
-            for (int o = 1; o < LPP; o <<= 1) acc[k] += __shfl_xor(acc[k], o);
-            acc[k] += b[k];
-        }
-        if (p < npix) {
-            if (mode == 0) {
-                const long n = p / HW, hw = p - n * HW;
-                if (cg < K) {
-                    float v = 0.f;
-                    #pragma unroll
-                    for (int k = 0; k < MAXCLS; ++k) if (k == cg) v = acc[k];
-                    out[((size_t)n * K + cg) * HW + hw] = v;
-                }
-                if (LPP < K && cg == 0)
-                    for (int k = LPP; k < K; ++k) out[((size_t)n * K + k) * HW + hw] = acc[k];
-            } else if (cg == 0) {
-                if (K == 1) out[p] = 1.f / (1.f + expf(-acc[0]));
-                else {
-                    float mx = acc[0];
-                    for (int k = 1; k < K; ++k) mx = fmaxf(mx, acc[k]);
-                    float s = 0.f, e[MAXCLS];
-                    for (int k = 0; k < K; ++k) { e[k] = expf(acc[k] - mx); s += e[k]; }
-                    for (int k = 0; k < K; ++k) out[(size_t)p * K + k] = e[k] / s;
-                }
-            }
+        if (mode == 0) {
+            const long n = p / HW, hw = p - n * HW;
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < K) out[((size_t)n * K + k) * HW + hw] = acc[k];
+        } else if (K == 1) {
+            out[p] = 1.f / (1.f + expf(-acc[0]));
+        } else {
+            float mx = acc[0];
+            #pragma unroll
+            for (int k = 1; k < MAXCLS; ++k) if (k < K) mx = fmaxf(mx, acc[k]);
+            float s = 0.f;
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < K) { acc[k] = expf(acc[k] - mx); s += acc[k]; }
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) if (k < K) out[(size_t)p * K + k] = acc[k] / s;
         }
     }
-}
-
-static int lanes_per_pixel(int Cs) {
-    int g = Cs / 4, l = 1;
-    while (l < g) l <<= 1;
-    return l;
 }
 
 extern "C" int amx_px_fwd(const float* a, const float* scale, const float* shift, const float* w,
@@ -90,11 +69,10 @@ extern "C" int amx_px_fwd(const float* a, const float* scale, const float* shift
     if (K < 1 || K > MAXCLS) AMX_BADARG(2);
     if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
     const long npix = (long)N * H * W;
-    const int LPP = lanes_per_pixel(Cs), ppb = 256 / LPP;
-    long nb = (npix + ppb - 1) / ppb;
+    long nb = (npix + 255) / 256;
     if (nb > 16384) nb = 16384;
     AMX_LAUNCH(px_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, a, scale, shift, w, b,
-               out, npix, (long)H * W, C, Cs, K, LPP, mode);
+               out, npix, (long)H * W, C, Cs, K, mode);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -79,8 +79,14 @@ class KernelTimer:
             fl = 0.0
             if name == "amx_conv2d_fwd":      # (.., C0s@3, .., C1s@7, .., N@16,H@17,W@18,cout@19,taps@20, ..)
                 fl = 2.0 * (args[3] + args[7]) * args[19] * args[20] * args[16] * args[17] * args[18]
+            elif name == "amx_conv2d_dgrad":  # (dy,aux,k1,k2,k3,bslope,Cs@6,wpk,addend,y,Y0s@10,y1,Y1s@12,..,N@16,H,W,taps@19)
+                fl = 2.0 * args[6] * (args[10] + args[12]) * args[19] * args[16] * args[17] * args[18]
+                name = "amx_conv2d_fwd"       # same kernel (conv_fwd_kernel): one family
             elif name == "amx_conv2d_wgrad":  # (.., C0s@3, .., C1s@7, dpre@8, Dos@9, part@10, N@11,H,W,cout@14,taps@15)
                 fl = 2.0 * (args[3] + args[7]) * args[14] * args[15] * args[11] * args[12] * args[13]
+            elif name == "amx_conv2d_wgrad_fused":  # (.., C0s@3, .., C1s@7, dy@8, .., Dos@14, part, bpart, N@17,H,W,cout@20,taps@21)
+                fl = 2.0 * (args[3] + args[7]) * args[20] * args[21] * args[17] * args[18] * args[19]
+                name = "amx_conv2d_wgrad"
             d = out.setdefault(name, dict(calls=0, total_ms=0.0, flops=0.0))
             d["calls"] += 1
             d["total_ms"] += ms
@@ -134,7 +140,7 @@ def main():
                           batch_size=BS, plot_training_history=False)
     if world > 1:
         model.dp = DataParallelGrads(model.optimizer, model.net)
-    timer = None if args.no_kernel_timing else KernelTimer(["amx_conv2d_fwd", "amx_conv2d_wgrad"])
+    timer = None if args.no_kernel_timing else KernelTimer(["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
     from atomai_amd.engine import Tape
 
     def barrier():
