@@ -167,6 +167,36 @@ class rDecoderNet(nn.Module):
         return h.reshape(batch_dim, *self.reshape_)
 
 
+class convEncoderNet(nn.Module):
+    """Convolutional inference network (reference: atomai/nets/ed.py:231-289).
+
+    ``conv`` is the HIP ConvBlock (``num_layers`` x [Conv2d 3x3 -> LeakyReLU(0.1)], no BatchNorm), followed
+    by two Linear heads over the flattened (hidden_dim*H*W, NCHW order) feature map.  Inputs are (B,H,W) or
+    channel-last (B,H,W,C), as in the reference.
+    """
+
+    def __init__(self, in_dim: Tuple[int], latent_dim: int = 2, num_layers: int = 2, hidden_dim: int = 32,
+                 **kwargs) -> None:
+        super().__init__()
+        if len(in_dim) not in (1, 2, 3):
+            raise ValueError("The input dimensions must be (length,) for 1D data and "
+                             "(height, width) or (height, width, channel) for 2D data")
+        if len(in_dim) == 1:
+            raise NotImplementedError("1-D (spectral) encoders are outside the MI355X hot path")
+        from .blocks import ConvBlock
+        channels = in_dim[-1] if len(in_dim) > 2 else 1
+        self.conv = ConvBlock(2, num_layers, channels, hidden_dim, lrelu_a=kwargs.get("lrelu_a", 0.1))
+        self.reshape_ = int(hidden_dim * np.prod(in_dim[:2]))
+        self.fc11 = nn.Linear(self.reshape_, latent_dim)
+        self.fc12 = nn.Linear(self.reshape_, latent_dim)
+        self._out = nn.Softplus() if kwargs.get("softplus_out") else (lambda t: t)
+
+    def forward(self, x: torch.Tensor):
+        x = x.unsqueeze(1) if x.ndim in (2, 3) else x.permute(0, -1, 1, 2)
+        feats = self.conv(x.contiguous()).reshape(-1, self.reshape_)
+        return self.fc11(feats), self._out(self.fc12(feats))
+
+
 def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_dim: Optional[List] = None,
                   nb_classes: int = 0, **kwargs):
     """Encoder / decoder factory + metadict with the reference's keys (ed.py:725-790)."""
@@ -181,14 +211,15 @@ def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_
     softplus_out = kwargs.get("softplus_out")
     if discrete_dim:
         raise NotImplementedError("joint (discrete) VAEs are outside the MI355X hot path of this build")
-    if conv_e or conv_d:
-        raise NotImplementedError("convolutional VAE encoders/decoders are the next widening step "
-                                  "(they reuse the ConvBlock kernels)")
+    if conv_d:
+        raise NotImplementedError("convDecoderNet is outside the MI355X hot path (SURVEY.md section 8a lists "
+                                  "the fc/rDecoder and the opt-in conv *encoder* only)")
     if not coord:
         decoder_net = fcDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d)
     else:
         decoder_net = rDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d, skip)
-    encoder_net = fcEncoderNet(in_dim, latent_dim + coord, numlayers_e, numhidden_e, softplus_out=softplus_out)
+    enc_cls = convEncoderNet if conv_e else fcEncoderNet
+    encoder_net = enc_cls(in_dim, latent_dim + coord, numlayers_e, numhidden_e, softplus_out=softplus_out)
     meta_state_dict = {"model_type": "vae", "in_dim": in_dim, "latent_dim": latent_dim, "coord": coord,
                        "conv_encoder": conv_e, "numlayers_encoder": numlayers_e,
                        "numlayers_decoder": numlayers_d, "numhidden_encoder": numhidden_e,
