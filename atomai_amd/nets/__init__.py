@@ -1,8 +1,8 @@
 from .blocks import ConvBlock, DilatedBlock, UpsampleBlock
-from .ed import coord_latent, fcDecoderNet, fcEncoderNet, init_VAE_nets, rDecoderNet
+from .ed import convEncoderNet, coord_latent, fcDecoderNet, fcEncoderNet, init_VAE_nets, rDecoderNet
 from .fcnn import Unet, dilnet, init_fcnn_model
 from .gp import GPRegressionModel, convFeatureExtractor, fcFeatureExtractor
 
 __all__ = ["ConvBlock", "UpsampleBlock", "DilatedBlock", "Unet", "dilnet", "init_fcnn_model",
-           "fcEncoderNet", "fcDecoderNet", "rDecoderNet", "coord_latent", "init_VAE_nets",
+           "fcEncoderNet", "convEncoderNet", "fcDecoderNet", "rDecoderNet", "coord_latent", "init_VAE_nets",
            "fcFeatureExtractor", "convFeatureExtractor", "GPRegressionModel"]

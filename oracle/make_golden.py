@@ -189,6 +189,62 @@ def make_predict(aoi):
     print("predict ok", out["Unet|probs"].shape, out["dilnet|probs"].shape)
 
 
+def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3):
+    x = rs.rand(B, *in_dim).astype(np.float32)
+    eps_all = rs.randn(steps, B, 8).astype(np.float32)
+    out[f"{name}|x"], out[f"{name}|eps"] = x, eps_all
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        m = ctor()
+        if tag == "f32":
+            for k, v in m.encoder_net.state_dict().items():
+                out[f"{name}|enc|{k}"] = v.numpy().copy()
+            for k, v in m.decoder_net.state_dict().items():
+                out[f"{name}|dec|{k}"] = v.numpy().copy()
+        m.encoder_net.to(dt), m.decoder_net.to(dt)
+        if hasattr(m, "x_coord"):
+            m.x_coord = m.x_coord.to(dt)
+        # what rVAE.fit / VAE.fit set up before the epoch loop (rvae.py:191-200, vae.py:722-731)
+        if hasattr(m, "translation"):
+            m.dx_prior = fit_kw.get("translation_prior", 0.1)
+            m.kdict_["phi_prior"] = fit_kw.get("rotation_prior", 0.1)
+        if "capacity" in fit_kw:
+            m.kdict_["capacity"] = fit_kw["capacity"]
+        m.loss = "mse"
+        m.compile_trainer((x, None), None, batch_size=B)
+        state = {"i": 0}
+
+        def reparam(z_mean, z_sd, st=state, e=eps_all, d=dt):
+            ee = torch.from_numpy(e[st["i"]][:, :z_mean.shape[1]]).to(d)
+            return z_mean + z_sd * ee
+        m.reparameterize = reparam
+        xt = torch.from_numpy(x).to(dt)
+        elbos = []
+        for s in range(steps):
+            state["i"] = s
+            m.encoder_net.train(), m.decoder_net.train()
+            m.optim.zero_grad()
+            elbo = m.forward_compute_elbo(xt)
+            (-elbo).backward()
+            if s == 0:
+                for k, p in m.encoder_net.named_parameters():
+                    out[f"{name}|genc|{k}|{tag}"] = p.grad.numpy().copy()
+                for k, p in m.decoder_net.named_parameters():
+                    out[f"{name}|gdec|{k}|{tag}"] = p.grad.numpy().copy()
+            m.optim.step()
+            elbos.append(elbo.item())
+        out[f"{name}|elbo|{tag}"] = np.array(elbos)
+        for k, v in m.encoder_net.state_dict().items():
+            out[f"{name}|enc_after|{k}|{tag}"] = v.numpy().copy()
+        for k, v in m.decoder_net.state_dict().items():
+            out[f"{name}|dec_after|{k}|{tag}"] = v.numpy().copy()
+        # encode / decode (eval) with the trained nets
+        with torch.no_grad():
+            zm, zs = m.encoder_net(xt)
+        out[f"{name}|zmean|{tag}"], out[f"{name}|zlogsd|{tag}"] = zm.numpy(), zs.numpy()
+    print(name, "elbo f32", out[f"{name}|elbo|f32"], "f64", out[f"{name}|elbo|f64"])
+
+
+
 def make_vae(aoi):
     from atomai.utils import set_train_rng
     from atomai.utils.coords import imcoordgrid, transform_coordinates
@@ -203,59 +259,8 @@ def make_vae(aoi):
     out["tc_phi"], out["tc_dx"] = phi.numpy(), dx.numpy()
     out["tc_out"] = transform_coordinates(g, phi, dx).numpy()
 
-    def run(name, ctor, fit_kw, in_dim, B, steps=3, inject=True):
-        x = rs.rand(B, *in_dim).astype(np.float32)
-        eps_all = rs.randn(steps, B, 8).astype(np.float32)
-        out[f"{name}|x"], out[f"{name}|eps"] = x, eps_all
-        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
-            m = ctor()
-            if tag == "f32":
-                for k, v in m.encoder_net.state_dict().items():
-                    out[f"{name}|enc|{k}"] = v.numpy().copy()
-                for k, v in m.decoder_net.state_dict().items():
-                    out[f"{name}|dec|{k}"] = v.numpy().copy()
-            m.encoder_net.to(dt), m.decoder_net.to(dt)
-            if hasattr(m, "x_coord"):
-                m.x_coord = m.x_coord.to(dt)
-            # what rVAE.fit / VAE.fit set up before the epoch loop (rvae.py:191-200, vae.py:722-731)
-            if hasattr(m, "translation"):
-                m.dx_prior = fit_kw.get("translation_prior", 0.1)
-                m.kdict_["phi_prior"] = fit_kw.get("rotation_prior", 0.1)
-            if "capacity" in fit_kw:
-                m.kdict_["capacity"] = fit_kw["capacity"]
-            m.loss = "mse"
-            m.compile_trainer((x, None), None, batch_size=B)
-            state = {"i": 0}
-
-            def reparam(z_mean, z_sd, st=state, e=eps_all, d=dt):
-                ee = torch.from_numpy(e[st["i"]][:, :z_mean.shape[1]]).to(d)
-                return z_mean + z_sd * ee
-            m.reparameterize = reparam
-            xt = torch.from_numpy(x).to(dt)
-            elbos = []
-            for s in range(steps):
-                state["i"] = s
-                m.encoder_net.train(), m.decoder_net.train()
-                m.optim.zero_grad()
-                elbo = m.forward_compute_elbo(xt)
-                (-elbo).backward()
-                if s == 0:
-                    for k, p in m.encoder_net.named_parameters():
-                        out[f"{name}|genc|{k}|{tag}"] = p.grad.numpy().copy()
-                    for k, p in m.decoder_net.named_parameters():
-                        out[f"{name}|gdec|{k}|{tag}"] = p.grad.numpy().copy()
-                m.optim.step()
-                elbos.append(elbo.item())
-            out[f"{name}|elbo|{tag}"] = np.array(elbos)
-            for k, v in m.encoder_net.state_dict().items():
-                out[f"{name}|enc_after|{k}|{tag}"] = v.numpy().copy()
-            for k, v in m.decoder_net.state_dict().items():
-                out[f"{name}|dec_after|{k}|{tag}"] = v.numpy().copy()
-            # encode / decode (eval) with the trained nets
-            with torch.no_grad():
-                zm, zs = m.encoder_net(xt)
-            out[f"{name}|zmean|{tag}"], out[f"{name}|zlogsd|{tag}"] = zm.numpy(), zs.numpy()
-        print(name, "elbo f32", out[f"{name}|elbo|f32"], "f64", out[f"{name}|elbo|f64"])
+    def run(*a, **k):
+        _vae_run(out, rs, *a, **k)
 
     cwd = os.getcwd()
     os.chdir("/tmp")
@@ -275,11 +280,27 @@ def make_vae(aoi):
     np.savez_compressed(os.path.join(GOLD, "vae.npz"), **out)
 
 
+def make_vae_conv(aoi):
+    """rVAE with the opt-in convolutional encoder (ed.py:231-289): ConvBlock(lrelu 0.1, no BN) + two Linear."""
+    out = {}
+    rs = np.random.RandomState(11)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        _vae_run(out, rs, "rvae16_conv",
+                 lambda: aoi.models.rVAE((16, 16), latent_dim=2, seed=0, conv_encoder=True,
+                                         numhidden_encoder=8, numhidden_decoder=32),
+                 dict(), (16, 16), 4)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "vae_conv.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv}[w](aoi)
     print("done ->", GOLD)

@@ -47,6 +47,24 @@ def fc_encoder(sd: StateDict, x: Tensor, num_layers: int = 2, softplus_out: bool
     return mu, ls
 
 
+def conv_encoder(sd: StateDict, x: Tensor, num_layers: int = 2, lrelu_a: float = 0.1,
+                 softplus_out: bool = False):
+    """convEncoderNet.forward (atomai/nets/ed.py:276-289): ConvBlock without BatchNorm
+    (conv 3x3 pad 1 -> LeakyReLU(lrelu_a), atomai/nets/blocks.py:59-76; Sequential indices 0,2,4..),
+    NCHW flatten, two Linear heads."""
+    F = torch.nn.functional
+    h = x.unsqueeze(1) if x.ndim in (2, 3) else x.permute(0, 3, 1, 2)
+    for i in range(num_layers):
+        h = F.leaky_relu(F.conv2d(h, sd[f"conv.block.{2 * i}.weight"], sd[f"conv.block.{2 * i}.bias"],
+                                  padding=1), lrelu_a)
+    h = h.reshape(h.shape[0], -1)
+    mu = F.linear(h, sd["fc11.weight"], sd["fc11.bias"])
+    ls = F.linear(h, sd["fc12.weight"], sd["fc12.bias"])
+    if softplus_out:
+        ls = F.softplus(ls)
+    return mu, ls
+
+
 def r_decoder(sd: StateDict, x_coord: Tensor, z: Tensor, out_hw: Tuple[int, int], num_layers: int = 2,
               skip: bool = False) -> Tensor:
     """rDecoderNet.forward + coord_latent.forward (atomai/nets/ed.py:626-642, 672-687)."""
@@ -120,11 +138,12 @@ def vae_elbo(x, x_rec, z_mean, z_logsd, capacity=None, num_iter: int = 0) -> Ten
 
 def rvae_forward_elbo(enc: StateDict, dec: StateDict, x: Tensor, eps: Tensor, x_coord: Tensor,
                       translation: bool = True, dx_prior: float = 0.1, phi_prior: float = 0.1,
-                      skip: bool = False, capacity=None, num_iter: int = 0, num_layers=(2, 2)) -> Tensor:
+                      skip: bool = False, capacity=None, num_iter: int = 0, num_layers=(2, 2),
+                      conv_enc: bool = False) -> Tensor:
     """rVAE.forward_compute_elbo, training mode, with the reparameterisation noise injected
     (atomai/models/dgm/rvae.py:110-147; trainers/vitrainer.py:223-234)."""
     B = x.shape[0]
-    z_mean, z_logsd = fc_encoder(enc, x, num_layers[0])
+    z_mean, z_logsd = (conv_encoder if conv_enc else fc_encoder)(enc, x, num_layers[0])
     z = z_mean + torch.exp(z_logsd) * eps[:, : z_mean.shape[1]]
     phi = z[:, 0]
     if translation:

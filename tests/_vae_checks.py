@@ -12,13 +12,15 @@ CASES = {
     "rvae16_cap": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32, translation=False,
                                               skip=True), fit=dict(capacity=[5.0, 100, 2.0])),
     "vae16": dict(cls="VAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32), fit=dict()),
+    "rvae16_conv": dict(cls="rVAE", ctor=dict(conv_encoder=True, numhidden_encoder=8, numhidden_decoder=32),
+                        fit=dict(), file="vae_conv.npz"),
 }
 
 
 def check_vae_case(name, device):
     import atomai_amd as aoi
-    g = np.load(os.path.join(GOLD, "vae.npz"))
     c = CASES[name]
+    g = np.load(os.path.join(GOLD, c.get("file", "vae.npz")))
     m = getattr(aoi.models, c["cls"])((16, 16), latent_dim=2, seed=0, **c["ctor"])
     for k, v in m.encoder_net.state_dict().items():        # RNG-order initialisation == reference
         assert np.array_equal(v.cpu().numpy(), g[f"{name}|enc|{k}"]), k

@@ -12,6 +12,7 @@ CASES = {
     "rvae16": dict(kind="rvae", translation=True, skip=False, capacity=None),
     "rvae16_cap": dict(kind="rvae", translation=False, skip=True, capacity=[5.0, 100, 2.0]),
     "vae16": dict(kind="vae", capacity=None),
+    "rvae16_conv": dict(kind="rvae", translation=True, skip=False, capacity=None, conv=True, file="vae_conv.npz"),
 }
 
 
@@ -31,8 +32,8 @@ def test_coordinate_helpers(golden_dir):
 @pytest.mark.parametrize("name", list(CASES))
 @pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-10)])
 def test_elbo_and_grads(golden_dir, name, tag, dtype, tol):
-    g = np.load(os.path.join(golden_dir, "vae.npz"))
     c = CASES[name]
+    g = np.load(os.path.join(golden_dir, c.get("file", "vae.npz")))
     enc, dec = _sd(g, f"{name}|enc|", dtype), _sd(g, f"{name}|dec|", dtype)
     x = torch.from_numpy(g[f"{name}|x"]).to(dtype)
     eps = torch.from_numpy(g[f"{name}|eps"][0]).to(dtype)
@@ -42,7 +43,7 @@ def test_elbo_and_grads(golden_dir, name, tag, dtype, tol):
     d = {k: leaves[("d", k)] for k in dec}
     if c["kind"] == "rvae":
         elbo = vo.rvae_forward_elbo(e, d, x, eps, vo.imcoordgrid((16, 16), dtype), c["translation"], 0.1, 0.1,
-                                    c["skip"], c["capacity"], num_iter=1)
+                                    c["skip"], c["capacity"], num_iter=1, conv_enc=c.get("conv", False))
     else:
         elbo = vo.vae_forward_elbo(e, d, x, eps, c["capacity"], num_iter=1)
     np.testing.assert_allclose(float(elbo), g[f"{name}|elbo|{tag}"][0], rtol=tol)
