@@ -71,16 +71,33 @@ class coord_latent(nn.Module):
         self.activation = nn.Tanh() if activation else None
 
 
+_RDEC_WIDTHS = (32, 64, 128)          # hidden widths the fused kernels are instantiated for (rdecoder.hip)
+
+
+def _zero_pad(t: torch.Tensor, shape) -> torch.Tensor:
+    """Zero-extends ``t`` to ``shape`` (leading corner).  Hidden units added this way have zero weights and
+    biases on both sides, hence stay exactly 0 through tanh / skip connections and change no result."""
+    t = t.detach()
+    if tuple(t.shape) == tuple(shape):
+        return t.contiguous()
+    out = torch.zeros(shape, dtype=t.dtype, device=t.device)
+    out[tuple(slice(0, d) for d in t.shape)] = t
+    return out
+
+
 class _RDecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x_coord, z, *params):
         B, n = x_coord.shape[:2]
-        hid, NL, Ldim = net.hidden_dim, net.num_layers, z.shape[1]
+        hid0, NL, Ldim = net.hidden_dim, net.num_layers, z.shape[1]
+        hid = next(w for w in _RDEC_WIDTHS if w >= hid0)
         Wc, bc, Wz = params[0], params[1], params[2]
         Ws, bs = params[3:3 + 2 * NL:2], params[4:4 + 2 * NL:2]
         Wo, bo = params[3 + 2 * NL], params[4 + 2 * NL]
-        W = torch.stack([w.detach() for w in Ws]).contiguous()
-        b = torch.stack([v.detach() for v in bs]).contiguous()
+        W = _zero_pad(torch.stack([w.detach() for w in Ws]), (NL, hid, hid))
+        b = _zero_pad(torch.stack([v.detach() for v in bs]), (NL, hid))
+        Wc, bc, Wz = _zero_pad(Wc, (hid, 2)), _zero_pad(bc, (hid,)), _zero_pad(Wz, (hid, Ldim))
+        Wo = _zero_pad(Wo, (1, hid))
         coords = x_coord.detach().contiguous()
         zz = z.detach().contiguous()
         xrec = torch.empty(B, n, dtype=torch.float32, device=coords.device)
@@ -88,7 +105,7 @@ class _RDecoderFn(torch.autograd.Function):
         L.call("amx_rdecoder_fwd", L.ptr(coords), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
                L.ptr(Wz.detach().contiguous()), L.ptr(W), L.ptr(b), L.ptr(Wo.detach().reshape(-1)),
                L.ptr(bo.detach()), L.ptr(xrec), B, n, Ldim, hid, NL, int(net.skip), sp)
-        ctx.net = net
+        ctx.net, ctx.hid = net, hid
         ctx.save_for_backward(coords, zz, W, b, *[p.detach() for p in (Wc, bc, Wz, Wo, bo)])
         return xrec
 
@@ -97,7 +114,7 @@ class _RDecoderFn(torch.autograd.Function):
         net = ctx.net
         coords, zz, W, b, Wc, bc, Wz, Wo, bo = ctx.saved_tensors
         B, n = coords.shape[:2]
-        hid, NL, Ldim = net.hidden_dim, net.num_layers, zz.shape[1]
+        hid, hid0, NL, Ldim = ctx.hid, net.hidden_dim, net.num_layers, zz.shape[1]
         dev = coords.device
         Wt = W.transpose(1, 2).contiguous()
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -121,12 +138,12 @@ class _RDecoderFn(torch.autograd.Function):
                 src, rows = tmp, -(-rows // -(-rows // nch))
             L.call("amx_reduce_rows_chunked", L.ptr(src), rows, cols, 1, L.ptr(out), sp)
             return out.view(shape)
-        gW = rsum(pW, (NL, hid, hid))
-        gb = rsum(pb, (NL, hid))
-        grads = [rsum(pWc, (hid, 2)), rsum(pbc, (hid,)), rsum(pWz, (hid, Ldim))]
+        gW = rsum(pW, (NL, hid, hid))[:, :hid0, :hid0]
+        gb = rsum(pb, (NL, hid))[:, :hid0]
+        grads = [rsum(pWc, (hid, 2))[:hid0], rsum(pbc, (hid,))[:hid0], rsum(pWz, (hid, Ldim))[:hid0]]
         for l in range(NL):
             grads += [gW[l], gb[l]]
-        grads += [rsum(pWo, (1, hid)), rsum(pbo, (1,))]
+        grads += [rsum(pWo, (1, hid))[:, :hid0], rsum(pbo, (1,))]
         return (None, dcoords, dz) + tuple(grads)
 
 
@@ -154,8 +171,8 @@ class rDecoderNet(nn.Module):
     def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         if self.channels != 1:
             raise NotImplementedError("multi-channel spatial decoding is outside this build's hot path")
-        if self.hidden_dim not in (32, 64, 128) or not 1 <= self.num_layers <= 3:
-            raise NotImplementedError("fused rDecoderNet supports hidden_dim in {32,64,128}, 1-3 layers")
+        if self.hidden_dim > _RDEC_WIDTHS[-1] or not 1 <= self.num_layers <= 3:
+            raise NotImplementedError("fused rDecoderNet supports hidden_dim <= 128 and 1-3 layers")
         batch_dim = x_coord.size(0)
         params = [self.coord_latent.fc_coord.weight, self.coord_latent.fc_coord.bias,
                   self.coord_latent.fc_latent.weight]

@@ -133,6 +133,15 @@ class FusedAdam(torch.optim.Adam):
         L.call("amx_adam_flat", L.ptr(f["p"][seg]), L.ptr(f["g"][seg]), L.ptr(f["m"][seg]),
                L.ptr(f["v"][seg]), n, lr, b1, b2, eps, bc1, bc2, float(self.grad_scale), sp)
 
+    def as_torch_adam(self) -> torch.optim.Adam:
+        """Plain ``torch.optim.Adam`` over the same parameters with a copy of the current state: what the
+        trainers pickle into checkpoints so that they load without this package (reference format:
+        atomai/trainers/trainer.py:344-358)."""
+        grp = self.param_groups[0]
+        opt = torch.optim.Adam(self._params(), lr=grp["lr"], betas=grp["betas"], eps=grp["eps"])
+        opt.load_state_dict(self.state_dict())
+        return opt
+
     def zero_grad(self, set_to_none: bool = True):
         # gradients are rewritten (not accumulated) by the next backward when they are None
         return super().zero_grad(set_to_none=set_to_none)

@@ -165,8 +165,13 @@ class BaseTrainer:
     def save_model(self, *args: str) -> None:
         """torch.save of {architecture kwargs, 'weights', 'optimizer'} (trainer.py:344-358)."""
         filename = args[0] if args else self.filename
-        self.meta_state_dict["weights"] = self.meta_state_dict.get("weights", self.net.state_dict())
-        self.meta_state_dict["optimizer"] = self.meta_state_dict.get("optimizer", self.optimizer)
+        # always re-read: FusedAdam re-points the parameters into its flat buffer, so a state dict captured
+        # at construction time (as the reference keeps, relying on aliasing) would be stale here
+        self.meta_state_dict["weights"] = self.net.state_dict()
+        if isinstance(self.optimizer, FusedAdam):    # stored as its torch.optim.Adam equivalent (portable)
+            self.meta_state_dict["optimizer"] = self.optimizer.as_torch_adam()
+        else:
+            self.meta_state_dict["optimizer"] = self.meta_state_dict.get("optimizer", self.optimizer)
         if self.dp is None or self.dp.rank == 0:
             torch.save(self.meta_state_dict, filename + '.tar')
 

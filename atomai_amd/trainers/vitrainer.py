@@ -159,7 +159,7 @@ class viBaseTrainer:
         savepath = args[0] if args else self.filename
         self.metadict["encoder"] = self.encoder_net.state_dict()
         self.metadict["decoder"] = self.decoder_net.state_dict()
-        self.metadict["optimizer"] = self.optim
+        self.metadict["optimizer"] = self.optim.as_torch_adam() if isinstance(self.optim, FusedAdam) else self.optim
         if self.dp is None or self.dp.rank == 0:
             torch.save(self.metadict, savepath + ".tar")
 

@@ -296,11 +296,45 @@ def make_vae_conv(aoi):
     np.savez_compressed(os.path.join(GOLD, "vae_conv.npz"), **out)
 
 
+def make_ckpt(aoi):
+    """Checkpoints written by the reference's own save_model (trainer.py:344-358, vitrainer.py:361-377) +
+    what the reference predicts / encodes after load_model (models/loaders.py:25-195)."""
+    import shutil
+    out = {}
+    rs = np.random.RandomState(21)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        X, Xt = rs.rand(6, 16, 16).astype(np.float32), rs.rand(4, 16, 16).astype(np.float32)
+        y, yt = rs.randint(0, 3, (6, 16, 16)), rs.randint(0, 3, (4, 16, 16))
+        m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4)
+        m.fit(X, y, Xt, yt, training_cycles=3, batch_size=2, filename="refseg", plot_training_history=False)
+        shutil.copy("refseg_metadict_final.tar", os.path.join(GOLD, "ref_seg_unet_ckpt.tar"))
+        lm = aoi.models.load_model("refseg_metadict_final.tar")
+        Xp = rs.rand(2, 16, 16).astype(np.float32)
+        out["seg|x"] = Xp
+        out["seg|pred"] = lm.predict(Xp, compute_coords=False)
+        out["seg|meta_keys"] = np.array(sorted(torch.load("refseg_metadict_final.tar", weights_only=False).keys()))
+        v = aoi.models.rVAE((16, 16), latent_dim=2, seed=0, numhidden_encoder=16, numhidden_decoder=16)
+        Xv = rs.rand(8, 16, 16).astype(np.float32)
+        v.fit(Xv, training_cycles=2, batch_size=4, filename="refrvae")
+        shutil.copy("refrvae.tar", os.path.join(GOLD, "ref_rvae_ckpt.tar"))
+        lv = aoi.models.load_model("refrvae.tar")
+        out["vae|x"] = Xv
+        zm, zs = lv.encode(Xv)
+        out["vae|zmean"], out["vae|zsd"] = zm, zs
+        out["vae|dec"] = lv.decode(np.array([[0.3, -0.2], [1.0, 0.5]], dtype=np.float32))
+        out["vae|meta_keys"] = np.array(sorted(torch.load("refrvae.tar", weights_only=False).keys()))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "ckpt.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt}[w](aoi)
     print("done ->", GOLD)

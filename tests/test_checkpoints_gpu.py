@@ -1,0 +1,23 @@
+"""`gpu` tier: checkpoint interchange with the reference through libatomai_amd.so on the MI355X."""
+import pytest
+
+import _ckpt_checks as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_load_reference_segmentor_checkpoint():
+    C.check_load_reference_seg()
+
+
+def test_load_reference_rvae_checkpoint():
+    C.check_load_reference_rvae()
+
+
+@pytest.mark.parametrize("model", ["Unet", "dilnet"])
+def test_io_segmentor(tmp_path, model):
+    C.check_roundtrip_seg(tmp_path, model)
+
+
+def test_io_rvae(tmp_path):
+    C.check_roundtrip_rvae(tmp_path)
