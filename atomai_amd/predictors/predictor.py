@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ..nets.fcnn import _HipNet, predict_proba
+from .locator import Locator, locate_device
 from ..utils import get_downsample_factor, get_nb_classes, img_pad, set_train_rng, torch_format_image
 
 
@@ -42,12 +43,17 @@ class BasePredictor:
         with torch.no_grad():
             return self.model(xnew.to(self.device))
 
-    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int) -> torch.Tensor:
-        """Batch-by-batch prediction into a host tensor (predictor.py:82-106)."""
+    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int,
+                      on_chunk=None) -> torch.Tensor:
+        """Batch-by-batch prediction into a host tensor (predictor.py:82-106).  ``on_chunk(start, out)`` sees
+        each chunk's output while it is still on the model's device."""
         bs = max(1, len(data) // max(1, num_batches))
         out = torch.empty(out_shape)
         for i in range(0, len(data), bs):
-            out[i:i + bs] = self.forward_(data[i:i + bs]).cpu()
+            res = self.forward_(data[i:i + bs])
+            if on_chunk is not None:
+                on_chunk(i, res)
+            out[i:i + bs] = res.cpu()
         return out
 
     def predict(self, data: torch.Tensor, out_shape: Tuple[int] = None, num_batches: int = 1):
@@ -105,9 +111,10 @@ class SegPredictor(BasePredictor):
             prob = torch.exp(prob)
         return prob.permute(0, 2, 3, 1)
 
-    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int) -> torch.Tensor:
+    def batch_predict(self, data: torch.Tensor, out_shape: Tuple[int], num_batches: int,
+                      on_chunk=None) -> torch.Tensor:
         if not (torch.cuda.is_available() and str(self.device).startswith("cuda")):
-            return super().batch_predict(data, out_shape, num_batches)
+            return super().batch_predict(data, out_shape, num_batches, on_chunk)
         n = len(data)
         out = torch.empty(out_shape)
         per_frame = max(data[0].numel(), int(np.prod(out_shape[1:]))) * 4
@@ -137,6 +144,8 @@ class SegPredictor(BasePredictor):
             main.wait_event(ev_in)
             prob = self.forward_(d)
             d.record_stream(main)
+            if on_chunk is not None:
+                on_chunk(s, prob)
             done = torch.cuda.Event()
             done.record(main)
             with torch.cuda.stream(copy_out):
@@ -156,19 +165,33 @@ class SegPredictor(BasePredictor):
         num_batches = kwargs.get("num_batches")
         if num_batches is None:
             num_batches = len(image_data) if (w >= 256 or h >= 256) else 10
-        segmented = self.batch_predict(image_data, (n, w, h, self.nb_classes), num_batches)
+        segmented = self.batch_predict(image_data, (n, w, h, self.nb_classes), num_batches,
+                                       kwargs.get("_on_chunk"))
         if return_image:
             return image_data.permute(0, 2, 3, 1).numpy(), segmented.numpy()
         return segmented.numpy()
 
     def run(self, image_data: np.ndarray, compute_coords=True, **kwargs: int):
+        """Prediction (+ blob centres).  With ``compute_coords`` the Locator kernels run on each chunk's
+        probabilities while they are still on the device (predictor.py:262-298 runs a host loop afterwards)."""
         start_time = time.time()
-        if compute_coords:
-            raise NotImplementedError("coordinate extraction (Locator: cv2 + scipy.ndimage on the CPU) is "
-                                      "the next widening step (SURVEY.md §8-f rank 1); pass "
-                                      "compute_coords=False")
-        decoded = self.predict(image_data, **kwargs)
+        if not compute_coords:
+            return self.predict(image_data, **kwargs)       # the reference prints nothing on this branch
+        if self.refine:
+            raise NotImplementedError("peak refinement (per-atom scipy.optimize Gaussian fits) is outside the "
+                                      "MI355X hot path of this build")
+        thresh = kwargs.get("thresh", self.thresh)
+        dist_edge = Locator(thresh).dist_edge               # Locator's default, as the reference uses it
+        coordinates = {}
+
+        def on_chunk(start, prob):
+            for i, v in locate_device(prob, thresh, dist_edge).items():
+                coordinates[start + i] = v
+        kw = {k: v for k, v in kwargs.items() if k != "thresh"}
+        decoded = self.predict(image_data, _on_chunk=on_chunk, **kw)
+        coordinates = {i: coordinates[i] for i in sorted(coordinates)}
         if self.verbose:
-            print(f"\n{decoded.shape[0]} image(s) decoded in approximately "
-                  f"{np.around(time.time() - start_time, decimals=4)} seconds")
-        return decoded
+            word = " image was " if decoded.shape[0] == 1 else " images were "
+            print("\n" + str(decoded.shape[0]) + word + "decoded in approximately "
+                  + str(np.around(time.time() - start_time, decimals=4)) + " seconds")
+        return decoded, coordinates

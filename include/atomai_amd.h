@@ -150,6 +150,21 @@ int amx_kernel_matvec(const void* X1, const void* X2, const void* inv_ls, double
 int amx_kernel_matrix_bwd(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
                           int is_double, const void* G, void* dX, void* part, void* stream);
 
+/* ---- Locator: thresholded class maps -> blob centres (atomai/predictors/predictor.py:531-639 Locator.run /
+ *      rem_edge_coord; atomai/utils/img.py:554-564 cv_thresh; atomai/utils/coords.py:21-34 find_com =
+ *      scipy.ndimage.label + center_of_mass).  prob: (B,H,W,C) fp32 NHWC probabilities; the first `nch`
+ *      channels are located (the reference skips the last = background class).  amx_locate_label labels the
+ *      4-connected components of prob > thr, accumulates the centres and writes the number of centres that
+ *      survive the dist_edge filter to *count (device int).  amx_locate_emit then writes them, ordered by
+ *      (frame, class, first pixel in raster order) = the reference's dictionary order: coords (cap,2) fp64
+ *      (row, col), meta (cap,2) int32 (frame, class).  Workspace: amx_locate_workspace_bytes (negative when
+ *      B*nch*H*W does not fit int32 labels: chunk the stack). */
+long amx_locate_workspace_bytes(int B, int H, int W, int nch);
+int amx_locate_label(const float* prob, int B, int H, int W, int C, int nch, float thr, int dist_edge, void* work,
+                     int* count, void* stream);
+int amx_locate_emit(const void* work, int B, int H, int W, int nch, int dist_edge, double* coords, int* meta,
+                    long cap, void* stream);
+
 /* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
 int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, double bc1, double bc2, float gscale, void* stream);

@@ -330,11 +330,40 @@ def make_ckpt(aoi):
     np.savez_compressed(os.path.join(GOLD, "ckpt.npz"), **out)
 
 
+def make_locator(aoi):
+    """Locator.run of the reference (predictor.py:584-611) on synthetic class maps.  cv2 is not installed in
+    this image: `cv_thresh` (utils/img.py:554-564, a one-line cv2.threshold wrapper) is replaced by the
+    documented THRESH_BINARY semantics; preprocess / find_com (scipy.ndimage) / rem_edge_coord / dictionary
+    assembly are the reference's own code."""
+    import atomai.predictors.predictor as rp
+    import locator_oracle as lo
+    rp.cv_thresh = lambda img, thr=.5: np.where(img > thr, 1, 0).astype(img.dtype)
+    rs = np.random.RandomState(33)
+    out = {}
+    cases = {"c3_48x64": (3, 48, 64, 3, 0.5, 5), "c1_40x40": (2, 40, 40, 1, 0.5, 3),
+             "c2_33x47_t07": (2, 33, 47, 2, 0.7, 0), "c3_64x64_dense": (2, 64, 64, 3, 0.3, 8)}
+    for name, (B, H, W, C, thr, de) in cases.items():
+        x = lo.synthetic_maps(rs, B, H, W, C, n_blobs=40 if "dense" in name else 12)
+        if name == "c1_40x40":
+            x[1] = 0.0                                   # a frame without any blob
+        d = rp.Locator(thr, de).run(x)
+        out[f"{name}|x"] = x
+        out[f"{name}|cfg"] = np.array([thr, de], dtype=np.float64)
+        for i, v in d.items():
+            out[f"{name}|coords|{i}"] = v
+        print(name, [v.shape for v in d.values()])
+    xcf = np.ascontiguousarray(np.transpose(out["c3_48x64|x"], (0, 3, 1, 2)))
+    dcf = rp.Locator(0.5, 5, dim_order="channel_first").run(xcf)
+    for i, v in dcf.items():
+        assert np.array_equal(v, out[f"c3_48x64|coords|{i}"])
+    np.savez_compressed(os.path.join(GOLD, "locator.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator}[w](aoi)
     print("done ->", GOLD)

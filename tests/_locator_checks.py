@@ -1,0 +1,82 @@
+"""Shared bodies of the Locator parity tests (emulator tier on CPU, gpu tier on the MI355X).
+Integer / index work: the bar is bit-exact against the oracle and the reference golden."""
+import os
+
+import numpy as np
+
+from oracle import locator_oracle as lo
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["c3_48x64", "c1_40x40", "c2_33x47_t07", "c3_64x64_dense"]
+
+
+def _same(got, want):
+    assert sorted(got) == sorted(want)
+    for i in want:
+        assert got[i].shape == want[i].shape and got[i].dtype == np.float64, (i, got[i].shape, want[i].shape)
+        assert np.array_equal(got[i], want[i]), (i, np.abs(got[i] - want[i]).max())
+
+
+def check_golden(name, device):
+    from atomai_amd.predictors import Locator
+    g = np.load(os.path.join(GOLD, "locator.npz"))
+    x = g[f"{name}|x"]
+    thr, de = g[f"{name}|cfg"]
+    want = {i: g[f"{name}|coords|{i}"] for i in range(len(x))}
+    _same(Locator(float(thr), int(de), device=device).run(x), want)
+    _same(lo.locate(x, float(thr), int(de)), want)                       # the oracle itself stays pinned
+    if name == "c3_48x64":                                               # channel_first + forced 1-frame chunks
+        xcf = np.ascontiguousarray(np.transpose(x, (0, 3, 1, 2)))
+        _same(Locator(float(thr), int(de), dim_order="channel_first", device=device, chunk_bytes=1).run(xcf), want)
+
+
+def check_shapes(device, big=False):
+    """Irregular components: percolation-like random masks (long snakes, holes, U-turns that need many
+    union-find hooks), all-foreground, all-background, single pixels, sizes that straddle the strip /
+    workgroup boundaries."""
+    from atomai_amd.predictors import Locator
+    rs = np.random.RandomState(17)
+    shapes = [(2, 37, 53, 2, 0.45), (1, 64, 96, 3, 0.62), (3, 17, 9, 1, 0.5), (1, 130, 257, 2, 0.41)]
+    if big:
+        shapes += [(4, 512, 512, 3, 0.4), (2, 1024, 1024, 1, 0.41)]
+    for (B, H, W, C, p) in shapes:
+        x = (rs.rand(B, H, W, C) > p).astype(np.float32) * 0.9
+        for de in (0, 4):
+            _same(Locator(0.5, de, device=device).run(x), lo.locate(x, 0.5, de))
+    ones = np.ones((1, 24, 40, 2), dtype=np.float32)
+    _same(Locator(0.5, 2, device=device).run(ones), lo.locate(ones, 0.5, 2))
+    zeros = np.zeros((2, 24, 40, 2), dtype=np.float32)
+    got = Locator(0.5, 2, device=device).run(zeros)
+    assert all(v.shape == (0, 3) for v in got.values()) and len(got) == 2
+    # spiral: one component whose first pixel is far from most of its mass
+    sp = np.zeros((1, 41, 41, 2), dtype=np.float32)
+    r0, r1, c0, c1 = 2, 38, 2, 38
+    while r1 - r0 > 3:
+        sp[0, r0, c0:c1 + 1, 0] = 1; sp[0, r0:r1 + 1, c1, 0] = 1; sp[0, r1, c0 + 2:c1 + 1, 0] = 1
+        sp[0, r0 + 2:r1 + 1, c0 + 2, 0] = 1; sp[0, r0 + 2, c0 + 2:c1 - 1, 0] = 1
+        r0 += 4; c0 += 4; r1 -= 4; c1 -= 4
+    _same(Locator(0.5, 0, device=device).run(sp), lo.locate(sp, 0.5, 0))
+    # threshold is strict (x > t) and NaN is background
+    edge = np.full((1, 8, 8, 2), 0.5, dtype=np.float32)
+    edge[0, 3, 3, 0] = np.nan
+    edge[0, 5, 5, 0] = np.nextafter(np.float32(0.5), np.float32(1))
+    got = Locator(0.5, 0, device=device).run(edge)[0]
+    assert np.array_equal(got, np.array([[5.0, 5.0, 0.0]]))
+
+
+def check_segmentor_predict(device):
+    """Segmentor.predict(compute_coords=True): (decoded, coordinates) as the reference returns them
+    (models/segmentor.py:151-200, predictors/predictor.py:262-298); coordinates must equal the oracle applied to
+    the decoded maps."""
+    import warnings
+    import atomai_amd as aoi
+    rs = np.random.RandomState(2)
+    m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4)
+    x = rs.rand(3, 32, 32).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        decoded, coords = m.predict(x, thresh=0.34, num_batches=2)
+        decoded2 = m.predict(x, compute_coords=False)
+    assert decoded.shape == (3, 32, 32, 3) and np.array_equal(decoded, decoded2)
+    _same(coords, lo.locate(decoded, 0.34, 5))
+    assert sum(len(v) for v in coords.values()) > 0
