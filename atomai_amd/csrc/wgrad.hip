@@ -256,14 +256,20 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     while (pl.WN * 2 <= rem && pl.WN * 2 <= co_tiles && 16 * pl.NT * pl.WN * 2 <= 64) pl.WN *= 2;
     pl.WK = rem / pl.WN;
     const int blocks = amx_ceil_div(pl.ci_pad, 16 * pl.WM) * amx_ceil_div(pl.co_pad, 16 * pl.NT * pl.WN);
-    // 4-row tiles: smaller LDS / register footprint -> more co-resident workgroups (+10..20 % measured,
-    // profiles/r01_conv_variants.md); the narrow NT == 1 case prefers 8 rows
-    pl.th = (taps == 9 && dil == 1 && pl.NT == 2) ? 4 : 8;
+    // Tile height / split-K target.  Stand-alone, layers with <= 32 input channels run 15-25 % faster with 4-row
+    // tiles and two workgroups per CU (profiles/r01_wgrad_sweep.md), but inside the training step the weight
+    // gradients run on the side stream next to the data-gradient convolutions, and there the lighter
+    // one-workgroup-per-CU launch wins (20.79 vs 21.43 ms/step, interleaved A/B with AMX_WGRAD_LIGHT): the step
+    // is what is optimised.  AMX_WGRAD_LIGHT=<wgs> switches the stand-alone optimum on for experiments.
+    bool light = false;
+    int light_wgs = 512;
+    if (const char* e = getenv("AMX_WGRAD_LIGHT")) { const int v = atoi(e); if (v >= 64) { light = pl.ci_pad <= 32; light_wgs = v; } }
+    pl.th = (taps == 9 && dil == 1 && (light || pl.NT == 2)) ? 4 : 8;
     if (const char* e = getenv("AMX_WGRAD_TH")) { const int v = atoi(e); if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }
     if (pl.WK > pl.th) pl.WK = pl.th;
     const int ntiles = amx_ceil_div(W, TW) * amx_ceil_div(H, pl.th) * N;
-    // split-K workgroups: one per CU is the measured optimum (256: 20.98 ms/step, 512: 21.5, 1024: 21.6, 128: 25.2)
-    int target = 256;
+    // split-K workgroups: one per CU (256: 20.98 ms/step, 512: 21.5, 1024: 21.6, 128: 25.2)
+    int target = light ? light_wgs : 256;
     if (const char* e = getenv("AMX_WGRAD_WGS")) { const int v = atoi(e); if (v >= 64) target = v; }
     int ks = amx_ceil_div(target, blocks);
     if (ks > ntiles) ks = ntiles;

@@ -134,10 +134,51 @@ def bench_dkl(N=16384, D=2):
     return out
 
 
+def bench_locate(frames=32, hw=1024, C=1):
+    """Locator on `frames` probability maps of hw x hw (the post-processing of configs[2]): HBM-bound integer
+    work; algorithmic bytes = the probabilities read once (4*C bytes per pixel)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import locator_oracle as lo
+    from atomai_amd.predictors.locator import locate_device
+    rs = np.random.RandomState(0)
+    base = lo.synthetic_maps(rs, 2, hw, hw, C, n_blobs=2500, noise=0.3)
+    x = torch.from_numpy(np.concatenate([base] * (frames // 2))).cuda()
+    recs = timed_calls({"amx_locate_label", "amx_locate_emit"})
+    import atomai_amd.predictors.locator as lm
+    lm.L.call = L.call
+    for _ in range(2):
+        d = locate_device(x, 0.5, 5)
+    torch.cuda.synchronize(); recs.clear()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        d = locate_device(x, 0.5, 5)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t_label = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_locate_label") / reps
+    t_emit = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_locate_emit") / reps
+    t0 = time.perf_counter()
+    ref = lo.locate(base.copy(), 0.5, 5)
+    cpu_dt = (time.perf_counter() - t0) / 2
+    same = all(np.array_equal(d[i], ref[i]) for i in range(2))
+    nbytes = frames * hw * hw * C * 4
+    gbps = nbytes / ((t_label + t_emit) * 1e-3) / 1e9
+    out = {"metric": f"Locator frames/sec ({hw}x{hw}, {C}-channel maps)", "value": round(frames / dt, 1),
+           "unit": "frames/s", "n_gpus": 1, "dtype": "i32", "ms_per_frame_device": round((t_label + t_emit) / frames, 4),
+           "ms_label": round(t_label, 3), "ms_emit": round(t_emit, 3), "ms_end_to_end": round(dt * 1e3, 3),
+           "centres_per_frame": int(np.mean([len(v) for v in d.values()])), "matches_oracle": bool(same),
+           "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000, "unit": "GB/s",
+                        "frac": round(gbps / 8000, 4), "traffic": None},
+           "cpu_baseline": {"value": round(1 / cpu_dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": "2 frames through oracle/locator_oracle.py (scipy.ndimage)"}}
+    print(json.dumps(out), flush=True)
+    return out
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["rvae", "predict"]
     os.makedirs("gpurun_out", exist_ok=True)
     res = {}
     for w in what:
-        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl}[w]()
+        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl, "locate": bench_locate}[w]()
     json.dump(res, open("gpurun_out/bench_extra.json", "w"), indent=1)

@@ -26,13 +26,14 @@ def run(N, H, C0, C1, Cout, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * N * H * H * Cin * Cout * 9 / ms / 1e9 / 157.3
+# forward shapes of the bs-32 U-Net step, then the dgrad-only shapes (Cin/Cout swapped)
 shapes = [(256, 16, 0, 32), (256, 32, 0, 32), (128, 32, 0, 64), (128, 64, 0, 64), (64, 64, 0, 128), (64, 128, 0, 128),
-          (128, 64, 64, 64), (256, 32, 32, 32), (512, 16, 16, 16), (512, 16, 0, 32), (256, 32, 0, 64), (128, 64, 0, 128)]
+          (128, 64, 64, 64), (256, 32, 32, 32), (512, 16, 16, 16), (512, 16, 0, 32), (256, 32, 0, 64), (128, 64, 0, 128),
+          (256, 32, 0, 16), (128, 64, 0, 32), (64, 128, 0, 64)]
 res = {}
-for th in ("8", "4"):
+for th in ("8", "16"):
     for nt in ("1", "2", "4"):
         os.environ["AMX_CONV_TH"] = th; os.environ["AMX_CONV_NT"] = nt
-        if th == "4" and nt == "1": continue
         for sh_ in shapes:
             if int(nt) * 16 > (sh_[3] + 15) // 16 * 16: continue
             ms, fr = run(32, *sh_)
