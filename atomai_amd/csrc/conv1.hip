@@ -21,6 +21,19 @@ __device__ __forceinline__ void sh_push(Sh4& s, const float4 v) {
     d = v.w - s.K.w; s.s1.w += d; s.s2.w = fmaf(d, d, s.s2.w);
 }
 
+// Pixel cursor of a thread that walks p, p + step, p + 2*step, ...: one 64-bit division at the start, then
+// incremental (x, y, image) updates (the per-pixel `p % W`, `p / W % H` cost more than the 36 FMAs of the tap loop).
+struct PixCursor {
+    int xx, yy; long nimg;
+    __device__ __forceinline__ void init(long p, int H, int W) {
+        xx = (int)(p % W); const long r = p / W; yy = (int)(r % H); nimg = r / H;
+    }
+    __device__ __forceinline__ void advance(int step, int H, int W) {
+        xx += step;
+        while (xx >= W) { xx -= W; if (++yy == H) { yy = 0; ++nimg; } }
+    }
+};
+
 // x [N][H][W] (single channel), w OIHW [Cout][1][3][3], y NHWC [P][Cs].
 // Block b owns pixels [b*ppb, (b+1)*ppb); stats row b = (sum, M2 about the row mean) per channel.
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
@@ -54,12 +67,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
     Sh4 st; st.K = make_float4(0, 0, 0, 0); st.s1 = st.K; st.s2 = st.K; st.n = 0.f;
     if (active)
-        for (long p = p0 + pl; p < p1; p += PL) {
-            const int xx = (int)(p % W);
-            const long r = p / W;
-            const int yy = (int)(r % H);
-            const long nimg = r / H;
-            const float* img = x + (size_t)nimg * H * W;
+    {
+        PixCursor cur; cur.init(p0 + pl < npix ? p0 + pl : 0, H, W);
+        for (long p = p0 + pl; p < p1; p += PL, cur.advance(PL, H, W)) {
+            const int xx = cur.xx, yy = cur.yy;
+            const float* img = x + (size_t)cur.nimg * H * W;
             float4 acc = b4;
             #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -74,6 +86,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             amx_st4(y + (size_t)p * Cs + cg * 4, acc);
             sh_push(st, acc);
         }
+    }
     if (!stats) return;
     if (active) {
         const float inv = st.n > 0.f ? 1.f / st.n : 0.f;
@@ -142,12 +155,11 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     float4 c1 = make_float4(1, 1, 1, 1), c2 = make_float4(0, 0, 0, 0), c3 = c2;
     if (active && aux && k1) { c1 = amx_ld4(k1 + cg * 4); c2 = amx_ld4(k2 + cg * 4); c3 = amx_ld4(k3 + cg * 4); }
     if (active)
-        for (long p = p0 + pl; p < p1; p += PL) {
-            const int xx = (int)(p % W);
-            const long r = p / W;
-            const int yy = (int)(r % H);
-            const long nimg = r / H;
-            const float* img = x + (size_t)nimg * H * W;
+    {
+        PixCursor cur; cur.init(p0 + pl < npix ? p0 + pl : 0, H, W);
+        for (long p = p0 + pl; p < p1; p += PL, cur.advance(PL, H, W)) {
+            const int xx = cur.xx, yy = cur.yy;
+            const float* img = x + (size_t)cur.nimg * H * W;
             float4 g = amx_ld4(dpre + (size_t)p * Cs + cg * 4);
             if (aux) {
                 const float4 t = amx_ld4(aux + (size_t)p * Cs + cg * 4);
@@ -166,6 +178,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
                 acc[t].z = fmaf(v, g.z, acc[t].z); acc[t].w = fmaf(v, g.w, acc[t].w);
             }
         }
+    }
     #pragma unroll
     for (int t = 0; t < 10; ++t) {
         if (t >= nrow) break;

@@ -67,22 +67,23 @@ class Act:
         self.grad: Optional[torch.Tensor] = None      # d loss / d (normalised value), NHWC
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
         self.needs_grad = needs_grad
-        self.producer = None                          # ConvNode that wrote `t` (owner of the pending BatchNorm)
-        self.first_consumer = None                    # first node that read this activation in forward order ==
-                                                      # the LAST one to add to `grad` in backward order
+        # No object references from an activation back to graph nodes: node <-> activation cycles would keep
+        # gigabytes of device memory alive until the cyclic garbage collector happens to run (erratic step times).
+        self.producer = False                         # True: written by a ConvNode that owns a pending BatchNorm
+        self.first_consumer = None                    # id() of the first node that read this activation in forward
+                                                      # order == the LAST one to add to `grad` in backward order
         self.bstats = None                            # (rows tensor, rows, stride, column offset): per-block
                                                       # (sum dy, sum dy*a) emitted by that last writer
 
     def consumed_by(self, node) -> None:
         if self.first_consumer is None:
-            self.first_consumer = node
+            self.first_consumer = id(node)            # nodes stay alive in tape.nodes for as long as this is used
 
     def wants_bstats(self, node, training: bool) -> bool:
         """True if `node` writes the final gradient of this activation and its producer needs BN-backward sums."""
-        p = self.producer
         bit = 8 if isinstance(node, ConvNode) else 2
-        return (bool(FUSE & bit) and training and p is not None and p.bn is not None and self.gx is None
-                and self.needs_grad and self.first_consumer is node)
+        return (bool(FUSE & bit) and training and self.producer and self.gx is None
+                and self.needs_grad and self.first_consumer == id(node))
 
     @property
     def npix(self) -> int:
@@ -172,7 +173,7 @@ class ConvNode(_Node):
         for src in self.srcs:
             src.consumed_by(self)
         self.out = self._forward(tape)
-        self.out.producer = self
+        self.out.producer = self.bn is not None
 
     # -------------------------------------------------------------------------------- forward
     def _forward(self, tape) -> Act:
@@ -354,7 +355,13 @@ class ConvNode(_Node):
                 part = _empty((self.rows, 9, cos), a)
                 L.call("amx_conv1_wgrad", L.ptr(x), L.ptr(dpre), L.ptr(part), N, H, W, cos, self.dil,
                        self.rows, self.rows_pix, sp)
-                L.call("amx_wgrad_reduce", L.ptr(part), self.rows, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
+                prows = self.rows
+                if prows > 64:           # thousands of per-block rows: chunk sums first (see colsum)
+                    nch = 32 if prows < 1024 else 128
+                    tmp = _empty((nch, 9 * cos), a)
+                    L.call("amx_reduce_rows_chunked", L.ptr(part), prows, 9 * cos, nch, L.ptr(tmp), sp)
+                    part, prows = tmp, -(-prows // -(-prows // nch))
+                L.call("amx_wgrad_reduce", L.ptr(part), prows, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
             tape.add_param_grad(w, dw)
             return
         s0 = self.srcs[0]
@@ -377,8 +384,9 @@ class ConvNode(_Node):
             db = grad_buffer(self.conv.bias, a)
             L.call("amx_reduce_rows", L.ptr(bpart), bpart.shape[0], co_pad, self.cout, 1.0, L.ptr(db), sp)
             tape.add_param_grad(self.conv.bias, db)
-        if wrows > 64:                   # two-stage: coalesced chunk sums first
-            nch = 32 if wrows < 1024 else 128
+        if wrows > 8:                    # two-stage: coalesced (1 KB per row and block) chunk sums first;
+            #                              the strided 128 B reads of wgrad_reduce are ~10x slower per byte
+            nch = 8 if wrows <= 64 else (32 if wrows < 1024 else 128)
             ncols = self.taps * ci_pad * co_pad
             part2 = _empty((nch, ncols), a)
             L.call("amx_reduce_rows_chunked", L.ptr(part), wrows, ncols, nch, L.ptr(part2), sp)

@@ -66,3 +66,39 @@ def test_segmentor_fit_api(tmp_path):
     assert list(ck["weights"].keys()) == list(m.net.state_dict().keys())
     with pytest.raises(AssertionError):
         aoi.models.Segmentor("Unet", nb_classes=1).fit(X, y, X, y, training_cycles=1, batch_size=2)
+
+
+def test_activations_are_freed_without_the_garbage_collector():
+    """Graph nodes and activations must not form reference cycles: with cycles, every step's activations
+    (gigabytes at the benchmark size) stay allocated until Python's cyclic GC happens to run, and the step time
+    becomes erratic (the caching allocator has to hipMalloc fresh blocks meanwhile)."""
+    import gc
+    import weakref
+    import atomai_amd as aoi
+    from atomai_amd import engine
+    rs = np.random.RandomState(0)
+    net, _ = aoi.nets.init_fcnn_model("Unet", 3, nb_filters=4)
+    x = torch.from_numpy(rs.rand(2, 1, 16, 16).astype(np.float32))
+    made, orig = [], engine.Act.__init__
+
+    def tracking_init(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(weakref.ref(self.t))
+    gc.collect()
+    gc.disable()
+    engine.Act.__init__ = tracking_init
+    try:
+        net.train()
+        y = net(x)
+        y.sum().backward()
+        del y
+        assert len(made) > 10 and sum(r() is not None for r in made) <= 1      # (the module output may linger)
+        made.clear()
+        net.eval()
+        with torch.no_grad():
+            y = net(x)
+        del y
+        assert len(made) > 10 and sum(r() is not None for r in made) == 0
+    finally:
+        engine.Act.__init__ = orig
+        gc.enable()

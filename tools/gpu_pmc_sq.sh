@@ -1,0 +1,7 @@
+#!/bin/bash
+# SQ issue/stall counters for the training step's kernels (one PMC pass, kernel-trace only).
+cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
+cd /tmp
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT --kernel-trace -d /root/repo/gpurun_out/pmc_sq -o pmc --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > /root/repo/gpurun_out/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace -d /root/repo/gpurun_out/pmc_sq2 -o pmc --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > /root/repo/gpurun_out/pmc_sq2.log 2>&1
+cd /root/repo; ls -R gpurun_out/pmc_sq gpurun_out/pmc_sq2 | head; tail -3 gpurun_out/pmc_sq.log; tail -3 gpurun_out/pmc_sq2.log
