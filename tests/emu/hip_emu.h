@@ -59,8 +59,44 @@ struct Wave {
     uint64_t bits[2];
 };
 
+// Fiber context.  On x86-64 a 20-instruction user-space switch (callee-saved registers + MXCSR/x87 CW);
+// glibc's swapcontext makes an rt_sigprocmask system call per switch, which dominated the emulator's run time
+// (an emulated MFMA is a 64-fiber rendezvous).  Other hosts keep ucontext.
+#if defined(__x86_64__)
+struct Ctx { void* sp = nullptr; };
+__attribute__((naked, noinline)) static void ctx_switch(Ctx* /*from: rdi*/, Ctx* /*to: rsi*/) {
+    asm volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "subq $8, %rsp\n\tstmxcsr (%rsp)\n\tfnstcw 4(%rsp)\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq (%rsi), %rsp\n\t"
+        "ldmxcsr (%rsp)\n\tfldcw 4(%rsp)\n\taddq $8, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret\n\t");
+}
+static inline void ctx_make(Ctx& c, char* stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = (reinterpret_cast<uintptr_t>(stack) + bytes) & ~uintptr_t(15);
+    uint64_t* sp = reinterpret_cast<uint64_t*>(top - 16);     // return address slot: entry sees rsp % 16 == 8
+    *sp = reinterpret_cast<uint64_t>(entry);
+    for (int i = 0; i < 6; ++i) *--sp = 0;                    // rbp rbx r12 r13 r14 r15
+    --sp;
+    *reinterpret_cast<uint32_t*>(sp) = 0x1F80u;               // MXCSR default
+    *(reinterpret_cast<uint16_t*>(sp) + 2) = 0x037Fu;         // x87 control word default
+    *(reinterpret_cast<uint16_t*>(sp) + 3) = 0;
+    c.sp = sp;
+}
+#else
+struct Ctx { ucontext_t uc; };
+static inline void ctx_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+static inline void ctx_make(Ctx& c, char* stack, size_t bytes, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack; c.uc.uc_stack.ss_size = bytes; c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     dim3 tid;
     int linear = 0;
     int lane = 0;
@@ -78,20 +114,21 @@ struct Block {
     std::vector<Fiber> fibers;
     std::vector<char> stacks;
     std::vector<char> dyn_smem;
-    ucontext_t sched;
+    Ctx sched;
     Fiber* cur = nullptr;
     std::function<void()> body;
 };
 
 inline Block& blk() { static Block b; return b; }
 
-inline void yield() { Block& B = blk(); swapcontext(&B.cur->ctx, &B.sched); }
+inline void yield() { Block& B = blk(); ctx_switch(&B.cur->ctx, &B.sched); }
 
 inline void trampoline() {
     Block& B = blk();
     B.body();
     B.cur->done = true;
-    swapcontext(&B.cur->ctx, &B.sched);
+    ctx_switch(&B.cur->ctx, &B.sched);
+    abort();                                                  // a finished fiber is never resumed
 }
 
 template <class F>
@@ -115,11 +152,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
             Fiber& fb = B.fibers[t];
             fb.linear = t; fb.lane = t % WAVE; fb.wave = t / WAVE; fb.done = false; fb.my_seq = 0;
             fb.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            getcontext(&fb.ctx);
-            fb.ctx.uc_stack.ss_sp = B.stacks.data() + (size_t)t * STACK_BYTES;
-            fb.ctx.uc_stack.ss_size = STACK_BYTES;
-            fb.ctx.uc_link = nullptr;
-            makecontext(&fb.ctx, (void (*)())trampoline, 0);
+            ctx_make(fb.ctx, B.stacks.data() + (size_t)t * STACK_BYTES, STACK_BYTES, trampoline);
         }
         int remaining = B.nthreads;
         while (remaining > 0) {
@@ -127,7 +160,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, F&& f) {
                 Fiber& fb = B.fibers[t];
                 if (fb.done) continue;
                 B.cur = &fb;
-                swapcontext(&B.sched, &fb.ctx);
+                ctx_switch(&B.sched, &fb.ctx);
                 if (fb.done) --remaining;
             }
         }
