@@ -53,6 +53,7 @@ struct ConvFwdArgs {
     int cout;            // real number of output channels
     int cop;             // cout rounded up to 16
     int nchunk;
+    int tail_kg;         // valid 4-channel k-groups in the LAST chunk (1..KG; KG == the chunk is full)
     int dil;             // dilation (== halo) for 9 taps; ignored for 1 tap
     float slope;         // LeakyReLU negative slope; 1.0f == no activation
     int tiles_x, tiles_y;
@@ -202,6 +203,37 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
     };
 
+    // Last chunk with fewer than KG valid k-groups (channel counts that are not multiples of 16, e.g. dilnet's
+    // 25 / 50 filters -> 28 / 52 stored channels): one MFMA per valid k-group and tap instead of four, with the
+    // k index of the MFMA running over the 4 channels of ONE k-group (scalar ds_read_b32, lane g = channel g).
+    auto compute_tail = [&](int nkg) {
+        const float* s_in = smem;
+        const float* s_w = s_in + KG * plane * 4;
+        #pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            #pragma unroll
+            for (int j = 0; j < KG - 1; ++j) {
+                if (j >= nkg) break;
+                float af[MTW], bf[NT];
+                #pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
+                    af[m] = s_in[((size_t)j * plane + slot) * 4 + g];
+                }
+                #pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    bf[q] = s_w[((size_t)(tap * KG + j) * NB + q * 16 + p) * 4 + g];
+                #pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    #pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[q], acc[m][q], 0, 0, 0);
+            }
+        }
+    };
+
     issue_loads(0);
     if (DBUF) {
         // Software pipeline over two LDS stages: the global loads of chunk c+1 are issued before, and their
@@ -223,7 +255,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             stage_to_lds(0);
             __syncthreads();
             if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
-            compute_taps(0, 0, TAPS);
+            if (chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
+            else compute_taps(0, 0, TAPS);
             __syncthreads();
         }
     }
@@ -409,6 +442,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.cout = cout;
     a.cop = amx_round_up(cout, 16);
     a.nchunk = amx_ceil_div(C0s + C1s, 4 * KG);
+    a.tail_kg = (C0s + C1s - (a.nchunk - 1) * 4 * KG) / 4;
     a.dil = dil; a.slope = slope;
     if (Y0s + Y1s < cout) AMX_BADARG(8);
     hipStream_t s = (hipStream_t)stream;
@@ -435,6 +469,18 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
         if (nt == 1) CONV_GO(9, 1, 1, 4);
         if (nt == 2) CONV_GO(9, 2, 1, 4);
         CONV_GO(9, 4, 1, 4);
+    }
+    // dilated 3x3: the halo bound sizes the prefetch registers and the LDS image, so one instantiation per
+    // dilation class (2, 3-4, 5-6) keeps the light dilations at a higher occupancy
+    if (dil <= 2) {
+        if (nt == 1) CONV_GO(9, 1, 2, 4);
+        if (nt == 2) CONV_GO(9, 2, 2, 4);
+        CONV_GO(9, 4, 2, 4);
+    }
+    if (dil <= 4) {
+        if (nt == 1) CONV_GO(9, 1, 4, 4);
+        if (nt == 2) CONV_GO(9, 2, 4, 4);
+        CONV_GO(9, 4, 4, 4);
     }
     if (nt == 1) CONV_GO(9, 1, 6, 4);
     if (nt == 2) CONV_GO(9, 2, 6, 4);

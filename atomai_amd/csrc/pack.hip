@@ -123,3 +123,22 @@ extern "C" int amx_add_inplace(float* dst, const float* src, long n, void* strea
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// y = (x - sub) / div : torch_format_image's global min-max normalisation (atomai/utils/preproc.py:818-823,
+// `(image_data - image_data.min()) / np.ptp(image_data)`) applied to a chunk that is already on the device.
+// Two correctly rounded fp32 operations, exactly what numpy performs on a float32 stack (bit-identical result).
+__global__ void sub_div_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float sub, float div) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = x[i] - sub;
+        y[i] = d / div;
+    }
+}
+
+extern "C" int amx_sub_div(const float* x, float* y, long n, float sub, float div, void* stream) {
+    if (!x || !y || n <= 0) AMX_BADARG(1);
+    const size_t nn = (size_t)n;
+    const int blocks = (int)((nn + 255) / 256 < 16384 ? (nn + 255) / 256 : 16384);
+    AMX_LAUNCH(sub_div_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, nn, sub, div);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

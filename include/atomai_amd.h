@@ -73,6 +73,9 @@ long amx_pack_weights_size(int cout, int C0s, int C1s, int taps, int mode);
 int amx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
 int amx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
 int amx_add_inplace(float* dst, const float* src, long n, void* stream);
+/* y = (x - sub) / div: the global min-max normalisation of torch_format_image (utils/preproc.py:798-825) for a
+ * chunk already on the device (two correctly rounded fp32 ops = numpy's float32 arithmetic) */
+int amx_sub_div(const float* x, float* y, long n, float sub, float div, void* stream);
 
 /* ---- BatchNorm2d after LeakyReLU (blocks.py:71-75; torch defaults eps 1e-5, momentum 0.1) */
 int amx_bn_finalize(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,

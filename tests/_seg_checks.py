@@ -136,3 +136,12 @@ def check_predict(device_is_gpu):
         probs = p.run(img, compute_coords=False, num_batches=2)
         assert probs.shape == g[f"{model}|probs"].shape
         np.testing.assert_allclose(probs, g[f"{model}|probs"], rtol=REL_TOL, atol=1e-6)
+        # float32 stack that needs no padding: normalisation happens on the device after the upload and must be
+        # bit-identical to the reference's numpy float32 `(x - min) / ptp` done on the host
+        sub = np.ascontiguousarray(img[:, :8, :16])
+        probs_dev = p.run(sub, compute_coords=False)
+        assert p._norm is not None
+        x_host = torch_format_image(sub.copy())
+        p._norm = None
+        probs_host = p.batch_predict(x_host, probs_dev.shape, 1).numpy()
+        assert np.array_equal(probs_dev, probs_host)
