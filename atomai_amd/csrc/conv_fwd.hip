@@ -35,6 +35,8 @@
 struct ConvFwdArgs {
     const float* x0; const float* sc0; const float* sh0; int C0s;
     const float* x1; const float* sc1; const float* sh1; int C1s;
+    float in_slope0, in_slope1;   // LeakyReLU applied AFTER the on-load affine of source 0 / 1 (1.0f == none):
+                                  // ResBlock's conv -> BatchNorm -> LeakyReLU order (atomai/nets/blocks.py:205-208)
     const float* wpk;    // [nchunk][taps][KG][cop][4]
     const float* bias;   // [cout] or nullptr
     const float* addend; // optional tensor (same shape as y) added to the first output, or nullptr
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     float4 xr[XLD];
     float4 wr[WLD];
     float4 r_sc, r_sh, r_k3;
+    float r_islope = 1.f;                                        // post-affine LeakyReLU slope of this thread's source
     int r_ch = -1;                                               // FUSED: channel of this thread's group in src0
 
     auto issue_loads = [&](int chunk) {
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
         r_k3 = r_sh;
         if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
+        r_islope = src == a.x1 ? a.in_slope1 : a.in_slope0;
         if (FUSED) {
             r_ch = src == a.x0 ? c : -1;
             if (r_ch >= 0 && a.k1) { r_sc = amx_ld4(a.k1 + c); r_sh = amx_ld4(a.k2 + c); r_k3 = amx_ld4(a.k3 + c); }
@@ -158,6 +162,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
                 } else if (x_off[i] >= 0) {                      // padding stays exactly zero
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
                     v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                    if (r_islope != 1.f) {
+                        v.x = v.x > 0.f ? v.x : v.x * r_islope; v.y = v.y > 0.f ? v.y : v.y * r_islope;
+                        v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
+                    }
                 }
                 amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
             }
@@ -421,7 +429,8 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
                          float* y, int Y0s, float* y1, int Y1s, float* stats,
                          int N, int H, int W, int cout, int taps, int dil, float slope,
                          const float* aux0, const float* k1, const float* k2, const float* k3, float bslope,
-                         const float* ea0, const float* ea1, float* bstats, void* stream) {
+                         const float* ea0, const float* ea1, float* bstats, void* stream,
+                         float in_slope0 = 1.f, float in_slope1 = 1.f) {
     if (!x0 || !wpk || !y) AMX_BADARG(1);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
     if ((C0s & 3) || (C1s & 3) || (Y0s & 3) || (Y1s & 3) || C0s <= 0) AMX_BADARG(3);
@@ -432,6 +441,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     ConvFwdArgs a;
     a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
+    a.in_slope0 = in_slope0; a.in_slope1 = in_slope1;
     a.wpk = wpk; a.bias = bias; a.addend = addend;
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
     a.aux0 = aux0; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.bslope = bslope;
@@ -497,6 +507,19 @@ extern "C" int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh
     return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, addend, y, Y0s, y1, Y1s, stats, N, H, W,
                          cout, taps, dil, slope, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr, nullptr,
                          stream);
+}
+
+// amx_conv2d_fwd with a LeakyReLU applied after the on-load BatchNorm affine of each source (1.0f == none):
+// the conv -> BatchNorm -> LeakyReLU order of ResBlock (atomai/nets/blocks.py:199-214).
+extern "C" int amx_conv2d_fwd_act(const float* x0, const float* sc0, const float* sh0, float in_slope0, int C0s,
+                                  const float* x1, const float* sc1, const float* sh1, float in_slope1, int C1s,
+                                  const float* wpk, const float* bias, const float* addend,
+                                  float* y, int Y0s, float* y1, int Y1s, float* stats,
+                                  int N, int H, int W, int cout, int taps, int dil, float slope, void* stream) {
+    if (!(in_slope0 > 0.f) || !(in_slope1 > 0.f)) AMX_BADARG(11);
+    return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, addend, y, Y0s, y1, Y1s, stats, N, H, W,
+                         cout, taps, dil, slope, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, nullptr, nullptr,
+                         stream, in_slope0, in_slope1);
 }
 
 // Data gradient with the BatchNorm/LeakyReLU backward of the layer fused into the loader (dy, a -> dpre) and the

@@ -21,6 +21,7 @@
 struct WgradArgs {
     const float* x0; const float* sc0; const float* sh0; int C0s;
     const float* x1; const float* sc1; const float* sh1; int C1s;
+    float in_slope0, in_slope1;      // LeakyReLU after the on-load affine of source 0 / 1 (1.0f == none)
     const float* dpre; int Dos;      // stored channels of dpre (or of dy when aux != nullptr)
     const float* aux;                // activation a: dpre = lrelu'(a) * (k1*dy + k2*a + k3) formed while loading
     const float* k1; const float* k2; const float* k3; float bslope;
@@ -64,8 +65,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const int ch = ci0 + xg * 4;
     const float* xsrc = nullptr; int xCs = 0, xc = 0;
     float4 r_sc = make_float4(1, 1, 1, 1), r_sh = make_float4(0, 0, 0, 0);
-    if (ch < a.C0s) { xsrc = a.x0; xCs = a.C0s; xc = ch; if (a.sc0) { r_sc = amx_ld4(a.sc0 + xc); r_sh = amx_ld4(a.sh0 + xc); } }
-    else if (ch - a.C0s < a.C1s) { xsrc = a.x1; xCs = a.C1s; xc = ch - a.C0s; if (a.sc1) { r_sc = amx_ld4(a.sc1 + xc); r_sh = amx_ld4(a.sh1 + xc); } }
+    float r_islope = 1.f;
+    if (ch < a.C0s) { xsrc = a.x0; xCs = a.C0s; xc = ch; r_islope = a.in_slope0; if (a.sc0) { r_sc = amx_ld4(a.sc0 + xc); r_sh = amx_ld4(a.sh0 + xc); } }
+    else if (ch - a.C0s < a.C1s) { xsrc = a.x1; xCs = a.C1s; xc = ch - a.C0s; r_islope = a.in_slope1; if (a.sc1) { r_sc = amx_ld4(a.sc1 + xc); r_sh = amx_ld4(a.sh1 + xc); } }
     const int npix_x = IH * IW;
     const int nd4 = TH * TW * DG;                                 // float4 loads of the dpre tile
     constexpr int DLD_MAX = (TH * TW * 16 + 255) / 256;           // COB <= 64 -> DG <= 16
@@ -122,6 +124,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 if (xvalid & (1u << i)) {
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
                     v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                    if (r_islope != 1.f) {
+                        v.x = v.x > 0.f ? v.x : v.x * r_islope; v.y = v.y > 0.f ? v.y : v.y * r_islope;
+                        v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
+                    }
                 }
                 amx_st4(s_x + (size_t)pix * SX + xg * 4, v);
             }
@@ -292,7 +298,7 @@ static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int
                         const float* x1, const float* sc1, const float* sh1, int C1s,
                         const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
                         int taps, int dil, const float* aux, const float* k1, const float* k2, const float* k3,
-                        float bslope, float* bpart, void* stream);
+                        float bslope, float* bpart, void* stream, float in_slope0 = 1.f, float in_slope1 = 1.f);
 
 extern "C" int amx_conv2d_wgrad(const float* x0, const float* sc0, const float* sh0, int C0s,
                                 const float* x1, const float* sc1, const float* sh1, int C1s,
@@ -313,13 +319,24 @@ extern "C" int amx_conv2d_wgrad_fused(const float* x0, const float* sc0, const f
                         k3, bslope, bpart, stream);
 }
 
+// amx_conv2d_wgrad_fused for a layer whose input is read as LeakyReLU(affine(x)) (ResBlock's second conv)
+extern "C" int amx_conv2d_wgrad_act(const float* x0, const float* sc0, const float* sh0, float in_slope0, int C0s,
+                                    const float* x1, const float* sc1, const float* sh1, float in_slope1, int C1s,
+                                    const float* dy, const float* aux, const float* k1, const float* k2,
+                                    const float* k3, float bslope, int Dos, float* part, float* bpart,
+                                    int N, int H, int W, int cout, int taps, int dil, void* stream) {
+    if (!(in_slope0 > 0.f) || !(in_slope1 > 0.f)) AMX_BADARG(8);
+    return wgrad_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, dy, Dos, part, N, H, W, cout, taps, dil, aux, k1, k2,
+                        k3, bslope, bpart, stream, in_slope0, in_slope1);
+}
+
 extern "C" int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 
 static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int C0s,
                         const float* x1, const float* sc1, const float* sh1, int C1s,
                         const float* dpre, int Dos, float* part, int N, int H, int W, int cout,
                         int taps, int dil, const float* aux, const float* k1, const float* k2, const float* k3,
-                        float bslope, float* bpart, void* stream) {
+                        float bslope, float* bpart, void* stream, float in_slope0, float in_slope1) {
     if (!x0 || !dpre || !part) AMX_BADARG(1);
     if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(7);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
@@ -331,6 +348,7 @@ static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int
     WgradArgs a;
     a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
+    a.in_slope0 = in_slope0; a.in_slope1 = in_slope1;
     a.dpre = dpre; a.Dos = Dos; a.part = part;
     a.aux = aux; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.bslope = bslope; a.bpart = bpart;
     a.N = N; a.H = H; a.W = W; a.dil = dil;

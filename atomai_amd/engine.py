@@ -57,14 +57,16 @@ class Act:
     """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
     per-channel affine of the producing BatchNorm (None == identity)."""
     __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad", "producer",
-                 "first_consumer", "bstats")
+                 "first_consumer", "bstats", "post_slope")
 
     def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
         self.t = t
         self.N, self.H, self.W, self.Cs = t.shape
         self.C = C
         self.scale, self.shift = scale, shift
-        self.grad: Optional[torch.Tensor] = None      # d loss / d (normalised value), NHWC
+        self.post_slope = 1.0                         # LeakyReLU applied by the consumer AFTER the pending affine
+                                                      # (ResBlock's conv -> BN -> activation order); 1.0 = none
+        self.grad: Optional[torch.Tensor] = None      # d loss / d (value the consumers see), NHWC
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
         self.needs_grad = needs_grad
         # No object references from an activation back to graph nodes: node <-> activation cycles would keep
@@ -155,9 +157,15 @@ class _Node:
 class ConvNode(_Node):
     """conv (3x3 / dilated / 1x1) [+bias] [+LeakyReLU] [+BatchNorm statistics] over 1 or 2 sources."""
 
-    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None):
+    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None, post_slope: float = 1.0):
         self.srcs = list(srcs)
         self.conv, self.bn, self.slope = conv, bn, float(slope)
+        # activation AFTER the BatchNorm (ResBlock): without a BatchNorm it is simply the epilogue activation
+        self.post_slope = float(post_slope)
+        if self.post_slope != 1.0 and bn is None:
+            assert self.slope == 1.0
+            self.slope, self.post_slope = self.post_slope, 1.0
+        assert self.post_slope == 1.0 or self.slope == 1.0, "one activation per layer"
         self.x_plain = x_plain                           # (N,1,H,W) tensor for the Cin==1 kernel
         w = conv.weight
         self.cout = w.shape[0]
@@ -173,7 +181,8 @@ class ConvNode(_Node):
         for src in self.srcs:
             src.consumed_by(self)
         self.out = self._forward(tape)
-        self.out.producer = self.bn is not None
+        self.out.post_slope = self.post_slope
+        self.out.producer = self.bn is not None and self.post_slope == 1.0
 
     # -------------------------------------------------------------------------------- forward
     def _forward(self, tape) -> Act:
@@ -206,11 +215,19 @@ class ConvNode(_Node):
             self.rows = L.load().amx_conv2d_num_tiles(N, H, W, th)
             self.rows_pix = th                               # mode 0: the conv tile height
             stats = _empty((self.rows, 2, cop), s0.t) if training_bn else None
-            L.call("amx_conv2d_fwd", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
-                   L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
-                   L.ptr(s1.shift if s1 else None), C1s, L.ptr(wpk), L.ptr(bias), None,
-                   L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
-                   self.slope, _sp(y))
+            ps0, ps1 = s0.post_slope, (s1.post_slope if s1 else 1.0)
+            if ps0 != 1.0 or ps1 != 1.0:
+                L.call("amx_conv2d_fwd_act", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), ps0, C0s,
+                       L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+                       L.ptr(s1.shift if s1 else None), ps1, C1s, L.ptr(wpk), L.ptr(bias), None,
+                       L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
+                       self.slope, _sp(y))
+            else:
+                L.call("amx_conv2d_fwd", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+                       L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+                       L.ptr(s1.shift if s1 else None), C1s, L.ptr(wpk), L.ptr(bias), None,
+                       L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
+                       self.slope, _sp(y))
             stat_mode = 0
         scale = shift = None
         if self.bn is not None:
@@ -256,6 +273,14 @@ class ConvNode(_Node):
         has_bias = self.conv.bias is not None
         if self.bn is not None and not tape.training:
             raise L.AmxError("backward through eval-mode BatchNorm is not on the hot path")
+        if self.post_slope != 1.0:
+            # consumers saw LeakyReLU(scale*a + shift): first back through that activation, then the usual
+            # BatchNorm backward (with an identity epilogue activation, self.slope == 1)
+            assert out.gx is None
+            masked = _empty(a.shape, a)
+            L.call("amx_lrelu_bwd", L.ptr(dy), L.ptr(a), L.ptr(out.scale), L.ptr(out.shift), self.post_slope,
+                   npix, cos, L.ptr(masked), None, sp)
+            dy = masked
         fused = out.gx is None and bool(FUSE & 5)
         k = None
         aux = None
@@ -376,10 +401,19 @@ class ConvNode(_Node):
         if want_bias:
             ks = L.load().amx_conv2d_wgrad_ksplit(N, H, W, C0s + C1s, self.cout, self.taps, self.dil)
             bpart = _empty((ks, co_pad), a)
-        L.call("amx_conv2d_wgrad_fused", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
-               L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
-               L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
-               self.slope, cos, L.ptr(part), L.ptr(bpart), N, H, W, self.cout, self.taps, self.dil, sp)
+        ps0, ps1 = s0.post_slope, (s1.post_slope if s1 else 1.0)
+        if ps0 != 1.0 or ps1 != 1.0:
+            L.call("amx_conv2d_wgrad_act", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), ps0, C0s,
+                   L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+                   L.ptr(s1.shift if s1 else None), ps1, C1s, L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2),
+                   L.ptr(k3), self.slope, cos, L.ptr(part), L.ptr(bpart), N, H, W, self.cout, self.taps,
+                   self.dil, sp)
+        else:
+            L.call("amx_conv2d_wgrad_fused", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+                   L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None),
+                   L.ptr(s1.shift if s1 else None), C1s, L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2),
+                   L.ptr(k3), self.slope, cos, L.ptr(part), L.ptr(bpart), N, H, W, self.cout, self.taps,
+                   self.dil, sp)
         if bpart is not None:
             db = grad_buffer(self.conv.bias, a)
             L.call("amx_reduce_rows", L.ptr(bpart), bpart.shape[0], co_pad, self.cout, 1.0, L.ptr(db), sp)
@@ -439,6 +473,39 @@ class ConvNode(_Node):
                L.ptr(bstats), N, H, W, self.taps, self.dil, sp)
         if scratch is not None:
             L.call("amx_add_inplace", L.ptr(tgt[1][0]), L.ptr(scratch), scratch.numel(), sp)
+
+
+class ResOutNode(_Node):
+    """Tail of a ResBlock (atomai/nets/blocks.py:210-213): out = LeakyReLU(bn2(t) + r), materialised.
+    ``t`` carries bn2 as its pending affine; ``r`` is the block's c0 output (plain tensor)."""
+
+    def __init__(self, tape, t: Act, r: Act, slope: float):
+        assert t.post_slope == 1.0 and r.post_slope == 1.0 and r.scale is None
+        assert t.t.shape == r.t.shape
+        self.t_act, self.r_act, self.slope = t, r, float(slope)
+        t.consumed_by(self)
+        r.consumed_by(self)
+        y = _empty(t.t.shape, t.t)
+        L.call("amx_res_out_fwd", L.ptr(t.t), L.ptr(t.scale), L.ptr(t.shift), L.ptr(r.t), self.slope, t.npix, t.Cs,
+               L.ptr(y), _sp(y))
+        self.out = Act(y, t.C, needs_grad=tape.need_grad)
+
+    def backward(self, tape) -> None:
+        g = self.out.grad
+        if g is None:
+            return
+        t, r = self.t_act, self.r_act
+        ds = _empty(g.shape, g)
+        # the convolution branch gets its own copy when its producer forwards the gradient tensor unchanged to a
+        # weight-gradient kernel on the side stream (no BatchNorm in between) while the residual branch keeps
+        # accumulating into it
+        alias_unsafe = not t.producer
+        ds2 = _empty(g.shape, g) if (alias_unsafe and r.needs_grad) else None
+        L.call("amx_lrelu_bwd", L.ptr(g), L.ptr(self.out.t), None, None, self.slope, t.npix, t.Cs, L.ptr(ds),
+               L.ptr(ds2), _sp(g))
+        tape.accumulate(t, ds)
+        if r.needs_grad:
+            tape.accumulate(r, ds2 if ds2 is not None else ds)
 
 
 class PoolNode(_Node):
@@ -659,8 +726,11 @@ class Tape:
     def input(self, x: torch.Tensor) -> InputNode:
         return self._push(InputNode(self, x))
 
-    def conv(self, srcs, conv, bn=None, slope: float = 1.0) -> Act:
-        return self._push(ConvNode(self, srcs, conv, bn, slope)).out
+    def conv(self, srcs, conv, bn=None, slope: float = 1.0, post_slope: float = 1.0) -> Act:
+        return self._push(ConvNode(self, srcs, conv, bn, slope, post_slope=post_slope)).out
+
+    def res_out(self, t: Act, r: Act, slope: float) -> Act:
+        return self._push(ResOutNode(self, t, r, slope)).out
 
     def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0) -> Act:
         return self._push(ConvNode(self, [], conv, bn, slope, x_plain=x_plain.detach().contiguous())).out

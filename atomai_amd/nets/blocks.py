@@ -164,3 +164,55 @@ class DilatedBlock(_HipBlock):
             acts.append(a)
             srcs = [a]
         return tape.dilated_sum(acts, slope)
+
+
+class ResBlock(_HipBlock):
+    """Residual block (reference: atomai/nets/blocks.py:135-214): x = c0(x) [1x1]; out = c1(x) -> bn1 -> LeakyReLU
+    -> c2 -> bn2; out += x; LeakyReLU(out).  BatchNorm sits BEFORE the activation here, so bn1's affine and the
+    activation are applied by c2's loader and bn2's affine by the residual kernel."""
+
+    def __init__(self, ndim: int, input_channels: int, output_channels: int,
+                 kernel_size: Union[Tuple[int], int] = 3, stride: Union[Tuple[int], int] = 1,
+                 padding: Union[Tuple[int], int] = 1, batch_norm: bool = True, lrelu_a: float = 0.01) -> None:
+        super().__init__()
+        if not 0 < ndim < 3:
+            raise AssertionError("ndim must be equal to 1 or 2")
+        if ndim == 1:
+            raise NotImplementedError("1-D ResBlock (ImSpec family) is outside the MI355X hot path")
+        self.lrelu_a = lrelu_a
+        self.batch_norm = batch_norm
+        self.c0 = nn.Conv2d(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
+        self.c1 = nn.Conv2d(output_channels, output_channels, kernel_size=3, stride=1, padding=1)
+        self.c2 = nn.Conv2d(output_channels, output_channels, kernel_size=3, stride=1, padding=1)
+        if batch_norm:
+            self.bn1 = nn.BatchNorm2d(output_channels)
+            self.bn2 = nn.BatchNorm2d(output_channels)
+
+    def _emit(self, tape, srcs):
+        bn1 = self.bn1 if self.batch_norm else None
+        bn2 = self.bn2 if self.batch_norm else None
+        x0 = tape.conv(srcs, self.c0, None, 1.0)
+        h1 = tape.conv([x0], self.c1, bn1, 1.0, post_slope=self.lrelu_a)
+        t2 = tape.conv([h1], self.c2, bn2, 1.0)
+        return tape.res_out(t2, x0, self.lrelu_a)
+
+
+class ResModule(_HipBlock):
+    """``res_depth`` residual blocks in sequence (reference: atomai/nets/blocks.py:217-254)."""
+
+    def __init__(self, ndim: int, res_depth: int, input_channels: int, output_channels: int,
+                 batch_norm: bool = True, lrelu_a: float = 0.01) -> None:
+        super().__init__()
+        res_module = []
+        for i in range(res_depth):
+            input_channels = output_channels if i > 0 else input_channels
+            res_module.append(ResBlock(ndim, input_channels, output_channels, lrelu_a=lrelu_a,
+                                       batch_norm=batch_norm))
+        self.res_module = nn.Sequential(*res_module)
+
+    def _emit(self, tape, srcs):
+        act = None
+        for blk in self.res_module:
+            act = blk._emit(tape, srcs)
+            srcs = [act]
+        return act

@@ -4,7 +4,7 @@ from typing import List, Type, Union
 import torch
 import torch.nn as nn
 
-from .blocks import ConvBlock, DilatedBlock, UpsampleBlock
+from .blocks import ConvBlock, DilatedBlock, ResModule, UpsampleBlock
 from ._function import run_tape
 
 
@@ -130,6 +130,48 @@ class dilnet(_HipNet):
         return self.px(self.c2(torch.cat([c1, u1], dim=1)))
 
 
+class SegResNet(_HipNet):
+    """SegNet-like net with residual blocks: c1-pool-c2(res)-pool-bn(res)-up1-cat-c3(res)-up2-cat-c4-px
+    (reference: atomai/nets/fcnn.py:297-376)."""
+
+    def __init__(self, nb_classes: int = 1, nb_filters: int = 32, batch_norm: bool = True,
+                 upsampling_mode: str = "bilinear", **kwargs: List[int]) -> None:
+        super().__init__()
+        nbl = kwargs.get("layers", [2, 2, 2])
+        self.c1 = ConvBlock(2, 1, 1, nb_filters, batch_norm=batch_norm)
+        self.c2 = ResModule(2, nbl[0], nb_filters, nb_filters * 2, batch_norm=batch_norm)
+        self.bn = ResModule(2, nbl[1], nb_filters * 2, nb_filters * 4, batch_norm=batch_norm)
+        self.upsample_block1 = UpsampleBlock(2, nb_filters * 4, nb_filters * 2, 2, upsampling_mode)
+        self.c3 = ResModule(2, nbl[2], nb_filters * 4, nb_filters * 2, batch_norm=batch_norm)
+        self.upsample_block2 = UpsampleBlock(2, nb_filters * 2, nb_filters, 2, upsampling_mode)
+        self.c4 = ConvBlock(2, 1, nb_filters * 2, nb_filters, batch_norm=batch_norm)
+        self.px = nn.Conv2d(nb_filters, nb_classes, 1, 1, 0)
+
+    def _build(self, tape, x, px_mode: int = 0):
+        if x.shape[2] % 4 or x.shape[3] % 4:
+            raise AssertionError("SegResNet needs H and W divisible by 4 (two 2x2 poolings); "
+                                 "SegPredictor pads inputs accordingly")
+        node, c1 = self.c1._emit_input(tape, x)
+        d1 = tape.pool(c1)
+        c2 = self.c2._emit(tape, [d1])
+        d2 = tape.pool(c2)
+        bn = self.bn._emit(tape, [d2])
+        u2 = self.upsample_block1._emit(tape, [bn])
+        u2 = self.c3._emit(tape, [c2, u2])
+        u1 = self.upsample_block2._emit(tape, [u2])
+        u1 = self.c4._emit(tape, [c1, u1])
+        return node, tape.px(u1, self.px, px_mode)
+
+    def _modular(self, x):
+        import torch.nn.functional as F
+        c1 = self.c1(x)
+        c2 = self.c2(F.max_pool2d(c1, 2, 2))
+        bn = self.bn(F.max_pool2d(c2, 2, 2))
+        u2 = self.c3(torch.cat([c2, self.upsample_block1(bn)], dim=1))
+        u1 = self.c4(torch.cat([c1, self.upsample_block2(u2)], dim=1))
+        return self.px(u1)
+
+
 def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwargs):
     """Factory + meta_state_dict, same keys as the reference (fcnn.py:379-442)."""
     if not isinstance(model, str) and hasattr(model, "state_dict"):
@@ -150,12 +192,18 @@ def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwarg
         nb_filters = kwargs.get('nb_filters', 25)
         layers = kwargs.get("layers", [1, 3, 3, 1])
         net = dilnet(nb_classes, nb_filters, dropout, batch_norm, upsampling, layers=layers)
-    elif isinstance(model, str) and model in ('SegResNet', 'ResHedNet'):
-        raise NotImplementedError(f"'{model}' is outside the MI355X hot path of this build "
-                                  "(SURVEY.md §8-f rank 4); use 'Unet' or 'dilnet'")
+    elif isinstance(model, str) and model == 'SegResNet':
+        nb_filters = kwargs.get('nb_filters', 32)
+        layers = kwargs.get("layers", [2, 2, 2])
+        net = SegResNet(nb_classes, nb_filters, batch_norm, upsampling, layers=layers)
+    elif isinstance(model, str) and model == 'ResHedNet':
+        raise NotImplementedError("'ResHedNet' (x4 interpolated side outputs) is outside the MI355X hot path "
+                                  "of this build; use 'Unet', 'dilnet' or 'SegResNet'")
     else:
         raise NotImplementedError(
             "Currently implemented models are 'Unet', 'dilnet', SegResNet', and 'ResHedNet'")
+    if model in ["ResHedNet", "SegResNet"]:
+        meta_state_dict["dropout"] = None
     meta_state_dict["nb_filters"] = nb_filters
     meta_state_dict["layers"] = layers
     return net, meta_state_dict

@@ -51,6 +51,24 @@ int amx_conv2d_wgrad_fused(const float* x0, const float* sc0, const float* sh0, 
                            const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
                            float bslope, int Dos, float* part, float* bpart, int N, int H, int W, int cout,
                            int taps, int dil, void* stream);
+/* ResBlock (atomai/nets/blocks.py:135-214: conv -> BatchNorm -> LeakyReLU, residual add): the forward conv and the
+ * weight gradient with a LeakyReLU applied after the on-load BatchNorm affine of each source (slope 1.0f = none) */
+int amx_conv2d_fwd_act(const float* x0, const float* sc0, const float* sh0, float in_slope0, int C0s,
+                       const float* x1, const float* sc1, const float* sh1, float in_slope1, int C1s,
+                       const float* wpk, const float* bias, const float* addend,
+                       float* y, int Y0s, float* y1, int Y1s, float* stats,
+                       int N, int H, int W, int cout, int taps, int dil, float slope, void* stream);
+int amx_conv2d_wgrad_act(const float* x0, const float* sc0, const float* sh0, float in_slope0, int C0s,
+                         const float* x1, const float* sc1, const float* sh1, float in_slope1, int C1s,
+                         const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
+                         float bslope, int Dos, float* part, float* bpart, int N, int H, int W, int cout,
+                         int taps, int dil, void* stream);
+/* out = LeakyReLU(t*scale + shift + r)  (bn2 affine + residual add + activation, blocks.py:210-213), and
+ * din = dout * LeakyReLU'(ref*scale + shift)  (scale == NULL: the sign of ref itself); din2 = optional copy */
+int amx_res_out_fwd(const float* t, const float* scale, const float* shift, const float* r, float slope,
+                    long npix, int Cs, float* out, void* stream);
+int amx_lrelu_bwd(const float* dout, const float* ref, const float* scale, const float* shift, float slope,
+                  long npix, int Cs, float* din, float* din2, void* stream);
 int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,

@@ -79,11 +79,18 @@ def _seg_case(aoi, name, model, nb_classes, nb_filters, B, H, seed, upsampling="
     print(name, "losses f32", out["losses|f32"], "f64", out["losses|f64"])
 
 
+def make_seg_res(aoi):
+    """SegResNet: residual blocks with BatchNorm BEFORE the activation."""
+    _seg_case(aoi, "seg_segresnet_c3_nf4_b2_32", "SegResNet", 3, 4, 2, 32, 1)
+    _seg_case(aoi, "seg_segresnet_c1_nf4_b2_16_nearest", "SegResNet", 1, 4, 2, 16, 3, upsampling="nearest")
+
+
 def make_seg(aoi):
     _seg_case(aoi, "seg_unet_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1)
     _seg_case(aoi, "seg_unet_c1_nf4_b2_16_nearest", "Unet", 1, 4, 2, 16, 2, upsampling="nearest")
     _seg_case(aoi, "seg_unet_dil_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1, with_dilation=True)
     _seg_case(aoi, "seg_dilnet_c1_nf5_b2_32", "dilnet", 1, 5, 2, 32, 1)
+    make_seg_res(aoi)
     # default-width nets: pin the RNG-order initialisation by per-tensor moments only
     from atomai.nets import init_fcnn_model
     from atomai.utils import set_train_rng
@@ -365,5 +372,5 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res}[w](aoi)
     print("done ->", GOLD)

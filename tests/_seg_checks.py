@@ -15,6 +15,8 @@ CASES = {
     "seg_unet_c1_nf4_b2_16_nearest": ("Unet", dict(upsampling="nearest")),
     "seg_unet_dil_c3_nf4_b2_32": ("Unet", dict(with_dilation=True)),
     "seg_dilnet_c1_nf5_b2_32": ("dilnet", dict()),
+    "seg_segresnet_c3_nf4_b2_32": ("SegResNet", dict()),
+    "seg_segresnet_c1_nf4_b2_16_nearest": ("SegResNet", dict(upsampling="nearest")),
 }
 REL_TOL = 1e-4          # north_star: "within 1e-4 rel fp32"
 
@@ -75,6 +77,35 @@ def check_net_case(name, device):
         ev = net(x).cpu().numpy()
     ref = g["eval_logits|f32"]
     assert relmax(ev, ref.astype(np.float64)) < 2e-2        # parameters after Adam steps: loose
+
+
+def check_vs_oracle_small(model, ncls, device, nf=4, B=2, H=16, seed=5, **kw):
+    """Configurations without a reference golden (e.g. batch_norm=False): logits, loss and every gradient against
+    the pinned oracle evaluated in fp64 on the CPU."""
+    from oracle import seg_oracle as so
+    from atomai_amd.nets import init_fcnn_model
+    from atomai_amd.losses_metrics import select_loss
+    torch.manual_seed(seed)
+    net, _ = init_fcnn_model(model, ncls, nb_filters=nf, **kw)
+    sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.rand(B, 1, H, H).astype(np.float32))
+    y = (torch.from_numpy(rs.randint(0, ncls, (B, H, H))) if ncls > 1
+         else torch.from_numpy((rs.rand(B, 1, H, H) > 0.5).astype(np.float32)))
+    okw = {("upsampling" if k == "upsampling" else k): v for k, v in kw.items()}
+    assert so.min_abs_preactivation(model, sd, x, **okw) > 1e-5      # inputs clear of the LeakyReLU kink
+    net.to(device).train()
+    logits = net(x.to(device))
+    loss = select_loss("ce", ncls)(logits, y.to(device))
+    loss.backward()
+    y64 = y if ncls > 1 else y.double()
+    ref_loss, ref_logits, ref_grads = so.loss_and_grads(model, so.cast(sd, torch.float64), x.double(), y64, ncls, **okw)
+    assert relmax(logits.detach().cpu().numpy(), ref_logits.numpy()) < REL_TOL
+    assert abs(loss.item() - float(ref_loss)) / abs(float(ref_loss)) < 1e-5
+    gmax = max(float(g.abs().max()) for g in ref_grads.values())
+    for k, p in net.named_parameters():
+        err = float((p.grad.cpu().double() - ref_grads[k]).abs().max()) / gmax
+        assert err < 2e-5, (k, err)
 
 
 def check_blocks(device):

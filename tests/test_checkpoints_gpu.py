@@ -14,7 +14,7 @@ def test_load_reference_rvae_checkpoint():
     C.check_load_reference_rvae()
 
 
-@pytest.mark.parametrize("model", ["Unet", "dilnet"])
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet"])
 def test_io_segmentor(tmp_path, model):
     C.check_roundtrip_seg(tmp_path, model)
 

@@ -14,6 +14,8 @@ CASES = {
     "seg_unet_c1_nf4_b2_16_nearest": dict(model="Unet", kw=dict(upsampling="nearest")),
     "seg_unet_dil_c3_nf4_b2_32": dict(model="Unet", kw=dict(with_dilation=True)),
     "seg_dilnet_c1_nf5_b2_32": dict(model="dilnet", kw=dict()),
+    "seg_segresnet_c3_nf4_b2_32": dict(model="SegResNet", kw=dict()),
+    "seg_segresnet_c1_nf4_b2_16_nearest": dict(model="SegResNet", kw=dict(upsampling="nearest")),
 }
 
 
@@ -38,6 +40,8 @@ def test_init_matches_reference_rng_order(golden_dir, name):
     # set_train_rng(seed) in the reference == torch.manual_seed(seed) for the weight draw
     if c["model"] == "Unet":
         sd = so.init_unet(ncls, nf, with_dilation=bool(dil), seed=seed)
+    elif c["model"] == "SegResNet":
+        sd = so.init_segresnet(ncls, nf, seed=seed)
     else:
         sd = so.init_dilnet(ncls, nf, seed=seed)
     ref = _sd(g, "|init", torch.float32)

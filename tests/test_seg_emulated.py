@@ -26,6 +26,13 @@ def test_net_fwd_bwd_adam(name):
     C.check_net_case(name, "cpu")
 
 
+@pytest.mark.parametrize("model,ncls,kw", [("SegResNet", 3, dict(batch_norm=False)),
+                                           ("SegResNet", 1, dict(layers=[1, 3, 1])),
+                                           ("Unet", 3, dict(batch_norm=False))])
+def test_variants_vs_oracle(model, ncls, kw):
+    C.check_vs_oracle_small(model, ncls, "cpu", **kw)
+
+
 def test_blocks():
     C.check_blocks("cpu")
 

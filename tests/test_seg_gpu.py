@@ -67,7 +67,13 @@ def _oracle_on(device, sd, x, y, ncls, model="Unet", **kw):
     return so.loss_and_grads(model, sd, x.to(device), y.to(device), ncls, **kw)
 
 
-@pytest.mark.parametrize("model,ncls,B,H", [("Unet", 3, 4, 512), ("dilnet", 1, 2, 256)])
+@pytest.mark.parametrize("model,ncls,kw", [("SegResNet", 3, dict(batch_norm=False)),
+                                           ("SegResNet", 1, dict(layers=[1, 3, 1]))])
+def test_variants_vs_oracle(model, ncls, kw):
+    C.check_vs_oracle_small(model, ncls, "cuda", **kw)
+
+
+@pytest.mark.parametrize("model,ncls,B,H", [("Unet", 3, 4, 512), ("dilnet", 1, 2, 256), ("SegResNet", 3, 4, 256)])
 def test_full_width_vs_oracle_on_device(model, ncls, B, H):
     """Default-width nets (nb_filters 16 / 25) at BASELINE resolution: logits, loss and gradients against
     the oracle graph executed with stock torch ops on the same GPU (fp32), errors normalised globally."""
