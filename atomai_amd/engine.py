@@ -552,6 +552,38 @@ class UpsampleNode(_Node):
         tape.accumulate(s, dv)
 
 
+class ResizeCatNode(_Node):
+    """torch.cat([F.interpolate(s, size=(H, W), mode) for s in srcs], 1) for small-channel score maps
+    (ResHedNet.forward, atomai/nets/fcnn.py:283-295); each source's pending BatchNorm affine is applied on load."""
+
+    def __init__(self, tape, srcs: Sequence[Act], H: int, W: int, mode: str):
+        self.srcs, self.mode = list(srcs), {"bilinear": 0, "nearest": 1}[mode]
+        a0 = self.srcs[0]
+        C = sum(s.C for s in self.srcs)
+        y = torch.zeros((a0.N, H, W, r4(C)), dtype=torch.float32, device=a0.t.device)
+        off = 0
+        for s_ in self.srcs:
+            assert s_.post_slope == 1.0
+            s_.consumed_by(self)
+            L.call("amx_resize_cat_fwd", L.ptr(s_.t), L.ptr(s_.scale), L.ptr(s_.shift), s_.N, s_.H, s_.W, s_.Cs, s_.C,
+                   L.ptr(y), H, W, r4(C), off, self.mode, _sp(y))
+            off += s_.C
+        self.out = Act(y, C, needs_grad=any(s_.needs_grad for s_ in self.srcs))
+
+    def backward(self, tape) -> None:
+        g = self.out.grad
+        if g is None:
+            return
+        off = 0
+        for s_ in self.srcs:
+            if s_.needs_grad:
+                ds = _empty(s_.t.shape, s_.t)
+                L.call("amx_resize_cat_bwd", L.ptr(g), self.out.N, self.out.H, self.out.W, self.out.Cs, off, s_.C,
+                       L.ptr(ds), s_.H, s_.W, s_.Cs, self.mode, _sp(g))
+                tape.accumulate(s_, ds)
+            off += s_.C
+
+
 class DilatedSumNode(_Node):
     """out = sum_i (pre_i + a_i + bn_i) over the layers of a DilatedBlock (blocks.py:321-329)."""
 
@@ -740,6 +772,9 @@ class Tape:
 
     def upsample(self, src: Act, mode: str) -> Act:
         return self._push(UpsampleNode(self, src, mode)).out
+
+    def resize_cat(self, srcs, H: int, W: int, mode: str) -> Act:
+        return self._push(ResizeCatNode(self, srcs, H, W, mode)).out
 
     def dilated_sum(self, acts, slope) -> Act:
         return self._push(DilatedSumNode(self, acts, slope)).out

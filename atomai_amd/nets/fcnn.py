@@ -130,6 +130,49 @@ class dilnet(_HipNet):
         return self.px(self.c2(torch.cat([c1, u1], dim=1)))
 
 
+class ResHedNet(_HipNet):
+    """Holistically-nested edge detector with residual blocks (reference: atomai/nets/fcnn.py:229-295): three
+    ResModules at full / half / quarter resolution, a 1x1 conv + BatchNorm side output from each, the two coarse ones
+    interpolated back to the input size, concatenated and fused by a 1x1 conv."""
+
+    def __init__(self, nb_classes: int = 1, nb_filters: int = 64, upsampling_mode: str = "bilinear",
+                 **kwargs: List[int]) -> None:
+        super().__init__()
+        nbl = kwargs.get("layers", [3, 4, 5])
+        if upsampling_mode not in ("bilinear", "nearest"):
+            raise NotImplementedError("use 'bilinear' or 'nearest' for upsampling mode")
+        self.upsample = upsampling_mode
+        self.net1 = ResModule(2, nbl[0], 1, nb_filters, True)
+        self.net2 = nn.Sequential(nn.MaxPool2d(2, 2), ResModule(2, nbl[1], nb_filters, 2 * nb_filters, True))
+        self.net3 = nn.Sequential(nn.MaxPool2d(2, 2), ResModule(2, nbl[2], 2 * nb_filters, 4 * nb_filters, True))
+        self.net1score = nn.Sequential(nn.Conv2d(nb_filters, nb_classes, 1, 1, 0), nn.BatchNorm2d(nb_classes))
+        self.net2score = nn.Sequential(nn.Conv2d(2 * nb_filters, nb_classes, 1, 1, 0), nn.BatchNorm2d(nb_classes))
+        self.net3score = nn.Sequential(nn.Conv2d(4 * nb_filters, nb_classes, 1, 1, 0), nn.BatchNorm2d(nb_classes))
+        self.out = nn.Conv2d(3 * nb_classes, nb_classes, 1, 1, 0)
+
+    def _build(self, tape, x, px_mode: int = 0):
+        h, w = x.shape[2:4]
+        node = tape.input(x)
+        n1 = self.net1._emit(tape, [node.out])
+        n2 = self.net2[1]._emit(tape, [tape.pool(n1)])
+        n3 = self.net3[1]._emit(tape, [tape.pool(n2)])
+        scores = [tape.conv([n], seq[0], seq[1], 1.0)                       # conv 1x1 -> BatchNorm, no activation
+                  for n, seq in ((n1, self.net1score), (n2, self.net2score), (n3, self.net3score))]
+        cat = tape.resize_cat(scores, h, w, self.upsample)
+        return node, tape.px(cat, self.out, px_mode)
+
+    def _modular(self, x):
+        import torch.nn.functional as F
+        h, w = x.shape[2:4]
+        n1 = self.net1(x)
+        n2 = self.net2(n1)
+        n3 = self.net3(n2)
+        s1, s2, s3 = self.net1score(n1), self.net2score(n2), self.net3score(n3)
+        s2 = F.interpolate(s2, size=(h, w), mode=self.upsample)
+        s3 = F.interpolate(s3, size=(h, w), mode=self.upsample)
+        return self.out(torch.cat([s1, s2, s3], 1))
+
+
 class SegResNet(_HipNet):
     """SegNet-like net with residual blocks: c1-pool-c2(res)-pool-bn(res)-up1-cat-c3(res)-up2-cat-c4-px
     (reference: atomai/nets/fcnn.py:297-376)."""
@@ -197,8 +240,9 @@ def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwarg
         layers = kwargs.get("layers", [2, 2, 2])
         net = SegResNet(nb_classes, nb_filters, batch_norm, upsampling, layers=layers)
     elif isinstance(model, str) and model == 'ResHedNet':
-        raise NotImplementedError("'ResHedNet' (x4 interpolated side outputs) is outside the MI355X hot path "
-                                  "of this build; use 'Unet', 'dilnet' or 'SegResNet'")
+        nb_filters = kwargs.get('nb_filters', 64)
+        layers = kwargs.get("layers", [3, 4, 5])
+        net = ResHedNet(nb_classes, nb_filters, upsampling, layers=layers)
     else:
         raise NotImplementedError(
             "Currently implemented models are 'Unet', 'dilnet', SegResNet', and 'ResHedNet'")

@@ -1,4 +1,5 @@
+from .epredictor import EnsemblePredictor, ensemble_locate
 from .locator import Locator
 from .predictor import BasePredictor, SegPredictor
 
-__all__ = ["BasePredictor", "SegPredictor", "Locator"]
+__all__ = ["BasePredictor", "SegPredictor", "Locator", "EnsemblePredictor", "ensemble_locate"]

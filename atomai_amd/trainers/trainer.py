@@ -16,7 +16,8 @@ import torch
 from .. import losses_metrics
 from ..nets import init_fcnn_model
 from ..optim import FusedAdam
-from ..utils import (average_weights, gpu_usage_map, init_fcnn_dataloaders, preprocess_training_image_data,
+from ..utils import (array2list, average_weights, gpu_usage_map, init_dataloaders, init_fcnn_dataloaders,
+                     preprocess_training_image_data,
                      reset_bnorm, set_train_rng, weights_init)
 
 warnings.filterwarnings("ignore", module="torch.nn.functional")
@@ -73,6 +74,19 @@ class BaseTrainer:
 
     def _delete_optimizer(self) -> None:
         self.optimizer = None
+
+    def set_data(self, X_train, y_train, X_test, y_test, **kwargs) -> None:
+        """Dataloaders (full_epoch) or lists of whole mini-batches to draw from (trainer.py:129-162)."""
+        memory_alloc = kwargs.get("memory_alloc", 4)
+        tor = lambda x: torch.from_numpy(x) if isinstance(x, np.ndarray) else x   # noqa: E731
+        X_train, y_train, X_test, y_test = tor(X_train), tor(y_train), tor(X_test), tor(y_test)
+        if self.full_epoch:
+            self.train_loader, self.test_loader = init_dataloaders(
+                X_train, y_train, X_test, y_test, self.batch_size, memory_alloc)
+        else:
+            self.X_train, self.y_train, self.X_test, self.y_test = array2list(
+                X_train, y_train, X_test, y_test, self.batch_size, memory_alloc)
+        self.data_is_set = True
 
     def set_model(self, model: Type[torch.nn.Module], nb_classes: int = None) -> None:
         self.net = model

@@ -87,6 +87,21 @@ def average_weights(ensemble: Dict[int, Dict[str, torch.Tensor]]) -> Dict[str, t
     return out
 
 
+def sample_weights(ensemble: Dict[int, Dict[str, torch.Tensor]], n_samples: int = 30
+                   ) -> Dict[int, Dict[str, torch.Tensor]]:
+    """theta_i ~ N(mu_i, sigma_i) per trainable tensor from the members' mean / std (utils/nn.py:84-117)."""
+    out = {i: copy.deepcopy(ensemble[0]) for i in range(n_samples)}
+    for name in ensemble[0]:
+        if name.split('_')[-1] in ("mean", "var", "tracked"):
+            continue
+        w_all = torch.cat([copy.deepcopy(m[name])[None, ...] for m in ensemble.values()], dim=0)
+        if w_all.dtype == torch.float32:
+            ndist = torch.distributions.Normal(torch.mean(w_all, axis=0), torch.std(w_all, axis=0))
+            for i in range(n_samples):
+                out[i][name].copy_(ndist.sample())
+    return out
+
+
 def gpu_usage_map(cuda_device: int = 0):
     """[used, total] MiB of the device.  The reference shells out to nvidia-smi (utils/nn.py:120-133),
     which does not exist on ROCm; torch's allocator query is used instead."""

@@ -69,6 +69,14 @@ int amx_res_out_fwd(const float* t, const float* scale, const float* shift, cons
                     long npix, int Cs, float* out, void* stream);
 int amx_lrelu_bwd(const float* dout, const float* ref, const float* scale, const float* shift, float slope,
                   long npix, int Cs, float* din, float* din2, void* stream);
+/* ResHedNet side outputs (atomai/nets/fcnn.py:283-295): F.interpolate(score, size=(H, W), mode) with the producer's
+ * pending BatchNorm affine applied on load, written into channels [coff, coff + C) of the concatenated NHWC tensor
+ * dst (N,H,W,Cd); and its deterministic gather-form backward (dsrc: (N,h,w,Cs), gradient after the affine).
+ * mode 0 bilinear (align_corners=False), 1 nearest. */
+int amx_resize_cat_fwd(const float* src, const float* scale, const float* shift, int N, int h, int w, int Cs, int C,
+                       float* dst, int H, int W, int Cd, int coff, int mode, void* stream);
+int amx_resize_cat_bwd(const float* ddst, int N, int H, int W, int Cd, int coff, int C, float* dsrc, int h, int w,
+                       int Cs, int mode, void* stream);
 int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,

@@ -28,7 +28,7 @@ def _np(d, suffix=""):
 
 
 def _seg_case(aoi, name, model, nb_classes, nb_filters, B, H, seed, upsampling="bilinear",
-              with_dilation=False, steps=3):
+              with_dilation=False, steps=3, layers=None):
     from atomai.nets import init_fcnn_model
     from atomai.losses_metrics import select_loss
     from atomai.utils import set_train_rng
@@ -43,6 +43,8 @@ def _seg_case(aoi, name, model, nb_classes, nb_filters, B, H, seed, upsampling="
     kw = dict(nb_filters=nb_filters, upsampling=upsampling)
     if model == "Unet":
         kw["with_dilation"] = with_dilation
+    if layers is not None:
+        kw["layers"] = layers
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         set_train_rng(seed)                                   # trainer.py:659-661
         net, meta = init_fcnn_model(model, nb_classes, **kw)
@@ -85,12 +87,21 @@ def make_seg_res(aoi):
     _seg_case(aoi, "seg_segresnet_c1_nf4_b2_16_nearest", "SegResNet", 1, 4, 2, 16, 3, upsampling="nearest")
 
 
+def make_seg_hed(aoi):
+    """ResHedNet: three residual stages, BatchNorm'ed 1x1 side outputs interpolated to the input size (x2 / x4)."""
+    _seg_case(aoi, "seg_reshednet_c3_nf4_b2_32", "ResHedNet", 3, 4, 2, 32, 1, layers=[2, 2, 2])
+    _seg_case(aoi, "seg_reshednet_c3_nf4_b2_22", "ResHedNet", 3, 4, 2, 22, 5, layers=[1, 1, 1])
+    _seg_case(aoi, "seg_reshednet_c1_nf4_b2_22_nearest", "ResHedNet", 1, 4, 2, 22, 4, upsampling="nearest",
+              layers=[1, 2, 1])
+
+
 def make_seg(aoi):
     _seg_case(aoi, "seg_unet_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1)
     _seg_case(aoi, "seg_unet_c1_nf4_b2_16_nearest", "Unet", 1, 4, 2, 16, 2, upsampling="nearest")
     _seg_case(aoi, "seg_unet_dil_c3_nf4_b2_32", "Unet", 3, 4, 2, 32, 1, with_dilation=True)
     _seg_case(aoi, "seg_dilnet_c1_nf5_b2_32", "dilnet", 1, 5, 2, 32, 1)
     make_seg_res(aoi)
+    make_seg_hed(aoi)
     # default-width nets: pin the RNG-order initialisation by per-tensor moments only
     from atomai.nets import init_fcnn_model
     from atomai.utils import set_train_rng
@@ -366,11 +377,46 @@ def make_locator(aoi):
     np.savez_compressed(os.path.join(GOLD, "locator.npz"), **out)
 
 
+def make_ensemble(aoi):
+    """EnsembleTrainer of the reference (trainers/etrainer.py): both strategies on a tiny U-Net."""
+    out = {}
+    rs = np.random.RandomState(41)
+    X, Xt = rs.rand(6, 16, 16).astype(np.float32), rs.rand(4, 16, 16).astype(np.float32)
+    y, yt = rs.randint(0, 3, (6, 16, 16)), rs.randint(0, 3, (4, 16, 16))
+    out["X"], out["y"], out["Xt"], out["yt"] = X, y, Xt, yt
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        et = aoi.trainers.EnsembleTrainer("Unet", nb_classes=3, nb_filters=4)
+        et.compile_ensemble_trainer(training_cycles=3, batch_size=2, plot_training_history=False, filename="ens_a")
+        net, ens = et.train_ensemble_from_scratch(X, y, Xt, yt, n_models=2)
+        for i, sd in ens.items():
+            for k, v in sd.items():
+                out[f"scratch|{i}|{k}"] = v.cpu().numpy().copy()
+        out["scratch|last_train_loss"] = np.array(et.loss_acc["train_loss"])
+        ep = aoi.predictors.EnsemblePredictor(net, ens, nb_classes=3, use_gpu=False)
+        out["epred|mean"], out["epred|var"] = ep.predict(Xt, num_batches=2)
+        et = aoi.trainers.EnsembleTrainer("Unet", nb_classes=3, nb_filters=4)
+        et.compile_ensemble_trainer(batch_size=2, plot_training_history=False, filename="ens_b")
+        net, ens = et.train_ensemble_from_baseline(X, y, Xt, yt, n_models=2, training_cycles_base=3,
+                                                   training_cycles_ensemble=2)
+        for i, sd in ens.items():
+            for k, v in sd.items():
+                out[f"baseline|{i}|{k}"] = v.cpu().numpy().copy()
+        for k, v in net.state_dict().items():
+            out[f"baseline|avg|{k}"] = v.cpu().numpy().copy()
+        out["ens_meta_keys"] = np.array(sorted(torch.load("ens_b_ensemble_metadict.tar", weights_only=False).keys()))
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "ensemble.npz"), **out)
+    print("ensemble ok", out["scratch|last_train_loss"], out["ens_meta_keys"])
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble}[w](aoi)
     print("done ->", GOLD)

@@ -17,6 +17,9 @@ CASES = {
     "seg_dilnet_c1_nf5_b2_32": ("dilnet", dict()),
     "seg_segresnet_c3_nf4_b2_32": ("SegResNet", dict()),
     "seg_segresnet_c1_nf4_b2_16_nearest": ("SegResNet", dict(upsampling="nearest")),
+    "seg_reshednet_c3_nf4_b2_32": ("ResHedNet", dict(layers=[2, 2, 2])),
+    "seg_reshednet_c3_nf4_b2_22": ("ResHedNet", dict(layers=[1, 1, 1])),
+    "seg_reshednet_c1_nf4_b2_22_nearest": ("ResHedNet", dict(upsampling="nearest", layers=[1, 2, 1])),
 }
 REL_TOL = 1e-4          # north_star: "within 1e-4 rel fp32"
 

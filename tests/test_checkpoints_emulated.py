@@ -25,7 +25,7 @@ def test_load_reference_rvae_checkpoint():
     C.check_load_reference_rvae()
 
 
-@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet"])
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet", "ResHedNet"])
 def test_io_segmentor(tmp_path, model):
     C.check_roundtrip_seg(tmp_path, model)
 
@@ -36,3 +36,13 @@ def test_io_rvae(tmp_path):
 
 def test_misc_loaders(tmp_path):
     C.check_misc_loaders(tmp_path)
+
+
+def test_ensemble_trainer_matches_reference(tmp_path):
+    import _ensemble_checks as E
+    E.check_ensemble(tmp_path)
+
+
+def test_ensemble_predictor_matches_reference():
+    import _ensemble_checks as E
+    E.check_ensemble_predictor()

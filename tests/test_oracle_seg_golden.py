@@ -16,6 +16,9 @@ CASES = {
     "seg_dilnet_c1_nf5_b2_32": dict(model="dilnet", kw=dict()),
     "seg_segresnet_c3_nf4_b2_32": dict(model="SegResNet", kw=dict()),
     "seg_segresnet_c1_nf4_b2_16_nearest": dict(model="SegResNet", kw=dict(upsampling="nearest")),
+    "seg_reshednet_c3_nf4_b2_32": dict(model="ResHedNet", kw=dict(layers=[2, 2, 2])),
+    "seg_reshednet_c3_nf4_b2_22": dict(model="ResHedNet", kw=dict(layers=[1, 1, 1])),
+    "seg_reshednet_c1_nf4_b2_22_nearest": dict(model="ResHedNet", kw=dict(upsampling="nearest", layers=[1, 2, 1])),
 }
 
 
@@ -42,6 +45,8 @@ def test_init_matches_reference_rng_order(golden_dir, name):
         sd = so.init_unet(ncls, nf, with_dilation=bool(dil), seed=seed)
     elif c["model"] == "SegResNet":
         sd = so.init_segresnet(ncls, nf, seed=seed)
+    elif c["model"] == "ResHedNet":
+        sd = so.init_reshednet(ncls, nf, layers=c["kw"]["layers"], seed=seed)
     else:
         sd = so.init_dilnet(ncls, nf, seed=seed)
     ref = _sd(g, "|init", torch.float32)

@@ -73,7 +73,8 @@ def test_variants_vs_oracle(model, ncls, kw):
     C.check_vs_oracle_small(model, ncls, "cuda", **kw)
 
 
-@pytest.mark.parametrize("model,ncls,B,H", [("Unet", 3, 4, 512), ("dilnet", 1, 2, 256), ("SegResNet", 3, 4, 256)])
+@pytest.mark.parametrize("model,ncls,B,H", [("Unet", 3, 4, 512), ("dilnet", 1, 2, 256), ("SegResNet", 3, 4, 256),
+                                            ("ResHedNet", 3, 2, 128)])
 def test_full_width_vs_oracle_on_device(model, ncls, B, H):
     """Default-width nets (nb_filters 16 / 25) at BASELINE resolution: logits, loss and gradients against
     the oracle graph executed with stock torch ops on the same GPU (fp32), errors normalised globally."""
