@@ -107,6 +107,7 @@ class EnsemblePredictor(BasePredictor):
         if not self.output_shape:
             self._set_output_shape(data)
         if self.downsample_factor is None:
+            self._model2device()                 # the mock forward below runs HIP kernels: the net must be on the GPU
             self.downsample_factor = get_downsample_factor(self.model)
         mean, var = self.ensemble_batch_predict(data, num_batches)
         if format_out == "channel_last":

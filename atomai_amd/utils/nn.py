@@ -65,9 +65,16 @@ def get_downsample_factor(model: Type[torch.nn.Module]) -> int:
 
 
 def weights_init(module) -> None:
+    """Xavier-uniform weights, zero biases (utils/nn.py:238-242).  The values are always drawn from the CPU
+    generator and copied to the parameter's device, so that a seed gives the same ensemble member on any device
+    (the reference draws from whichever generator the parameter lives on: its GPU and CPU members differ)."""
     if isinstance(module, (Conv1d, Conv2d, ConvTranspose1d, ConvTranspose2d, Linear)):
-        torch.nn.init.xavier_uniform_(module.weight.data)
-        torch.nn.init.zeros_(module.bias)
+        w = torch.empty(module.weight.shape, dtype=module.weight.dtype)
+        torch.nn.init.xavier_uniform_(w)
+        with torch.no_grad():
+            module.weight.copy_(w)
+            if module.bias is not None:
+                module.bias.zero_()
 
 
 def reset_bnorm(module) -> None:

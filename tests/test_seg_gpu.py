@@ -96,10 +96,17 @@ def test_full_width_vs_oracle_on_device(model, ncls, B, H):
     ref_loss, ref_logits, ref_grads = _oracle_on("cuda", sd, x, y, ncls, model)
     assert C.relmax(logits.detach().cpu().numpy(), ref_logits.cpu().double().numpy()) < C.REL_TOL
     assert abs(loss.item() - float(ref_loss)) / abs(float(ref_loss)) < 1e-5
-    gmax = max(float(g.abs().max()) for g in ref_grads.values())
+    # gradients: judged against the oracle in fp64, relative to the global gradient scale and to the noise the
+    # oracle's own fp32 run shows against fp64 (deep nets: 12 residual blocks amplify fp32 rounding and LeakyReLU
+    # kink flips; SURVEY section 7 "Parity budget")
+    from oracle import seg_oracle as so
+    y64 = y if ncls > 1 else y.double()
+    _, _, g64 = _oracle_on("cuda", so.cast(sd, torch.float64), x.double(), y64, ncls, model)
+    gmax = max(float(g.abs().max()) for g in g64.values())
     for k, p in net.named_parameters():
-        err = float((p.grad - ref_grads[k]).abs().max()) / gmax
-        assert err < 1e-3, (k, err)            # fp32-vs-fp32 at 1M+ pixel reductions (<= 3.8e-4)
+        err = float((p.grad.double() - g64[k]).abs().max()) / gmax
+        floor = float((ref_grads[k].double() - g64[k]).abs().max()) / gmax
+        assert err < max(4 * floor, 1e-3), (k, err, floor)
 
 
 def test_determinism_and_loss_decrease_at_full_size():
