@@ -29,5 +29,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void amx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// Streaming (non-temporal) 16-byte store for outputs that are written once and not re-read by the same kernel
+static __device__ __forceinline__ void amx_st4_stream(float* p, float4 v) {
+#ifdef AMX_EMU
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#endif
+}
 static __host__ __device__ __forceinline__ int amx_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static __host__ __device__ __forceinline__ int amx_round_up(int a, int b) { return (a + b - 1) / b * b; }
