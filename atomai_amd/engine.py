@@ -14,6 +14,7 @@ the kernels.  No CPU fallback exists; `_lib` raises if the extension is missing.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -93,7 +94,9 @@ class Act:
 
 
 class _PackCache:
-    """Packed weight images keyed by (storage, version, optimizer generation, layout)."""
+    """Packed weight images keyed by (tensor identity, layout), valid for one (storage, version, optimizer
+    generation).  Entries hold only a weak reference to the parameter: they die with it, and an `id()` that gets
+    reused by a later tensor can never produce a stale hit."""
 
     def __init__(self):
         self.store: Dict[tuple, tuple] = {}
@@ -102,10 +105,12 @@ class _PackCache:
         key = (id(w),) + key_extra
         ver = (w.data_ptr(), w._version, _weight_generation[0])
         hit = self.store.get(key)
-        if hit is not None and hit[0] == ver:
+        if hit is not None and hit[0] == ver and hit[2]() is w:
             return hit[1]
         val = build()
-        self.store[key] = (ver, val)
+        if len(self.store) > 4096:                               # long sessions (ensembles): drop dead entries
+            self.store = {k: v for k, v in self.store.items() if v[2]() is not None}
+        self.store[key] = (ver, val, weakref.ref(w))
         return val
 
 
