@@ -29,6 +29,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void amx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// XCD-aware block index: the dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup
+// dispatch"); this bijective remap gives every XCD one CONTIGUOUS range of logical blocks instead, so that blocks
+// which share halo rows / columns of their input hit the same 4 MiB L2.  Speed only — never correctness.
+static __device__ __forceinline__ unsigned amx_xcd_remap(unsigned b, unsigned nb) {
+    const unsigned xcd = b & 7u, idx = b >> 3, q = nb >> 3, r = nb & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + idx;
+}
+
 // Streaming (non-temporal) 16-byte store for outputs that are written once and not re-read by the same kernel
 static __device__ __forceinline__ void amx_st4_stream(float* p, float4 v) {
 #ifdef AMX_EMU

@@ -60,6 +60,7 @@ struct ConvFwdArgs {
     float slope;         // LeakyReLU negative slope; 1.0f == no activation
     int tiles_x, tiles_y;
     int th;              // tile height in pixels (16 or 32)
+    int xcd;             // 1: XCD-aware tile order (neighbouring tiles share an L2)
 };
 
 template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED>
@@ -81,10 +82,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int stage_floats = KG * plane * 4 + TAPS * KG * NB * 4;
     float* s_red = smem;                                         // reused after the K loop
 
-    int t = blockIdx.x;
+    // logical (tile, cout-block) of this workgroup: cout blocks of one tile adjacent, tiles in raster order,
+    // contiguous ranges of them per XCD
+    unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.xcd) lin = amx_xcd_remap(lin, gridDim.x * gridDim.y);
+    int t = a.xcd ? (int)(lin / gridDim.y) : (int)blockIdx.x;
+    const int ob = a.xcd ? (int)(lin % gridDim.y) : (int)blockIdx.y;
+    const int tile_id = t;
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
-    const int n0 = blockIdx.y * NB;                              // first cout of this workgroup
+    const int n0 = ob * NB;                                      // first cout of this workgroup
     const int gy0 = ty * TH - halo, gx0 = tx * TILE - halo;
 
     // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             const int co = n0 + c;
             if (co < a.cop) {
                 const float* r = s_red + which * 4 * NB;
-                a.bstats[((size_t)blockIdx.x * 2 + which) * a.cop + co] = r[c] + r[NB + c] + r[2 * NB + c] + r[3 * NB + c];
+                a.bstats[((size_t)tile_id * 2 + which) * a.cop + co] = r[c] + r[NB + c] + r[2 * NB + c] + r[3 * NB + c];
             }
         }
         return;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         const int co = n0 + tid;
         if (co < a.cop) {
             const float m2 = s_red[tid] + s_red[NB + tid] + s_red[2 * NB + tid] + s_red[3 * NB + tid];
-            a.stats[((size_t)blockIdx.x * 2 + 1) * a.cop + co] = m2;
+            a.stats[((size_t)tile_id * 2 + 1) * a.cop + co] = m2;
         }
     }
     // tile sums: every lane holds mean[q] (= tile sum) for column q*16+p; 16 lanes of wave 0 write them
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int co = n0 + q * 16 + p;
-            if (co < a.cop) a.stats[(size_t)blockIdx.x * 2 * a.cop + co] = mean[q];
+            if (co < a.cop) a.stats[(size_t)tile_id * 2 * a.cop + co] = mean[q];
         }
     }
 }
@@ -459,6 +466,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     const ConvPlan pl = plan_conv(C0s + C1s, cout, taps, dil, H);
     const int nt = pl.nt;
     a.th = pl.th;
+    { const char* e = getenv("AMX_XCD"); a.xcd = e ? (atoi(e) & 1) : 0; }
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     // (the two-stage LDS pipeline, DBUF = true, was measured slower for every layer shape and is not instantiated:
     //  profiles/r01_conv_variants.md)

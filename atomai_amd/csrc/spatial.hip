@@ -6,6 +6,7 @@
 //   F.interpolate(scale_factor=2, mode=bilinear|nearest), align_corners=False   atomai/nets/blocks.py:130-131
 //   DilatedBlock: sum of every sub-layer output                              atomai/nets/blocks.py:321-329
 #include "amx_device.h"
+#include <cstdlib>
 
 #define GRID_FOR(n) dim3((unsigned)(((n) + 255) / 256 < 16384 ? ((n) + 255) / 256 : 16384))
 
@@ -220,10 +221,12 @@ __device__ __forceinline__ int up_bwd_taps(int i, int n, int mode, int* o, float
 }
 
 __global__ void upsample_bwd_kernel(const float* __restrict__ du, float* __restrict__ dv, int N, int h,
-                                    int w, int G, int mode) {
+                                    int w, int G, int mode, int xcd) {
     const int H = 2 * h, W = 2 * w;
     const size_t total = (size_t)N * h * w * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+    // neighbouring low-res rows gather from shared high-res rows: contiguous block ranges per XCD keep them in one L2
+    const unsigned bid = xcd ? amx_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int cg = (int)(i % G);
         size_t r = i / G;
@@ -248,8 +251,9 @@ extern "C" int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int 
                                   void* stream) {
     if (!du || !dv || (Cs & 3) || Cs <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
     const size_t total = (size_t)N * h * w * (Cs / 4);
+    const char* e = getenv("AMX_XCD");
     AMX_LAUNCH(upsample_bwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, du, dv, N, h, w,
-               Cs / 4, mode);
+               Cs / 4, mode, e ? ((atoi(e) >> 1) & 1) : 0);
     AMX_CHECK_LAUNCH();
     return 0;
 }
