@@ -63,7 +63,10 @@ struct ConvFwdArgs {
     int xcd;             // 1: XCD-aware tile order (neighbouring tiles share an L2)
 };
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED>
+// TAIL: compiled-in support for a partial last chunk (compute_tail).  It is a separate instantiation because the
+// extra unrolled tap loop costs registers — 108+16 -> 128+32 VGPR/AGPR, i.e. 4 -> 3 waves per SIMD — which slowed
+// every layer by ~10 %, including the ones (all channel counts multiples of 16) that never take that path.
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             stage_to_lds(0);
             __syncthreads();
             if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
-            if (chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
+            if (TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
             else compute_taps(0, 0, TAPS);
             __syncthreads();
         }
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     }
 }
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED>
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int I = TILE + 2 * halo;
@@ -398,13 +401,13 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -471,8 +474,12 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     // (the two-stage LDS pipeline, DBUF = true, was measured slower for every layer shape and is not instantiated:
     //  profiles/r01_conv_variants.md)
     const bool fz = aux0 != nullptr || bstats != nullptr;
-#define CONV_GO(T, N_, H_, M_) return fz ? launch_conv_fwd<T, N_, H_, false, M_, true>(a, s) \
-                                         : launch_conv_fwd<T, N_, H_, false, M_, false>(a, s)
+    // partial last chunk: the cheaper tail path exists for the plain variants; the loader-fused (backward
+    // experiment) variants just run the zero-padded k-groups through the full path
+    const bool tail = !fz && a.tail_kg < KG;
+#define CONV_GO(T, N_, H_, M_) return fz ? launch_conv_fwd<T, N_, H_, false, M_, true>(a, s)           \
+                                     : (tail ? launch_conv_fwd<T, N_, H_, false, M_, false, true>(a, s)  \
+                                             : launch_conv_fwd<T, N_, H_, false, M_, false, false>(a, s))
     if (taps == 1) {
         if (nt == 1) CONV_GO(1, 1, 0, 4);
         if (nt == 2) CONV_GO(1, 2, 0, 4);

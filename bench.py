@@ -149,14 +149,19 @@ def main():
         torch.cuda.synchronize()
 
     losses = []
+    wmarks = [time.perf_counter()]
     for i in range(args.warmup):
         losses.append(model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0])
+        wmarks.append(time.perf_counter())
     barrier()
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(args.steps):
         losses.append(model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0])
+        marks.append(time.perf_counter())                    # loss.item() already synchronised this step
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = np.diff(marks) * 1e3
     ksteps = 0
     if timer:                      # every rank takes part (the step contains the gradient all-reduce)
         # Per-kernel HIP-event pass, in the same run right after the timed region: the step normally overlaps
@@ -189,6 +194,8 @@ def main():
                                "(BASELINE.json configs[1]); step = fwd+bwd+allreduce+Adam+loss.item()",
                    "global_batch": world * BS, "parallelism": f"dp{world}",
                    "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]},
+        "step_ms_median_max": [round(float(np.median(per_step)), 3), round(float(per_step.max()), 3)],
+        "step_ms_all": [round(float(v), 1) for v in list(np.diff(wmarks) * 1e3) + list(per_step)],
         "step_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_mfma_f32_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32, 4),
     }
