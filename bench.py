@@ -154,6 +154,7 @@ def main():
         losses.append(model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0])
         wmarks.append(time.perf_counter())
     barrier()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     marks = [t0]
     for i in range(args.steps):
@@ -162,6 +163,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     per_step = np.diff(marks) * 1e3
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc_info = {"hipMalloc_calls_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+                  "hipFree_calls_in_timed_region": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+                  "reserved_GB": round(ms1.get("reserved_bytes.all.current", 0) / 1e9, 2),
+                  "peak_allocated_GB": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
     ksteps = 0
     if timer:                      # every rank takes part (the step contains the gradient all-reduce)
         # Per-kernel HIP-event pass, in the same run right after the timed region: the step normally overlaps
@@ -195,6 +201,7 @@ def main():
                    "global_batch": world * BS, "parallelism": f"dp{world}",
                    "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]},
         "step_ms_median_max": [round(float(np.median(per_step)), 3), round(float(per_step.max()), 3)],
+        "allocator": alloc_info,
         "step_ms_all": [round(float(v), 1) for v in list(np.diff(wmarks) * 1e3) + list(per_step)],
         "step_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_mfma_f32_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32, 4),
