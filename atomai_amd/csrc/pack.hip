@@ -142,3 +142,24 @@ extern "C" int amx_sub_div(const float* x, float* y, long n, float sub, float di
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// dst[i] = src[i], 16 B per lane, on a bounded number of workgroups.  Used by the predictor to write a chunk's
+// probabilities straight into PINNED HOST memory (device-accessible under unified addressing) from a side stream:
+// a kernel behind a cross-stream event wait never blocks the launching thread, whereas hipMemcpyAsync behind such a
+// wait was measured to stall the host for up to two chunk times (SegPredictor.batch_predict).
+__global__ __launch_bounds__(256) void copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+extern "C" int amx_copy16(const void* src, void* dst, long nbytes, int max_wgs, void* stream) {
+    if (!src || !dst || nbytes <= 0 || (nbytes & 15) || max_wgs <= 0) AMX_BADARG(1);
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) AMX_BADARG(2);
+    const size_t n16 = (size_t)nbytes / 16;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > (size_t)max_wgs) blocks = (size_t)max_wgs;
+    AMX_LAUNCH(copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+               (const float4*)src, (float4*)dst, n16);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

@@ -710,18 +710,24 @@ class PxNode(_Node):
 
 
 # ====================================================================================== tape
-_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def aux_stream(dev, which: int = 0) -> "torch.cuda.Stream":
+    """Persistent auxiliary stream number `which` of a device (0: weight gradients, 1 / 2: the predictor's
+    upload / download copies).  Persistent so that its hardware queue never changes between calls."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get((idx, which))
+    if st is None:
+        st = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(dev)
+    return st
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
     """ONE persistent side stream per device.  The HIP runtime multiplexes streams onto 4 hardware queues round-robin;
     with a fresh stream per step every 4th one landed on the main stream's queue and that step lost the
     weight-gradient overlap (+2.6 ms, visible as a period-4 pattern in the per-step times)."""
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
-    if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(dev)
-    return st
+    return aux_stream(dev, 0)
 
 
 class _SideCtx:

@@ -6,6 +6,7 @@ chunked pipeline: pinned staging buffers, H2D / kernels / D2H of consecutive chu
 streams.  In eval mode BatchNorm uses running statistics, so frames are independent and the result does
 not depend on how the stack is chunked (``num_batches`` keeps its meaning for the caller only).
 """
+import os
 import time
 from typing import Dict, List, Tuple, Type, Union
 
@@ -137,43 +138,59 @@ class SegPredictor(BasePredictor):
         per_frame = max(data[0].numel(), int(np.prod(out_shape[1:]))) * 4
         chunk = max(1, min(n, self.chunk_bytes // per_frame))
         dev = torch.device(self.device)
-        copy_in, copy_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        from ..engine import aux_stream
+        copy_in, copy_out = aux_stream(dev, 1), aux_stream(dev, 2)
         main = torch.cuda.current_stream(dev)
-        pin_in = [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(2)]
-        pin_out = [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(2)]
-        pending = [None, None]                      # per staging slot: (event, start, count)
+        NS = 3                                      # chunks in flight (host runs up to NS chunks ahead of the GPU)
+        pin_in = [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(NS)]
+        pin_out = [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(NS)]
+        stage = {}                                  # chunk index -> its in-flight state
 
-        def drain(slot):
-            if pending[slot] is not None:
-                ev, ps, pm = pending[slot]
-                ev.synchronize()
-                out[ps:ps + pm] = pin_out[slot][:pm]
-                pending[slot] = None
+        # Software pipeline over chunks, NS of them in flight.  The DOWNLOAD is a copy kernel on a side stream that
+        # writes straight into pinned host memory: hipMemcpyAsync behind a cross-stream event wait was measured to
+        # block the calling thread on this runtime (the "asynchronous" D2H call stalled the host for up to two chunk
+        # times and the compute stream ran dry); a kernel launch never blocks.  The UPLOAD stays a hipMemcpyAsync
+        # (it depends on nothing, so it is issued without waiting; a copy kernel READING pinned host memory was
+        # tried and returned stale data — torch's pinned buffers are not fine-grained coherent).  Tensors stay
+        # referenced in `stage` until the streams that read them are known to be done.
+        import ctypes
 
+        def finish(k):                              # chunk k queued -> hooks, queue its download
+            st = stage[k]
+            if on_chunk is not None:
+                st["done"].synchronize()
+                on_chunk(st["s"], st["prob"])
+            prob = st["prob"] = st["prob"].contiguous()
+            copy_out.wait_event(st["done"])
+            L.call("amx_copy16", L.ptr(prob), ctypes.c_void_p(pin_out[k % NS].data_ptr()), prob.numel() * 4, 128,
+                   ctypes.c_void_p(copy_out.cuda_stream))
+            st["ev_out"] = torch.cuda.Event()
+            st["ev_out"].record(copy_out)
+
+        def collect(k):                             # chunk k downloaded -> user-visible output; its staging
+            st = stage.pop(k)                       # buffers and device tensors are free again after this
+            st["ev_out"].synchronize()
+            out[st["s"]:st["s"] + st["m"]] = pin_out[k % NS][:st["m"]]
+
+        nchunks = 0
         for k, s in enumerate(range(0, n, chunk)):
-            slot, m = k % 2, min(chunk, n - s)
-            drain(slot)                             # the slot's buffers are free again after this
-            pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of chunk k-1
-            with torch.cuda.stream(copy_in):
+            slot, m = k % NS, min(chunk, n - s)
+            if k >= NS:
+                collect(k - NS)
+            pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of the chunks in flight
+            with torch.cuda.stream(copy_in):        # upload: hipMemcpyAsync with no dependency (see above)
                 d = pin_in[slot][:m].to(dev, non_blocking=True)
-                ev_in = torch.cuda.Event()
-                ev_in.record(copy_in)
+            ev_in = torch.cuda.Event()
+            ev_in.record(copy_in)
             main.wait_event(ev_in)
             prob = self.forward_(d)
-            d.record_stream(main)
-            if on_chunk is not None:
-                on_chunk(s, prob)
             done = torch.cuda.Event()
             done.record(main)
-            with torch.cuda.stream(copy_out):
-                copy_out.wait_event(done)
-                pin_out[slot][:m].copy_(prob, non_blocking=True)
-                prob.record_stream(copy_out)
-                ev_out = torch.cuda.Event()
-                ev_out.record(copy_out)
-            pending[slot] = (ev_out, s, m)
-        drain(0)
-        drain(1)
+            stage[k] = {"d": d, "prob": prob, "done": done, "s": s, "m": m}
+            finish(k)
+            nchunks = k + 1
+        for k in range(max(0, nchunks - NS), nchunks):
+            collect(k)
         return out
 
     def predict(self, image_data: np.ndarray, return_image: bool = False, **kwargs: int):

@@ -102,6 +102,9 @@ int amx_add_inplace(float* dst, const float* src, long n, void* stream);
 /* y = (x - sub) / div: the global min-max normalisation of torch_format_image (utils/preproc.py:798-825) for a
  * chunk already on the device (two correctly rounded fp32 ops = numpy's float32 arithmetic) */
 int amx_sub_div(const float* x, float* y, long n, float sub, float div, void* stream);
+/* contiguous 16-byte-granular copy on at most max_wgs workgroups; dst may be pinned host memory (the predictor's
+ * download of a chunk: atomai/predictors/predictor.py:99-104 copies each batch to the host) */
+int amx_copy16(const void* src, void* dst, long nbytes, int max_wgs, void* stream);
 
 /* ---- BatchNorm2d after LeakyReLU (blocks.py:71-75; torch defaults eps 1e-5, momentum 0.1) */
 int amx_bn_finalize(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,

@@ -38,6 +38,7 @@ struct dim3 {
 struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) int2 { int x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 typedef float f32x4 __attribute__((vector_size(16)));

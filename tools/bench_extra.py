@@ -64,7 +64,7 @@ def bench_rvae(steps=10, warmup=3, B=512):
     return out
 
 
-def bench_predict(frames=64, hw=1024):
+def bench_predict(frames=256, hw=1024):
     """configs[2] on a bounded stack: dilnet nb_classes=1 predict over `frames` 1024x1024 frames."""
     torch.manual_seed(1)
     net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
