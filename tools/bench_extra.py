@@ -134,6 +134,58 @@ def bench_dkl(N=16384, D=2):
     return out
 
 
+def _conv_flops(name, a):
+    """Executed MFMA-conv FLOPs of one C-ABI call (stored/padded channel counts, as launched)."""
+    if name == "amx_conv2d_fwd":
+        return 2.0 * (a[3] + a[7]) * a[19] * a[20] * a[16] * a[17] * a[18]
+    if name == "amx_conv2d_fwd_act":
+        return 2.0 * (a[4] + a[9]) * a[21] * a[22] * a[18] * a[19] * a[20]
+    if name == "amx_conv2d_dgrad":
+        return 2.0 * a[6] * (a[10] + a[12]) * a[19] * a[16] * a[17] * a[18]
+    if name == "amx_conv2d_wgrad_fused":
+        return 2.0 * (a[3] + a[7]) * a[20] * a[21] * a[17] * a[18] * a[19]
+    if name == "amx_conv2d_wgrad_act":
+        return 2.0 * (a[4] + a[9]) * a[22] * a[23] * a[19] * a[20] * a[21]
+    return 0.0
+
+
+def bench_segfamily(models=("SegResNet", "ResHedNet", "dilnet"), hw=512, bs=32, steps=10, warmup=4):
+    """Training throughput of the other Segmentor families (default widths) at the headline shape."""
+    import atomai_amd.engine as eng
+    res = {}
+    for model in models:
+        rs = np.random.RandomState(0)
+        ncls = 1 if model == "dilnet" else 3
+        X = rs.rand(2 * bs, hw, hw).astype(np.float32)
+        y = rs.randint(0, 3, (2 * bs, hw, hw)) if ncls > 1 else (rs.rand(2 * bs, hw, hw) > 0.5).astype(np.float32)
+        m = aoi.models.Segmentor(model, nb_classes=ncls, seed=1)
+        m.compile_trainer((X, y, X[:bs], y[:bs]), training_cycles=steps + warmup, batch_size=bs,
+                          plot_training_history=False)
+        flops, orig = [0.0], L.call
+
+        def call(name, *a):
+            flops[0] += _conv_flops(name, a)
+            return orig(name, *a)
+        for i in range(warmup):
+            m.train_step(m.X_train[i % 2], m.y_train[i % 2])
+        L.call = eng.L.call = call
+        m.train_step(m.X_train[0], m.y_train[0])
+        L.call = eng.L.call = orig
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            last = m.train_step(m.X_train[i % 2], m.y_train[i % 2])[0]
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        res[model] = {"images_per_s": round(bs / dt, 1), "ms_per_step": round(dt * 1e3, 2), "loss": round(last, 4),
+                      "conv_TFLOP_per_step_as_launched": round(flops[0] / 1e12, 3),
+                      "step_TFLOPs": round(flops[0] / dt / 1e12, 1), "frac_of_mfma_peak": round(flops[0] / dt / 1e12 / PEAK, 3)}
+        del m
+        torch.cuda.empty_cache()
+    out = {"metric": f"training images/sec, {hw}x{hw}, bs={bs}, default-width families", "unit": "images/s",
+           "value": res.get("SegResNet", {}).get("images_per_s"), "detail": res}
+    print(json.dumps(out), flush=True)
+    return out
+
+
 def bench_locate(frames=32, hw=1024, C=1):
     """Locator on `frames` probability maps of hw x hw (the post-processing of configs[2]): HBM-bound integer
     work; algorithmic bytes = the probabilities read once (4*C bytes per pixel)."""
@@ -180,5 +232,5 @@ if __name__ == "__main__":
     os.makedirs("gpurun_out", exist_ok=True)
     res = {}
     for w in what:
-        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl, "locate": bench_locate}[w]()
+        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl, "locate": bench_locate, "segfamily": bench_segfamily}[w]()
     json.dump(res, open("gpurun_out/bench_extra.json", "w"), indent=1)
