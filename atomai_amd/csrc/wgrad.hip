@@ -35,7 +35,12 @@ struct WgradArgs {
 };
 
 template <int TAPS, int NT, int WM, int MAXHALO, int TH>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+// Forcing two waves per SIMD for the wide variant (191 + 72 registers -> 256 with 6 spills) was measured in-step with
+// tools/gpu_lib_ab.py: 20.82 ms (256 workgroups) / 20.50 ms (384) against 20.34 ms for one wave per SIMD -> rejected.
+#ifndef AMX_WGRAD_WAVES
+#define AMX_WGRAD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ? AMX_WGRAD_WAVES : 1) void wgrad_kernel(WgradArgs a) {
     constexpr int CIB = 16 * WM;
     constexpr int CG = CIB / 4;                                   // float4 groups per pixel (x)
     constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;         // == 16 mod 32
