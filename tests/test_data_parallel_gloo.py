@@ -83,3 +83,107 @@ def test_two_rank_training_matches_averaged_gradient_oracle():
         assert np.array_equal(got[0][1][k], got[1][1][k]), k       # replicas stay bit-identical
         a = torch.from_numpy(got[0][1][k]).double()
         assert float((a - sd[k]).abs().max()) < 2e-3 * max(1.0, float(sd[k].abs().max())), k
+
+
+def _rvae_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    from atomai_amd.parallel import DataParallelGrads, init_distributed
+    init_distributed("gloo")
+    rs = np.random.RandomState(20 + rank)
+    x = rs.rand(4, 16, 16).astype(np.float32)
+    eps = torch.from_numpy(rs.randn(2, 4, 8).astype(np.float32))
+    m = aoi.models.rVAE((16, 16), latent_dim=2, seed=rank, numhidden_encoder=32, numhidden_decoder=32)
+    m.dx_prior, m.kdict_["phi_prior"] = 0.1, 0.1
+    m.compile_trainer((x, None), None, batch_size=4)
+    m.dp = DataParallelGrads(m.optim)                          # broadcast rank 0's parameters
+    state = {"i": 0}
+    m.reparameterize = lambda zm, zs: zm + zs * eps[state["i"]][:, :zm.shape[1]]
+    xt = torch.from_numpy(x)
+    elbos = []
+    for s in range(2):
+        state["i"] = s
+        m.encoder_net.train(), m.decoder_net.train()
+        m.optim.zero_grad()
+        elbo = m.forward_compute_elbo(xt)
+        (-elbo).backward()
+        m.dp.allreduce_grads()
+        m.optim.step()
+        elbos.append(elbo.item())
+    sd = {"enc|" + k: v.detach().numpy().copy() for k, v in m.encoder_net.state_dict().items()}
+    sd.update({"dec|" + k: v.detach().numpy().copy() for k, v in m.decoder_net.state_dict().items()})
+    q.put((rank, elbos, sd))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_rvae_step_matches_averaged_gradient_oracle():
+    """rVAE train step sharded over 2 ranks: ONE all-reduce of the flat gradient bucket."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    from oracle import seg_oracle as so
+    from oracle import vae_oracle as vo
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + os.getpid() % 500
+    procs = [ctx.Process(target=_rvae_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, elbos, sd = q.get(timeout=500)
+        got[r] = (elbos, sd)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in got[0][1]:
+        assert np.array_equal(got[0][1][k], got[1][1][k]), k       # replicas stay bit-identical
+    # oracle: rank 0's initial weights (seed 0), per-rank data / noise, gradients averaged, Adam lr 1e-4
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    m0 = aoi.models.rVAE((16, 16), latent_dim=2, seed=0, numhidden_encoder=32, numhidden_decoder=32)
+    enc = OrderedDict((k, v.detach().double()) for k, v in m0.encoder_net.state_dict().items())
+    dec = OrderedDict((k, v.detach().double()) for k, v in m0.decoder_net.state_dict().items())
+    data = []
+    for r in range(2):
+        rs = np.random.RandomState(20 + r)
+        x = torch.from_numpy(rs.rand(4, 16, 16).astype(np.float32)).double()
+        eps = torch.from_numpy(rs.randn(2, 4, 8).astype(np.float32)).double()
+        data.append((x, eps))
+    opt = so.AdamState(lr=1e-4)
+    ref_elbos = [[], []]
+    grid = vo.imcoordgrid((16, 16), torch.float64)
+    for step in range(2):
+        grads = []
+        for r in range(2):
+            le = {k: v.clone().requires_grad_(True) for k, v in enc.items()}
+            ld = {k: v.clone().requires_grad_(True) for k, v in dec.items()}
+            elbo = vo.rvae_forward_elbo(le, ld, data[r][0], data[r][1][step], grid, True, 0.1, 0.1, False, None,
+                                        num_iter=step + 1)
+            (-elbo).backward()
+            ref_elbos[r].append(float(elbo))
+            g = {"dec|" + k: v.grad for k, v in ld.items()}
+            g.update({"enc|" + k: v.grad for k, v in le.items()})
+            grads.append(g)
+        avg = {k: 0.5 * (grads[0][k] + grads[1][k]) for k in grads[0]}
+        allp = {"dec|" + k: v for k, v in dec.items()}
+        allp.update({"enc|" + k: v for k, v in enc.items()})
+        opt.step(allp, avg)
+        dec = OrderedDict((k, allp["dec|" + k]) for k in dec)
+        enc = OrderedDict((k, allp["enc|" + k]) for k in enc)
+    for r in range(2):
+        np.testing.assert_allclose(got[r][0], ref_elbos[r], rtol=1e-4)
+    for k, v in list(enc.items()):
+        a = torch.from_numpy(got[0][1]["enc|" + k]).double()
+        assert float((a - v).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
+    for k, v in list(dec.items()):
+        a = torch.from_numpy(got[0][1]["dec|" + k]).double()
+        assert float((a - v).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
