@@ -1,8 +1,7 @@
 """rVAE: rotationally (and translationally) invariant VAE (reference: atomai/models/dgm/rvae.py:22-219)."""
 from copy import deepcopy as dc
-from typing import Optional, Union
+from typing import Optional
 
-import numpy as np
 import torch
 
 from ...losses_metrics import rvae_loss

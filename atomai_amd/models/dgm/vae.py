@@ -1,6 +1,6 @@
 """BaseVAE / VAE (reference: atomai/models/dgm/vae.py:28-221, 594-747)."""
 from copy import deepcopy as dc
-from typing import List, Optional, Tuple, Union
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch

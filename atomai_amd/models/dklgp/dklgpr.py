@@ -1,5 +1,5 @@
 """dklGPR: deep kernel learning GP regression (reference: atomai/models/dklgp/dklgpr.py:23-241)."""
-from typing import Tuple, Union
+from typing import Tuple
 
 import numpy as np
 import torch

@@ -1,7 +1,6 @@
 """Segmentor: sklearn-like user API for semantic segmentation (reference: atomai/models/segmentor.py:10-207)."""
-from typing import Dict, Optional, Tuple, Type, Union
+from typing import Tuple, Type, Union
 
-import numpy as np
 import torch
 
 from ..predictors import SegPredictor

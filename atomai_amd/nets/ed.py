@@ -7,7 +7,7 @@
   kernels of csrc/rdecoder.hip (all hidden activations stay in LDS, forward and backward).
 Module trees / state-dict keys / RNG-order initialisation are those of the reference.
 """
-from typing import Dict, List, Optional, Tuple, Type, Union
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch

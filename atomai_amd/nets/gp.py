@@ -8,7 +8,7 @@ north_star.  The reference wraps the same base kernel in gpytorch's KISS-GP grid
 not vendored, so this layer follows gpytorch's documented closed forms (oracle/gp_oracle.py).
 """
 import math
-from typing import Tuple, Type
+from typing import Type
 
 import torch
 import torch.nn as nn

@@ -10,7 +10,6 @@ a 16-byte-aligned view of the flat parameter buffer, and the tape writes weight 
 views of the flat gradient buffer (``p._amx_grad``), which is also the single bucket the data-parallel
 wrapper all-reduces (parallel.py).
 """
-import math
 from typing import List
 
 import torch

@@ -6,9 +6,8 @@ chunked pipeline: pinned staging buffers, H2D / kernels / D2H of consecutive chu
 streams.  In eval mode BatchNorm uses running statistics, so frames are independent and the result does
 not depend on how the stack is chunked (``num_batches`` keeps its meaning for the caller only).
 """
-import os
 import time
-from typing import Dict, List, Tuple, Type, Union
+from typing import List, Tuple, Type, Union
 
 import numpy as np
 import torch

@@ -7,7 +7,7 @@ multi-GPU node each rank can train its own slice of the ensemble (``member_range
 """
 import warnings
 from copy import deepcopy as dc
-from typing import Callable, Dict, Optional, Tuple, Type, Union
+from typing import Callable, Dict, Tuple, Type, Union
 
 import numpy as np
 import torch

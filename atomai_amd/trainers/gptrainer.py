@@ -1,7 +1,7 @@
 """dklGPTrainer: deep-kernel-learning GP training loop (reference: atomai/trainers/gptrainer.py:144-349).
 Shared-embedding path (``compile_trainer``); the per-output independent-network variant
 (``compile_multi_model_trainer``) is out of this build's scope."""
-from typing import Optional, Tuple, Type, Union
+from typing import Tuple
 
 import numpy as np
 import torch

@@ -5,7 +5,7 @@ DataLoader semantics (shuffle, drop_last, device-resident data), same checkpoint
 flat optimizer (decoder parameters first, as in the reference) and, when a process group is active, the
 flat gradient bucket is all-reduced over RCCL before the step.
 """
-from typing import Callable, Optional, Tuple, Type, Union
+from typing import Callable
 
 import numpy as np
 import torch

@@ -1,6 +1,5 @@
 """Seeds, hooks and weight utilities (reference: atomai/utils/nn.py:59-81, 136-249)."""
 import copy
-import subprocess
 from typing import Dict, Tuple, Type
 
 import numpy as np

@@ -1,7 +1,6 @@
 """numpy -> tensor plumbing for Segmentor training / prediction
 (reference: atomai/utils/preproc.py:18-74, 138-278, 365-421, 798-825)."""
 import warnings
-from typing import List, Tuple, Union
 
 import numpy as np
 import torch
