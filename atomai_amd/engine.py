@@ -30,7 +30,7 @@ import os as _os
 #   2: BN-backward sums emitted by the pool / px backward kernels that write the final dy
 #   8: BN-backward sums emitted by the dgrad epilogue that writes the final dy
 # Interleaved in-process A/B on MI355X (tools/gpu_fuse_ab.py, U-Net bs 32 512^2, ms/step, min of 3):
-#   0: 22.30   2: 22.11   8: 22.90   10: 22.04   5: 23.35   15: 22.98
+#   0: 20.76   2: 20.22   10: 21.22   15: 22.40      (earlier, noisier harness: 0: 22.30  2: 22.11  8: 22.90  5: 23.35)
 # -> moving the HBM-bound BatchNorm-backward passes INTO the MFMA kernels costs them more (registers ->
 #    fewer co-resident workgroups, exposed load latency) than the removed passes save; only the sums emitted
 #    by the pool / px backward kernels are kept by default.
