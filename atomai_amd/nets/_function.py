@@ -11,6 +11,7 @@ class _TapeFn(torch.autograd.Function):
     def forward(ctx, build, training, x, *params):
         tape = Tape(training, True)
         in_node, out_node = build(tape, x)
+        tape.end_forward()
         ctx.tape, ctx.in_node, ctx.out_node, ctx.params = tape, in_node, out_node, params
         # The returned tensor will own this Function's grad_fn, which owns ctx: keeping it reachable from ctx
         # (ctx -> out_node -> value) would close a reference cycle through the C++ autograd node, and the step's
@@ -37,5 +38,7 @@ def run_tape(build: Callable, x: torch.Tensor, params: Sequence[torch.Tensor], t
     need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
     if not need:
         tape = Tape(training, False)
-        return build(tape, x)[1].value
+        value = build(tape, x)[1].value
+        tape.end_forward()
+        return value
     return _TapeFn.apply(build, training, x, *params)
