@@ -96,22 +96,57 @@ class Act:
 class _PackCache:
     """Packed weight images keyed by (tensor identity, layout), valid for one (storage, version, optimizer
     generation).  Entries hold only a weak reference to the parameter: they die with it, and an `id()` that gets
-    reused by a later tensor can never produce a stale hit."""
+    reused by a later tensor can never produce a stale hit.
+
+    Weight images (entries with a layout `meta`) are refreshed TOGETHER: the first miss after an optimizer step
+    re-packs every image used during the previous generation in place with one batched launch per 8 layers
+    (`amx_pack_weights_batch`), instead of 30 small launches scattered between the convolutions of the step."""
 
     def __init__(self):
-        self.store: Dict[tuple, tuple] = {}
+        self.store: Dict[tuple, list] = {}          # key -> [ver, value, weakref, meta, last generation used]
+        self.refreshed_gen = -1
 
-    def get(self, w: torch.Tensor, key_extra: tuple, build):
+    @staticmethod
+    def _ver(w):
+        return (w.data_ptr(), w._version, _weight_generation[0])
+
+    def get(self, w: torch.Tensor, key_extra: tuple, build, meta=None):
         key = (id(w),) + key_extra
-        ver = (w.data_ptr(), w._version, _weight_generation[0])
+        gen = _weight_generation[0]
         hit = self.store.get(key)
-        if hit is not None and hit[0] == ver and hit[2]() is w:
-            return hit[1]
+        if hit is not None and hit[2]() is w:
+            if hit[0] != self._ver(w) and meta is not None and self.refreshed_gen != gen:
+                self._refresh_all(w.device)
+            if hit[0] == self._ver(w):
+                hit[4] = gen
+                return hit[1]
         val = build()
         if len(self.store) > 4096:                               # long sessions (ensembles): drop dead entries
             self.store = {k: v for k, v in self.store.items() if v[2]() is not None}
-        self.store[key] = (ver, val, weakref.ref(w))
+        self.store[key] = [self._ver(w), val, weakref.ref(w), meta, gen]
         return val
+
+    def _refresh_all(self, device) -> None:
+        gen = _weight_generation[0]
+        self.refreshed_gen = gen
+        if _os.environ.get("AMX_PACK_BATCH", "1") == "0":       # experiment switch: per-layer packing only
+            return
+        jobs = []
+        for ent in self.store.values():
+            w = ent[2]()
+            if (w is None or ent[3] is None or ent[4] < gen - 1 or w.device != device
+                    or ent[0] == self._ver(w)):
+                continue
+            jobs.append((ent, w))
+        if not jobs:
+            return
+        n = len(jobs)
+        wp = (ctypes.c_void_p * n)(*[w.data_ptr() for _, w in jobs])
+        dp = (ctypes.c_void_p * n)(*[ent[1].data_ptr() for ent, _ in jobs])
+        desc = (ctypes.c_int * (7 * n))(*[v for ent, w in jobs for v in (w.shape[0],) + tuple(ent[3])])
+        L.call("amx_pack_weights_batch", wp, dp, desc, n, _sp(jobs[0][1]))
+        for ent, w in jobs:
+            ent[0] = self._ver(w)
 
 
 _pack_cache = _PackCache()
@@ -141,7 +176,7 @@ def pack_weights(w: torch.Tensor, C0, C0s, C1, C1s, taps, mode) -> torch.Tensor:
         L.call("amx_pack_weights", L.ptr(w.detach()), L.ptr(dst), w.shape[0], C0, C0s, C1, C1s, taps,
                mode, _sp(w))
         return dst
-    return _pack_cache.get(w, (C0, C0s, C1, C1s, taps, mode), build)
+    return _pack_cache.get(w, (C0, C0s, C1, C1s, taps, mode), build, meta=(C0, C0s, C1, C1s, taps, mode))
 
 
 def padded_vec(v: torch.Tensor, n: int) -> torch.Tensor:

@@ -96,6 +96,9 @@ int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, con
 int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C0, int C0s, int C1, int C1s,
                      int taps, int mode, void* stream);
 long amx_pack_weights_size(int cout, int C0s, int C1s, int taps, int mode);
+/* n images in one launch per 8 jobs; w / dst: host arrays of n device pointers, desc: n x (cout, C0, C0s, C1, C1s, taps,
+ * mode) */
+int amx_pack_weights_batch(const void* const* w, void* const* dst, const int* desc, int n, void* stream);
 int amx_nchw_to_nhwc(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
 int amx_nhwc_to_nchw(const float* src, float* dst, int N, int C, int Cs, int H, int W, void* stream);
 int amx_add_inplace(float* dst, const float* src, long n, void* stream);
