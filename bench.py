@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="run every kernel on one stream (no weight-gradient overlap): the mode of the per-kernel "
+                         "HIP-event pass behind `roofline`; used for the rocprofv3 summary that pass must agree with")
     args = ap.parse_args()
 
     import atomai_amd as aoi
@@ -142,6 +145,8 @@ def main():
         model.dp = DataParallelGrads(model.optimizer, model.net)
     timer = None if args.no_kernel_timing else KernelTimer(["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
     from atomai_amd.engine import Tape
+    if args.serial:
+        Tape.use_side_stream = False
 
     def barrier():
         if world > 1:
@@ -180,7 +185,7 @@ def main():
             model.train_step(model.X_train[i % nb], model.y_train[i % nb])
         torch.cuda.synchronize()
         timer.active = False
-        Tape.use_side_stream = True
+        Tape.use_side_stream = not args.serial
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -11,13 +11,14 @@ def short(n):
     return re.sub(r"\(.*", "", n).replace("void ", "")
 
 
-def kernel_stats(steps=7):
-    c = sqlite3.connect(os.path.join(G, "prof", "r01_results.db"))
+def kernel_stats(steps=7, sub="prof", outname="r01_unet_bs32_512_kernel_stats_final.md", note=""):
+    c = sqlite3.connect(os.path.join(G, sub, "r01_results.db"))
     rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
     tot = sum(r[2] for r in rows)
-    out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 (7 training steps), MI355X, round 1\n\n",
-           "U-Net nb_classes=3, 512x512, bs=32, fp32.  Weight-gradient kernels run on a second stream, so kernel times "
-           "overlap and their sum exceeds the step time.\n\n",
+    out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 (7 training steps), MI355X, round 1\n\n", note,
+           "U-Net nb_classes=3, 512x512, bs=32, fp32.  " + ("" if note else "Weight-gradient kernels run on a second stream, "
+           "so kernel times overlap (and are longer than stand-alone) and their sum exceeds the step time; the "
+           "serialised companion is `r01_unet_bs32_512_kernel_stats_serial.md`.") + "\n\n",
            "| kernel | calls | total us | avg us | % | us/step |\n|---|---|---|---|---|---|\n"]
     for n, cl, td, av, pc in rows:
         out.append(f"| `{short(n)[:72]}` | {cl} | {td:.0f} | {av:.1f} | {pc:.2f} | {td / steps:.0f} |\n")
@@ -40,7 +41,11 @@ def kernel_stats(steps=7):
         side = sum(r[2] - r[1] for r in R if r[3] != 0) / 1e6
         out.append(f"\nSteady-state step (5th of the trace): wall {(e1 - s0) / 1e6:.2f} ms, GPU busy (union of kernel intervals) "
                    f"{busy / 1e6:.2f} ms, main-stream kernel time {main:.2f} ms, side-stream (weight gradients) {side:.2f} ms.\n")
-    open(os.path.join(ROOT, "profiles", "r01_unet_bs32_512_kernel_stats_final.md"), "w").writelines(out)
+    fam = [(cl, td) for n, cl, td, av, pc in rows if short(n).startswith("conv_fwd_kernel")]
+    if fam:
+        out.append(f"\nconv_fwd_kernel family (amx_conv2d_fwd + amx_conv2d_dgrad): {sum(c_ for c_, _ in fam)} launches, "
+                   f"average {sum(t for _, t in fam) / sum(c_ for c_, _ in fam) / 1e3:.4f} ms per launch.\n")
+    open(os.path.join(ROOT, "profiles", outname), "w").writelines(out)
 
 
 def pmc_traffic():
@@ -90,4 +95,8 @@ def pmc_traffic():
 
 if __name__ == "__main__":
     kernel_stats()
+    if os.path.exists(os.path.join(G, "prof_serial", "r01_results.db")):
+        kernel_stats(sub="prof_serial", outname="r01_unet_bs32_512_kernel_stats_serial.md",
+                     note="**`--serial`: every kernel on ONE stream** — the mode of bench.py's per-kernel HIP-event pass "
+                          "(`roofline.avg_launch_ms`), which this summary must agree with.\n\n")
     pmc_traffic()
