@@ -157,3 +157,31 @@ def test_kernel_level_large_shapes():
             # of the LeakyReLU kink changes single entries by O(1%) in either implementation
             rel = float((a.view_as(b) - b).norm() / b.norm())
             assert rel < 1e-3, (B, H, C0, C1, Co, a.shape, rel)
+
+
+def test_config3_dilnet_predict_full_size_vs_oracle_on_device():
+    """BASELINE.json configs[2] at full frame size: default dilnet (nb_filters 25), 1024x1024 frames, through
+    SegPredictor's chunked pipeline (several chunks in flight, device-side normalisation, kernel download) against the
+    oracle's eval-mode graph executed with stock torch ops on the same GPU; plus chunk-size independence (bit-exact)."""
+    import atomai_amd as aoi
+    from oracle import seg_oracle as so
+    torch.manual_seed(3)
+    net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
+    with torch.no_grad():                                    # non-trivial BatchNorm running statistics
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
+    rs = np.random.RandomState(5)
+    stack = rs.rand(5, 1024, 1024).astype(np.float32)
+    p = aoi.predictors.SegPredictor(net, use_gpu=True, nb_classes=1, downsampling=2, verbose=False,
+                                    chunk_bytes=8 << 20)      # 2 frames per chunk -> 3 chunks, last one ragged
+    out = p.run(stack, compute_coords=False)
+    assert out.shape == (5, 1024, 1024, 1) and p._norm is not None
+    x = (stack - stack.min()) / np.ptp(stack)                 # the reference's host-side normalisation
+    ref = so.predict_probs("dilnet", OrderedDict((k, v.cuda()) for k, v in sd.items()),
+                           torch.from_numpy(x[:, None]).cuda(), 1).cpu().numpy()
+    assert C.relmax(out, ref.astype(np.float64)) < C.REL_TOL
+    p.chunk_bytes = 64 << 20                                  # one chunk
+    assert np.array_equal(p.run(stack, compute_coords=False), out)
