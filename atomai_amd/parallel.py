@@ -52,5 +52,7 @@ def init_distributed(backend: str = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("AMX_DIST_TIMEOUT_S", "600"))))
     return rank, world, local

@@ -15,6 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def _free_port() -> int:
+    """A TCP port the kernel reports as free right now (a fixed port may be held by another process or still be in
+    TIME_WAIT from an earlier run, which would leave the gloo rendezvous waiting)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(HERE, "emu"))
@@ -44,7 +53,7 @@ def test_two_rank_training_matches_averaged_gradient_oracle():
     from oracle import seg_oracle as so
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 500
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -132,7 +141,7 @@ def test_two_rank_rvae_step_matches_averaged_gradient_oracle():
     sys.path.insert(0, os.path.join(HERE, "emu"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 30100 + os.getpid() % 500
+    port = _free_port()
     procs = [ctx.Process(target=_rvae_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
