@@ -109,3 +109,34 @@ def test_activations_are_freed_without_the_garbage_collector():
     finally:
         engine.Act.__init__ = orig
         gc.enable()
+
+
+@pytest.mark.parametrize("opts", [dict(full_epoch=True), dict(swa=True, full_epoch=True, training_cycles=5),
+                                  dict(lr_scheduler=[1e-3, 5e-4, 1e-4]),
+                                  dict(perturb_weights=True, batch_norm=False),
+                                  dict(optimizer=lambda p: torch.optim.SGD(p, lr=1e-2))])
+def test_trainer_options(tmp_path, opts):
+    """compile_trainer's options (reference: trainers/trainer.py:441-565; test/trainers/test_trainer.py): full-epoch
+    data loaders, stochastic weight averaging, learning-rate schedule, time-dependent weight perturbation, and a stock
+    torch optimizer driving the HIP modules through ordinary autograd."""
+    import warnings
+    import atomai_amd as aoi
+    opts = dict(opts)
+    rs = np.random.RandomState(0)
+    X = rs.rand(6, 16, 16).astype(np.float32)
+    y = rs.randint(0, 3, (6, 16, 16))
+    net_kw = dict(batch_norm=opts.pop("batch_norm")) if "batch_norm" in opts else {}
+    m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, **net_kw)
+    init = {k: v.clone() for k, v in m.net.state_dict().items()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cycles = opts.pop("training_cycles", 3)
+        m.fit(X, y, X, y, training_cycles=cycles, batch_size=2, plot_training_history=False,
+              filename=str(tmp_path / "m"), **opts)
+    assert len(m.loss_acc["train_loss"]) == cycles and all(np.isfinite(m.loss_acc["train_loss"]))
+    moved = [k for k, v in m.net.state_dict().items() if v.is_floating_point() and not torch.equal(v, init[k])]
+    assert moved, "training changed nothing"
+    if "lr_scheduler" in opts:
+        assert m.optimizer.param_groups[0]["lr"] == 1e-4
+    if opts.get("swa"):      # the last 5 epochs are averaged (like the reference, SWA needs >= 5 epochs / 30 iterations)
+        assert sorted(m.running_weights) == [0, 1, 2, 3, 4]
