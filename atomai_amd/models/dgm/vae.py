@@ -83,6 +83,55 @@ class BaseVAE(viBaseTrainer):
             x_decoded = torch.sigmoid(x_decoded)
         return x_decoded.cpu().numpy()
 
+    def reconstruct(self, x_new, **kwargs) -> np.ndarray:
+        """Decodes ``num_samples`` draws from the encoded distribution of ONE input (vae.py:223-271; regular VAE:
+        the coordinate latents are dropped)."""
+        if kwargs.get("label") is not None:
+            raise NotImplementedError("class-conditioned decoding is outside this build's hot path")
+        num_samples = kwargs.get("num_samples", 32)
+        z_mean, z_sd = self.encode(x_new)
+        z_mean = torch.from_numpy(z_mean[:, self.coord:])
+        z_sd = torch.from_numpy(z_sd[:, self.coord:])
+        ndist = torch.distributions.Normal(z_mean, torch.exp(z_sd))
+        return np.concatenate([self.decode(ndist.rsample().view(1, -1)) for _ in range(num_samples)], axis=0)
+
+    def encode_image_(self, img: np.ndarray, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        """Encodes the training-window-sized sub-image around EVERY pixel of a 2-D image (vae.py:300-344); returns the
+        image and its latent map, both cropped to the pixels whose window fits."""
+        from ...utils import crop_borders, extract_subimages, get_coord_grid
+        num_batches = kwargs.get("num_batches", 10)
+        inf = int(1e5)
+        img_to_encode = img.copy()
+        coordinates = get_coord_grid(img_to_encode, 1, return_dict=False)
+        batch_size = coordinates.shape[0] // num_batches
+        encoded_img = -inf * np.ones((*img_to_encode.shape, self.z_dim))
+        bounds = [(i * batch_size, (i + 1) * batch_size) for i in range(num_batches)]
+        bounds.append((num_batches * batch_size, coordinates.shape[0]))
+        for lo, hi in bounds:
+            coord_i = coordinates[lo:hi]
+            if len(coord_i) == 0:
+                continue
+            subimgs_i, com_i, _ = extract_subimages(img_to_encode, coord_i, self.in_dim[0])
+            if len(subimgs_i) > 0:
+                z_mean, _ = self.encode(subimgs_i, num_batches=10)
+                encoded_img[com_i[:, 0].astype(int), com_i[:, 1].astype(int)] = z_mean
+        img_to_encode[encoded_img[..., 0] == -inf] = 0
+        img_to_encode = crop_borders(img_to_encode[..., None], 0)
+        encoded_img = crop_borders(encoded_img, -inf)
+        return img_to_encode[..., 0], encoded_img
+
+    def encode_images(self, imgdata: np.ndarray, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        """``encode_image_`` for every image of a stack (vae.py:273-298)."""
+        if (imgdata.ndim == len(self.in_dim) == 2 or imgdata.ndim == len(self.in_dim) == 3):
+            imgdata = np.expand_dims(imgdata, axis=0)
+        imgs, encoded = [], []
+        for i, img in enumerate(imgdata):
+            print("\rImage {}/{}".format(i + 1, imgdata.shape[0]), end="")
+            img_, enc_ = self.encode_image_(img, **kwargs)
+            imgs.append(img_)
+            encoded.append(enc_)
+        return np.array(imgs), np.array(encoded)
+
     def _check_inputs(self, X_train, y_train=None, X_test=None, y_test=None) -> None:
         if self.in_dim != X_train.shape[1:]:
             raise RuntimeError("The values of input dimensions you specified do not match "

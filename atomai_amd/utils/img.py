@@ -1,4 +1,7 @@
-"""Image helpers on the predict path (reference: atomai/utils/img.py:112-135)."""
+"""Image helpers on the predict path and between Segmentor predictions and VAE training stacks
+(reference: atomai/utils/img.py:112-180, 298-350, 502-551)."""
+from typing import Dict, Tuple, Union
+
 import numpy as np
 
 
@@ -14,3 +17,72 @@ def img_pad(image_data: np.ndarray, pooling: int) -> np.ndarray:
     out = np.zeros((n, H, W), dtype=np.result_type(image_data.dtype, np.float64))
     out[:, :h, :w] = image_data
     return out
+
+
+def get_imgstack(imgdata: np.ndarray, coord: np.ndarray, r: int) -> Tuple[np.ndarray]:
+    """Square windows of side ``r`` around the given (row, col) centres of ONE image (h, w, c); centres whose window
+    sticks out of the image or contains NaN are dropped (img.py:138-180).  Vectorised: one fancy-indexing gather
+    instead of a Python loop over the centres."""
+    coord = np.asarray(coord)
+    if len(coord) == 0:
+        return None, None
+    r = int(r)
+    centres = np.around(coord[:, :2]).astype(np.int64)
+    lo = centres - r // 2
+    hi = lo + r                                      # odd r: [c - r//2, c + r//2]; even r: [c - r//2, c + r//2 - 1]
+    h, w = imgdata.shape[:2]
+    ok = (lo[:, 0] >= 0) & (lo[:, 1] >= 0) & (hi[:, 0] <= h) & (hi[:, 1] <= w)
+    if not ok.any():
+        return None, None
+    rows = lo[ok, 0][:, None] + np.arange(r)[None, :]
+    cols = lo[ok, 1][:, None] + np.arange(r)[None, :]
+    stack = imgdata[rows[:, :, None], cols[:, None, :]]
+    kept = coord[ok]
+    finite = ~np.isnan(stack.reshape(len(stack), -1)).any(axis=1)
+    if not finite.any():
+        return None, None
+    return stack[finite], kept[finite]
+
+
+def extract_subimages(imgdata: np.ndarray, coordinates: Union[Dict[int, np.ndarray], np.ndarray],
+                      window_size: int, coord_class: int = 0) -> Tuple[np.ndarray]:
+    """Sub-images centred on the detected objects of one class, for every frame (img.py:298-350): returns
+    (stack, centres, frame numbers) — the usual bridge from ``Segmentor.predict`` output to ``rVAE.fit`` input."""
+    if isinstance(coordinates, np.ndarray):
+        coordinates = {0: np.concatenate((coordinates, np.zeros((coordinates.shape[0], 1))), axis=-1)}
+    if np.ndim(imgdata) == 2:
+        imgdata = imgdata[None, ..., None]
+    subimages_all, com_all, frames_all = [], [], []
+    for i, (img, coord) in enumerate(zip(imgdata, coordinates.values())):
+        coord_i = coord[np.where(coord[:, 2] == coord_class)][:, :2]
+        stack_i, com_i = get_imgstack(img, coord_i, window_size)
+        if stack_i is None:
+            continue
+        subimages_all.append(stack_i)
+        com_all.append(com_i)
+        frames_all.append(np.ones(len(com_i), int) * i)
+    if len(subimages_all) > 0:
+        subimages_all = np.concatenate(subimages_all, axis=0)
+        com_all = np.concatenate(com_all, axis=0)
+        frames_all = np.concatenate(frames_all, axis=0)
+    return subimages_all, com_all, frames_all
+
+
+def crop_borders(imgdata: np.ndarray, thresh: float = 0) -> np.ndarray:
+    """Drops the border rows / columns of an (h, w, c) array whose values are all <= thresh (img.py:502-519)."""
+    def crop(img):
+        mask = img > thresh
+        return img[np.ix_(mask.any(1), mask.any(0))]
+    return np.array([crop(imgdata[..., i]) for i in range(imgdata.shape[-1])]).transpose(1, 2, 0)
+
+
+def get_coord_grid(imgdata: np.ndarray, step: int, return_dict: bool = True):
+    """Square grid of coordinates for every image of a stack, in the Locator's output format (img.py:522-551)."""
+    if np.ndim(imgdata) == 2:
+        imgdata = np.expand_dims(imgdata, axis=0)
+    ii, jj = np.meshgrid(np.arange(0, imgdata.shape[1], step), np.arange(0, imgdata.shape[2], step), indexing="ij")
+    coord = np.stack((ii.ravel(), jj.ravel()), axis=1)
+    if return_dict:
+        coord = np.concatenate((coord, np.zeros((coord.shape[0], 1))), axis=-1)
+        return {i: coord for i in range(imgdata.shape[0])}
+    return np.concatenate([coord for _ in range(imgdata.shape[0])], axis=0)

@@ -412,11 +412,53 @@ def make_ensemble(aoi):
     print("ensemble ok", out["scratch|last_train_loss"], out["ens_meta_keys"])
 
 
+def make_vae_api(aoi):
+    """extract_subimages / get_coord_grid / crop_borders (utils/img.py) and BaseVAE.encode_images / reconstruct."""
+    from atomai.utils import extract_subimages, get_coord_grid, crop_borders
+    out = {}
+    rs = np.random.RandomState(51)
+    img = rs.rand(2, 20, 24, 2).astype(np.float32)
+    coords = {0: np.array([[3.2, 4.7, 0], [0.4, 1.0, 0], [10.5, 12.49, 1], [18.9, 22.0, 0], [9.0, 9.0, 0]]),
+              1: np.array([[8.0, 8.0, 0], [15.6, 3.3, 0]])}
+    out["img"] = img
+    for k, v in coords.items():
+        out[f"coords|{k}"] = v
+    for ws in (5, 6):
+        st, com, fr = extract_subimages(img, coords, ws)
+        out[f"sub|{ws}|stack"], out[f"sub|{ws}|com"], out[f"sub|{ws}|frames"] = st, com, fr
+    out["grid3"] = get_coord_grid(img[..., 0], 3, return_dict=False)
+    out["grid_dict2"] = get_coord_grid(img[0, ..., 0], 7)[0]
+    z = -np.ones((9, 11, 2)); z[2:7, 3:9] = rs.rand(5, 6, 2)
+    out["crop_in"], out["crop_out"] = z, crop_borders(z, -1)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        v = aoi.models.VAE((8, 8), latent_dim=2, seed=0, numhidden_encoder=16, numhidden_decoder=16)
+        X = rs.rand(12, 8, 8).astype(np.float32)
+        v.fit(X, training_cycles=2, batch_size=4, filename="vapi")
+        for k, t in v.encoder_net.state_dict().items():
+            out[f"enc|{k}"] = t.numpy().copy()
+        for k, t in v.decoder_net.state_dict().items():
+            out[f"dec|{k}"] = t.numpy().copy()
+        big = rs.rand(14, 17).astype(np.float32)
+        out["big"] = big
+        im_, enc_ = v.encode_image_(big, num_batches=3)
+        out["encimg|img"], out["encimg|z"] = im_, enc_
+        ims, encs = v.encode_images(np.stack([big, big[::-1].copy()]), num_batches=4)
+        out["encimgs|img"], out["encimgs|z"] = ims, encs
+        torch.manual_seed(3)
+        out["recon"] = v.reconstruct(X[:1], num_samples=4)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "vae_api.npz"), **out)
+    print("vae_api ok", out["encimg|z"].shape, out["recon"].shape)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api}[w](aoi)
     print("done ->", GOLD)

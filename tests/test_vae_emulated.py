@@ -56,3 +56,35 @@ def test_rvae_fit_api(tmp_path):
     ck = torch.load(str(tmp_path / "rv.tar"), weights_only=False)
     assert {"encoder", "decoder", "optimizer", "num_iter"} <= set(ck.keys())
     assert m.decode(np.array([0.0, 0.0], dtype=np.float32)).shape == (1, 8, 8)
+
+
+def test_subimage_utilities_and_encode_images(golden_dir):
+    """Bridge utilities between Segmentor output and VAE input (utils/img.py: extract_subimages, get_coord_grid,
+    crop_borders) and BaseVAE.encode_image_ / encode_images / reconstruct, against the reference golden."""
+    from collections import OrderedDict
+    import atomai_amd as aoi
+    from atomai_amd.utils import crop_borders, extract_subimages, get_coord_grid
+    g = np.load(os.path.join(golden_dir, "vae_api.npz"))
+    coords = {k: g[f"coords|{k}"] for k in (0, 1)}
+    for ws in (5, 6):
+        st, com, fr = extract_subimages(g["img"], coords, ws)
+        assert np.array_equal(st, g[f"sub|{ws}|stack"]) and np.array_equal(com, g[f"sub|{ws}|com"])
+        assert np.array_equal(fr, g[f"sub|{ws}|frames"])
+    assert np.array_equal(get_coord_grid(g["img"][..., 0], 3, return_dict=False), g["grid3"])
+    assert np.array_equal(get_coord_grid(g["img"][0, ..., 0], 7)[0], g["grid_dict2"])
+    assert np.array_equal(crop_borders(g["crop_in"], -1), g["crop_out"])
+    st, com, fr = extract_subimages(g["img"], {0: np.zeros((0, 3)), 1: np.array([[0.0, 0.0, 0.0]])}, 5)
+    assert len(st) == 0                                            # nothing fits: empty lists, as the reference
+
+    v = aoi.models.VAE((8, 8), latent_dim=2, seed=0, numhidden_encoder=16, numhidden_decoder=16)
+    v.encoder_net.load_state_dict(OrderedDict((k[4:], torch.from_numpy(g[k])) for k in g.files if k.startswith("enc|")))
+    v.decoder_net.load_state_dict(OrderedDict((k[4:], torch.from_numpy(g[k])) for k in g.files if k.startswith("dec|")))
+    im_, enc_ = v.encode_image_(g["big"], num_batches=3)
+    assert np.array_equal(im_, g["encimg|img"])
+    np.testing.assert_allclose(enc_, g["encimg|z"], rtol=1e-4, atol=1e-6)
+    ims, encs = v.encode_images(np.stack([g["big"], g["big"][::-1].copy()]), num_batches=4)
+    assert np.array_equal(ims, g["encimgs|img"])
+    np.testing.assert_allclose(encs, g["encimgs|z"], rtol=1e-4, atol=1e-6)
+    torch.manual_seed(3)
+    rec = v.reconstruct(g["big"][:8, :8][None], num_samples=4)
+    assert rec.shape == g["recon"].shape
