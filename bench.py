@@ -5,22 +5,36 @@
 
 A "step" is one full training step of the reference's hot loop (atomai/trainers/trainer.py:189-211):
 zero_grad -> forward -> CE loss -> backward -> [RCCL all-reduce of the flat gradient bucket] -> Adam ->
-loss.item().  Synthetic data (uniform images, random labels, RandomState(0)), random-init weights
-(seed 1), inputs resident in HBM before the timed region.  N>1: one process per GPU (torchrun
-contract), weak scaling (bs=32 per GPU), value = images of all ranks / max-over-ranks time.
+loss.item().  Synthetic data (uniform images, random labels, RandomState(rank)), random-init weights
+(seed 1), inputs resident in HBM before the timed region.
+
+Launching.  `python bench.py --gpus N` works both ways:
+  * under a launcher (torch.distributed.run / torchrun): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read
+    from the environment, one rank per GPU;
+  * plain (no WORLD_SIZE in the environment) with N > 1: this process spawns the N ranks itself
+    (127.0.0.1 rendezvous on a free port) and relays rank 0's JSON line.
+Weak scaling (bs=32 per GPU); value = images of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     – the dominant kernel family (MFMA direct convolution: forward + dgrad launches), timed
-                 with HIP events on the launch stream over the timed region; algorithmic FLOPs =
-                 2*Cin*Cout*k^2*H*W per conv launch (UpsampleBlock 1x1 convs counted at the LOW
-                 resolution they are executed at); peak = 157.3 TFLOP/s fp32 MFMA.
-  cpu_baseline – oracle/seg_oracle.py (the CPU restatement through stock PyTorch CPU ops) timed on the
-                 host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      – the dominant kernel family (MFMA direct convolution: forward + dgrad launches), timed
+                  with HIP events on the launch stream; algorithmic FLOPs = 2*Cin*Cout*k^2*H*W per conv
+                  launch (UpsampleBlock 1x1 convs counted at the LOW resolution they are executed at,
+                  SURVEY.md §8-d); peak = 157.3 TFLOP/s fp32 MFMA.
+  sustained     – the same step repeated for >= --sustain-seconds after the timed region (steady-state
+                  clocks): images/s, min/median/max step, shader clock samples when sysfs exposes them.
+  extra_configs – bounded one-liners for BASELINE.json configs[2..4] (dilnet predict, rVAE step, DKL
+                  covariance) timed in the same process (N=1 only).
+  cpu_baseline  – oracle/seg_oracle.py (the CPU restatement through stock PyTorch CPU ops) timed on the
+                  host cores at the best thread count of a small sweep (rank 0, N=1 only).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -32,6 +46,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
 H = W = 512
 BS = 32
+PMC_FILE = "profiles/r02_pmc_hbm_traffic.json"
 
 
 def unet_conv_table(nb_filters=16, nb_classes=3, hw=512):
@@ -45,9 +60,9 @@ def unet_conv_table(nb_filters=16, nb_classes=3, hw=512):
             ("up3", 2 * f, f, 1, hw // 2), ("c6.0", 2 * f, f, 9, hw), ("px", f, nb_classes, 1, hw)]
 
 
-def step_flops(bs):
-    fwd = sum(2.0 * ci * co * t * h * h for _, ci, co, t, h in unet_conv_table())
-    first = 2.0 * 1 * 16 * 9 * 512 * 512
+def step_flops(bs, nb_filters=16, hw=512):
+    fwd = sum(2.0 * ci * co * t * h * h for _, ci, co, t, h in unet_conv_table(nb_filters, 3, hw))
+    first = 2.0 * 1 * nb_filters * 9 * hw * hw
     return bs * (3 * fwd - first)           # fwd + dgrad + wgrad, no dgrad for the image itself
 
 
@@ -94,24 +109,126 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(sample_bs=8, steps=2):
-    """Oracle (CPU restatement, stock PyTorch CPU ops) train step on a bounded sample of the workload."""
+def physical_cores():
+    """Physical core count of the host (unique (package, core) pairs); falls back to os.cpu_count()."""
+    try:
+        seen = set()
+        for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology"):
+            seen.add((open(os.path.join(d, "physical_package_id")).read().strip(),
+                      open(os.path.join(d, "core_id")).read().strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count()
+
+
+def cpu_baseline(hw=H, budget_s=45.0):
+    """Oracle (CPU restatement, stock PyTorch CPU ops) train step on a bounded sample of the workload, at the
+    BEST thread count of a small sweep (an oversubscribed 256-thread run is ~18x slower than 8 threads)."""
     from oracle import seg_oracle as so
-    torch.set_num_threads(os.cpu_count())
     rs = np.random.RandomState(0)
-    x = torch.from_numpy(rs.rand(sample_bs, 1, H, W).astype(np.float32))
-    y = torch.from_numpy(rs.randint(0, 3, (sample_bs, H, W)))
+    sample_bs = 8
+    x = torch.from_numpy(rs.rand(sample_bs, 1, hw, hw).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, 3, (sample_bs, hw, hw)))
     sd = so.init_unet(3, 16, seed=1)
     opt = so.AdamState(lr=1e-3)
-    so.train_step("Unet", sd, opt, x, y, 3)                 # warm-up
-    t0 = time.time()
-    for _ in range(steps):
+    phys = physical_cores()
+    cands = sorted({t for t in (8, 16, 32, 64, phys) if t and t <= (os.cpu_count() or 1)})
+    t_begin = time.time()
+    sweep = {}
+    probe = (x[:2], y[:2])
+    for t in cands:
+        torch.set_num_threads(t)
+        so.train_step("Unet", sd, opt, *probe, 3)             # warm-up at this thread count
+        t0 = time.time()
+        so.train_step("Unet", sd, opt, *probe, 3)
+        sweep[t] = round(2 / (time.time() - t0), 3)
+        if time.time() - t_begin > budget_s * 0.5:
+            break
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    so.train_step("Unet", sd, opt, x, y, 3)                   # warm-up
+    steps, t0 = 0, time.time()
+    while steps < 2 or (steps < 6 and time.time() - t_begin < budget_s):
         so.train_step("Unet", sd, opt, x, y, 3)
+        steps += 1
     dt = time.time() - t0
-    return {"value": round(sample_bs * steps / dt, 3), "unit": "images/s", "cores": os.cpu_count(),
-            "kind": "port",
-            "sample": f"{steps} U-Net train steps (fwd+bwd+Adam) at bs={sample_bs}, 512x512, fp32, "
-                      f"torch CPU ops, {os.cpu_count()} threads"}
+    return {"value": round(sample_bs * steps / dt, 3), "unit": "images/s", "cores": best, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "host_physical_cores": phys,
+            "thread_sweep_images_per_s_bs2": {str(k): v for k, v in sweep.items()},
+            "sample": f"{steps} U-Net train steps (fwd+bwd+Adam) at bs={sample_bs}, {hw}x{hw}, fp32, "
+                      f"torch CPU ops, {best} threads (best of the sweep)"}
+
+
+class ClockSampler(threading.Thread):
+    """Samples the shader clock (sysfs pp_dpm_sclk, the entry marked '*') once a second while running."""
+
+    def __init__(self, local=0):
+        super().__init__(daemon=True)
+        self.samples, self._stop_ev = [], threading.Event()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.path = cards[min(local, len(cards) - 1)] if cards else None
+
+    def read(self):
+        if not self.path:
+            return None
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            return None
+        return None
+
+    def run(self):
+        while not self._stop_ev.wait(1.0):
+            v = self.read()
+            if v is not None:
+                self.samples.append(v)
+
+    def stop(self):
+        self._stop_ev.set()
+
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU) from here."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AMX_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def extra_configs():
+    """Bounded samples of BASELINE.json configs[2..4], each timed by its own harness in tools/bench_extra.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_extra as bx
+    out = {}
+    for key, fn, kw in (("config3_dilnet_predict_1024", bx.bench_predict, dict(frames=64)),
+                        ("config4_rvae_bs512_64x64", bx.bench_rvae, dict(steps=20, warmup=3)),
+                        ("config5_dkl_rbf_n16384", bx.bench_dkl, dict())):
+        t0 = time.perf_counter()
+        try:
+            r = fn(emit=False, **kw)
+            r["wall_s"] = round(time.perf_counter() - t0, 2)
+        except Exception as e:                               # an extra must never take the headline line down
+            r = {"error": f"{type(e).__name__}: {e}"}
+        out[key] = r
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -119,31 +236,58 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
+                    help="length of the steady-state leg after the timed region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2..4] one-liners")
     ap.add_argument("--serial", action="store_true",
                     help="run every kernel on one stream (no weight-gradient overlap): the mode of the per-kernel "
                          "HIP-event pass behind `roofline`; used for the rocprofv3 summary that pass must agree with")
+    # ---- test-only overrides (a line produced with any of them carries "headline": false)
+    ap.add_argument("--hw", type=int, default=H, help="TEST ONLY: image size")
+    ap.add_argument("--bs", type=int, default=BS, help="TEST ONLY: batch size per GPU")
+    ap.add_argument("--nb-filters", type=int, default=16, help="TEST ONLY: U-Net width")
+    ap.add_argument("--test-backend", choices=["emu"], default=None,
+                    help="TEST ONLY: run the kernels on the CPU emulator of tests/emu over gloo (no GPU)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
+    emu = args.test_backend == "emu"
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import emu_backend
+        emu_backend.use_emulator()
+    elif not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback (tests use --test-backend emu)")
     import atomai_amd as aoi
     from atomai_amd.parallel import DataParallelGrads, init_distributed
-    rank, world, local = init_distributed()
+    rank, world, local = init_distributed("gloo" if emu else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    hw, bs = args.hw, args.bs
+    headline = (hw, bs, args.nb_filters) == (H, BS, 16) and not emu
+    if not emu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cpu") if emu else torch.device("cuda", local)
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
 
     rs = np.random.RandomState(rank)                         # a different shard per rank
     nb = 2                                                   # distinct mini-batches resident per GPU
-    X = rs.rand(nb * BS, H, W).astype(np.float32)
-    y = rs.randint(0, 3, (nb * BS, H, W))
-    model = aoi.models.Segmentor("Unet", nb_classes=3, seed=1)
-    model.compile_trainer((X, y, X[:BS], y[:BS]), loss="ce", training_cycles=args.steps + args.warmup,
-                          batch_size=BS, plot_training_history=False)
+    X = rs.rand(nb * bs, hw, hw).astype(np.float32)
+    y = rs.randint(0, 3, (nb * bs, hw, hw))
+    model = aoi.models.Segmentor("Unet", nb_classes=3, seed=1, nb_filters=args.nb_filters)
+    model.compile_trainer((X, y, X[:bs], y[:bs]), loss="ce", training_cycles=args.steps + args.warmup,
+                          batch_size=bs, plot_training_history=False)
     if world > 1:
         model.dp = DataParallelGrads(model.optimizer, model.net)
-    timer = None if args.no_kernel_timing else KernelTimer(["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
+    timer = None if (args.no_kernel_timing or emu) else KernelTimer(
+        ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
     from atomai_amd.engine import Tape
     if args.serial:
         Tape.use_side_stream = False
@@ -151,77 +295,124 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def one_step(i):
+        return model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0]
 
     losses = []
     wmarks = [time.perf_counter()]
     for i in range(args.warmup):
-        losses.append(model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0])
+        losses.append(one_step(i))
         wmarks.append(time.perf_counter())
     barrier()
-    ms0 = torch.cuda.memory_stats(dev)
+    ms0 = torch.cuda.memory_stats(dev) if not emu else {}
     t0 = time.perf_counter()
     marks = [t0]
     for i in range(args.steps):
-        losses.append(model.train_step(model.X_train[i % nb], model.y_train[i % nb])[0])
+        losses.append(one_step(i))
         marks.append(time.perf_counter())                    # loss.item() already synchronised this step
     barrier()
     elapsed = time.perf_counter() - t0
     per_step = np.diff(marks) * 1e3
-    ms1 = torch.cuda.memory_stats(dev)
+    ms1 = torch.cuda.memory_stats(dev) if not emu else {}
     alloc_info = {"hipMalloc_calls_in_timed_region": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
                   "hipFree_calls_in_timed_region": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
                   "reserved_GB": round(ms1.get("reserved_bytes.all.current", 0) / 1e9, 2),
                   "peak_allocated_GB": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- sustained leg: the same step for >= sustain-seconds (every rank runs the same, pre-agreed step count)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(np.ceil(args.sustain_seconds / (elapsed / args.steps))))
+        clk = ClockSampler(local)
+        clk0 = clk.read()
+        clk.start()
+        barrier()
+        s0 = time.perf_counter()
+        smarks = [s0]
+        for i in range(n_sus):
+            one_step(i)
+            smarks.append(time.perf_counter())
+        barrier()
+        s_el = time.perf_counter() - s0
+        clk.stop()
+        if world > 1:
+            t = torch.tensor([s_el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            s_el = float(t.item())
+        sp = np.diff(smarks) * 1e3
+        sustained = {"seconds": round(s_el, 2), "steps": n_sus, "images_per_s": round(world * bs * n_sus / s_el, 2),
+                     "ms_per_step": round(s_el / n_sus * 1e3, 3),
+                     "step_ms_min_median_max": [round(float(sp.min()), 3), round(float(np.median(sp)), 3),
+                                                round(float(sp.max()), 3)],
+                     "step_ms_p99": round(float(np.percentile(sp, 99)), 3),
+                     "sclk_mhz_idle_then_samples": ([clk0] + clk.samples) if clk0 is not None else None}
+
     ksteps = 0
     if timer:                      # every rank takes part (the step contains the gradient all-reduce)
-        # Per-kernel HIP-event pass, in the same run right after the timed region: the step normally overlaps
+        # Per-kernel HIP-event pass, in the same run after the timed regions: the step normally overlaps
         # the weight-gradient kernels with HBM-bound kernels on a second stream, which makes per-launch event
         # durations meaningless, so this pass serialises everything on one stream (it does not enter `value`).
         Tape.use_side_stream = False
         ksteps = min(args.steps, 5)
         timer.active = True
         for i in range(ksteps):
-            model.train_step(model.X_train[i % nb], model.y_train[i % nb])
-        torch.cuda.synchronize()
+            one_step(i)
+        sync()
         timer.active = False
         Tape.use_side_stream = not args.serial
     barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
     if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()              # rank 0 may still be formatting; leave together
         return
     ms = elapsed / args.steps * 1e3
-    value = world * BS * args.steps / elapsed
-    fl = step_flops(BS)
+    value = world * bs * args.steps / elapsed
+    fl = step_flops(bs, args.nb_filters, hw)
     out = {
         "metric": "training images/sec (512x512, bs=32/GPU) U-Net Segmentor",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Segmentor U-Net nb_classes=3, 512x512, bs=32/GPU, fp32, CE loss, Adam 1e-3 "
+        "config": {"workload": f"Segmentor U-Net nb_classes=3, {hw}x{hw}, bs={bs}/GPU, fp32, CE loss, Adam 1e-3 "
                                "(BASELINE.json configs[1]); step = fwd+bwd+allreduce+Adam+loss.item()",
-                   "global_batch": world * BS, "parallelism": f"dp{world}",
+                   "global_batch": world * bs, "parallelism": f"dp{world}",
+                   "world_size_seen": world,
+                   "collective_backend": ("gloo (test emulator)" if emu else ("nccl (RCCL)" if world > 1 else None)),
+                   "launcher": "self" if os.environ.get("AMX_BENCH_SELF_LAUNCHED") else
+                               ("torchrun" if "WORLD_SIZE" in os.environ else "single"),
                    "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]},
+        "headline": headline,
         "step_ms_median_max": [round(float(np.median(per_step)), 3), round(float(per_step.max()), 3)],
         "allocator": alloc_info,
         "step_ms_all": [round(float(v), 1) for v in list(np.diff(wmarks) * 1e3) + list(per_step)],
         "step_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_mfma_f32_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32, 4),
     }
+    if emu:
+        out["backend"] = "CPU emulator of the kernel sources (tests only; not a measurement)"
+    if sustained:
+        sustained["agrees_with_value_within"] = round(abs(sustained["images_per_s"] / value - 1.0), 4)
+        out["sustained"] = sustained
     if timer:
         summ = timer.summarize()
         conv = summ.get("amx_conv2d_fwd")
         if conv:
             ach = conv["flops"] / (conv["total_ms"] * 1e-3) / 1e12
-            traffic = None                   # HBM bytes per launch from the committed rocprofv3 PMC pass
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            traffic, tsrc = None, None       # HBM bytes per launch: rocprofv3 PMC pass committed under profiles/
+            pmc = os.path.join(ROOT, PMC_FILE)
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc))["conv_fwd_family"]["hbm_MB_per_launch"] * 1e6
+                pj = json.load(open(pmc))
+                traffic = pj["conv_fwd_family"]["hbm_MB_per_launch"] * 1e6
+                tsrc = f"{PMC_FILE}@{pj.get('git_head', 'unknown')} (separate rocprofv3 --pmc pass, not this run)"
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
                                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic,
+                               "traffic_source": tsrc,
                                "kernel": "conv_fwd_kernel<TAPS,NT,HALO> (amx_conv2d_fwd: all forward + dgrad "
                                          "launches of the step)",
                                "launches_per_step": conv["calls"] // ksteps,
@@ -235,9 +426,16 @@ def main():
                                      "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
                                      "kernel": "wgrad_kernel<TAPS,NT,WM,HALO> (amx_conv2d_wgrad)",
                                      "ms_per_step": round(wg["total_ms"] / ksteps, 3)}
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    if world == 1 and not emu:
+        del model
+        torch.cuda.empty_cache()
+        if not args.no_extra:
+            out["extra_configs"] = extra_configs()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def timed_calls(names):
     return recs
 
 
-def bench_rvae(steps=10, warmup=3, B=512):
+def bench_rvae(steps=10, warmup=3, B=512, emit=True):
     rs = np.random.RandomState(0)
     X = rs.rand(B * 2, 64, 64).astype(np.float32)
     m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
@@ -60,11 +60,12 @@ def bench_rvae(steps=10, warmup=3, B=512):
                         "frac": round(3 * fl_fwd / (tb * 1e-3) / 1e12 / PEAK, 4), "ms": round(tb, 3)},
            "roofline_fwd": {"kernel": "rdecoder_fwd_kernel<128,128>", "achieved": round(fl_fwd / (tf * 1e-3) / 1e12, 2),
                             "frac": round(fl_fwd / (tf * 1e-3) / 1e12 / PEAK, 4), "ms": round(tf, 3)}}
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
     return out
 
 
-def bench_predict(frames=256, hw=1024):
+def bench_predict(frames=256, hw=1024, emit=True):
     """configs[2] on a bounded stack: dilnet nb_classes=1 predict over `frames` 1024x1024 frames."""
     torch.manual_seed(1)
     net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
@@ -88,11 +89,12 @@ def bench_predict(frames=256, hw=1024):
            "device_only_ms_per_frame": round(dk * 1e3, 3),
            "device_tflops": round(91.62e9 / dk / 1e12, 2), "device_frac_of_mfma_peak": round(91.62e9 / dk / 1e12 / PEAK, 4),
            "out_shape": list(out.shape)}
-    print(json.dumps(res), flush=True)
+    if emit:
+        print(json.dumps(res), flush=True)
     return res
 
 
-def bench_dkl(N=16384, D=2):
+def bench_dkl(N=16384, D=2, emit=True):
     """configs[4]: RBF covariance on N=16384 embedded points — HBM-write bound (4*N^2 bytes)."""
     from atomai_amd.nets.gp import kernel_matrix, kernel_matvec, convFeatureExtractor
     rs = np.random.RandomState(0)
@@ -130,7 +132,8 @@ def bench_dkl(N=16384, D=2):
            "higher_is_better": False,
            "roofline": {"bound": "hbm", "achieved": res["f32"]["GBps"], "peak": 8000, "unit": "GB/s",
                         "frac": res["f32"]["frac_of_8TBps"], "traffic": None}, "detail": res}
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
     return out
 
 
@@ -149,7 +152,7 @@ def _conv_flops(name, a):
     return 0.0
 
 
-def bench_segfamily(models=("SegResNet", "ResHedNet", "dilnet"), hw=512, bs=32, steps=10, warmup=4):
+def bench_segfamily(models=("SegResNet", "ResHedNet", "dilnet"), hw=512, bs=32, steps=10, warmup=4, emit=True):
     """Training throughput of the other Segmentor families (default widths) at the headline shape."""
     import atomai_amd.engine as eng
     res = {}
@@ -182,11 +185,12 @@ def bench_segfamily(models=("SegResNet", "ResHedNet", "dilnet"), hw=512, bs=32, 
         torch.cuda.empty_cache()
     out = {"metric": f"training images/sec, {hw}x{hw}, bs={bs}, default-width families", "unit": "images/s",
            "value": res.get("SegResNet", {}).get("images_per_s"), "detail": res}
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
     return out
 
 
-def bench_locate(frames=32, hw=1024, C=1):
+def bench_locate(frames=32, hw=1024, C=1, emit=True):
     """Locator on `frames` probability maps of hw x hw (the post-processing of configs[2]): HBM-bound integer
     work; algorithmic bytes = the probabilities read once (4*C bytes per pixel)."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -223,7 +227,8 @@ def bench_locate(frames=32, hw=1024, C=1):
                         "frac": round(gbps / 8000, 4), "traffic": None},
            "cpu_baseline": {"value": round(1 / cpu_dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                             "sample": "2 frames through oracle/locator_oracle.py (scipy.ndimage)"}}
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
     return out
 
 
