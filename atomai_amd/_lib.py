@@ -33,7 +33,7 @@ def parse_header(path: str = None):
     for m in re.finditer(r"\b(int|long)\s+(amx_\w+)\s*\(([^)]*)\)\s*;", text):
         res, name, args = m.group(1), m.group(2), m.group(3)
         argtypes = []
-        for a in [x.strip() for x in args.split(",") if x.strip()]:
+        for a in [x.strip() for x in args.split(",") if x.strip() and x.strip() != "void"]:
             if "*" in a:
                 argtypes.append(_P)
             else:
@@ -57,6 +57,8 @@ def _bind(cdll):
         fn = getattr(cdll, name)          # AttributeError -> symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    cdll.amx_last_error.restype = C.c_char_p     # the one entry point that does not return int
+    cdll.amx_last_error.argtypes = []
     return cdll
 
 
@@ -85,9 +87,16 @@ def is_test_backend() -> bool:
     return _is_test_backend
 
 
+class _StreamPtr(C.c_void_p):
+    """hipStream_t of a launch plus the index of the device it belongs to (`call` selects that device)."""
+    dev = None
+
+
 def stream_ptr(t: torch.Tensor):
     if t.is_cuda:
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        sp = _StreamPtr(torch.cuda.current_stream(t.device).cuda_stream)
+        sp.dev = t.device.index
+        return sp
     if not _is_test_backend:
         raise AmxError("atomai_amd ops need tensors on an MI355X (cuda) device; got a CPU tensor "
                        "and there is no CPU fallback")
@@ -102,8 +111,23 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def last_error() -> str:
+    """Message of the last failed call on this thread (amx_last_error of the C ABI)."""
+    msg = load().amx_last_error()
+    return msg.decode() if msg else ""
+
+
 def call(name: str, *args):
-    rc = getattr(load(), name)(*args)
+    fn = getattr(load(), name)
+    # A kernel must be launched with ITS device current: the stream in the last argument belongs to the device of
+    # the tensors (stream_ptr), which need not be torch's current device (SegPredictor(device='cuda:1'), DKL replicas
+    # on ranks > 0).  The C ABI itself never calls hipSetDevice.
+    dev = getattr(args[-1], "dev", None) if args else None
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            rc = fn(*args)
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise AmxError(f"{name} failed with code {rc} "
-                       f"({'bad argument #%d' % -rc if rc < 0 else 'hipError_t'})")
+                       f"({'bad argument #%d' % -rc if rc < 0 else 'hipError_t'}): {last_error()}")

@@ -19,12 +19,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define AMX_WAVE 64
 
-// Error convention of the C ABI (include/atomai_amd.h): 0 = ok, >0 = hipError_t, <0 = bad argument.
-#define AMX_BADARG(code) return -(code)
-#define AMX_CHECK_LAUNCH()                    \
-    do {                                      \
-        hipError_t e__ = hipGetLastError();   \
-        if (e__ != hipSuccess) return (int)e__; \
+// Error convention of the C ABI (include/atomai_amd.h): 0 = ok, >0 = hipError_t, <0 = bad argument; the text of
+// the last failure on the calling thread is kept for amx_last_error() (abi.hip).
+#include <cstdio>
+extern "C" void amx_set_error(const char* fn, int code, const char* detail);
+#define AMX_BADARG(code)                                          \
+    do {                                                          \
+        amx_set_error(__func__, -(code), "bad argument group");   \
+        return -(code);                                           \
+    } while (0)
+#ifdef AMX_EMU
+#define AMX_ERRSTR(e) "launch failed (emulator)"
+#else
+#define AMX_ERRSTR(e) hipGetErrorString(e)
+#endif
+#define AMX_CHECK_LAUNCH()                                        \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) {                                  \
+            amx_set_error(__func__, (int)e__, AMX_ERRSTR(e__));   \
+            return (int)e__;                                      \
+        }                                                         \
     } while (0)
 
 static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -215,9 +215,9 @@ __global__ __launch_bounds__(256) void locate_emit_kernel(const int* __restrict_
 
 // ---------------------------------------------------------------------------------------------- C ABI
 extern "C" long amx_locate_workspace_bytes(int B, int H, int W, int nch) {
-    if (B <= 0 || H <= 0 || W <= 0 || nch <= 0) return -1;
+    if (B <= 0 || H <= 0 || W <= 0 || nch <= 0) AMX_BADARG(1);
     const long ne = (long)B * nch * H * W;
-    if (ne >= 2147483647L) return -2;                // int32 labels: chunk the stack on the host
+    if (ne >= 2147483647L) AMX_BADARG(2);                // int32 labels: chunk the stack on the host
     return ne * 24 + (loc_nchunks(ne) + 1) * 4 + 64;
 }
 

@@ -438,7 +438,7 @@ static size_t bwd_lds(int skip) {
 template <int HID, int MT>
 static int launch_fwd(const RDecArgs& a, hipStream_t s) {
     const size_t lds = fwd_lds<HID, MT>(a.skip);
-    if (lds > 160 * 1024) return -20;
+    if (lds > 160 * 1024) AMX_BADARG(20);
 #ifndef AMX_EMU
     static bool attr = false;
     if (!attr) {
@@ -456,7 +456,7 @@ static int launch_fwd(const RDecArgs& a, hipStream_t s) {
 template <int HID, int MT, int NL>
 static int launch_bwd(const RDecArgs& a, hipStream_t s) {
     const size_t lds = bwd_lds<HID, MT, NL>(a.skip);
-    if (lds > 160 * 1024) return -20;
+    if (lds > 160 * 1024) AMX_BADARG(20);
 #ifndef AMX_EMU
     static bool attr = false;
     if (!attr) {
@@ -472,9 +472,9 @@ static int launch_bwd(const RDecArgs& a, hipStream_t s) {
 }
 
 static int check_common(const RDecArgs& a, int hid) {
-    if (!a.coords || !a.z || !a.Wc || !a.bc || !a.Wz || !a.W || !a.b || !a.Wo || !a.bo) return -1;
-    if (a.B <= 0 || a.n <= 0 || a.L < 1 || a.L > MAXL || a.NL < 1 || a.NL > 3) return -2;
-    if (hid != 32 && hid != 64 && hid != 128) return -3;
+    if (!a.coords || !a.z || !a.Wc || !a.bc || !a.Wz || !a.W || !a.b || !a.Wo || !a.bo) AMX_BADARG(1);
+    if (a.B <= 0 || a.n <= 0 || a.L < 1 || a.L > MAXL || a.NL < 1 || a.NL > 3) AMX_BADARG(2);
+    if (hid != 32 && hid != 64 && hid != 128) AMX_BADARG(3);
     return 0;
 }
 

@@ -162,9 +162,15 @@ def _sp(t):
 
 def grad_buffer(p: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
     """Where a kernel should write d loss / d p: the optimizer's flat-bucket view when the parameter has
-    one and no gradient is pending accumulation (optim.FusedAdam), else a fresh tensor."""
+    one, no gradient is pending accumulation and the view has not been handed out yet in this generation
+    (optim.FusedAdam), else a fresh tensor."""
     v = getattr(p, "_amx_grad", None)
-    if v is not None and p.grad is None and v.shape == p.shape and v.device == like.device:
+    if (v is not None and p.grad is None and not getattr(p, "_amx_grad_busy", False)
+            and v.shape == p.shape and v.device == like.device):
+        # handed out at most ONCE per optimizer generation (FusedAdam.zero_grad / step clear the mark): a parameter
+        # used twice in one tape, or by two tapes before one backward, must not get two aliases of the same memory
+        # (autograd would then sum the last write with itself instead of G1 + G2)
+        p._amx_grad_busy = True
         return v
     return torch.empty(p.shape, dtype=torch.float32, device=like.device)
 

@@ -109,12 +109,13 @@ class FusedAdam(torch.optim.Adam):
                 st["exp_avg"] = f["m"][seg].view(p.shape)
                 st["exp_avg_sq"] = f["v"][seg].view(p.shape)
         sp = L.stream_ptr(f["p"])
-        if all(have):
-            t = int(self.state[ps[0]]["step"].item()) + 1
+        steps = {int(self.state[p]["step"].item()) for p, h in zip(ps, have) if h}
+        if all(have) and len(steps) == 1:               # one launch over the whole bucket (the normal case)
+            t = steps.pop() + 1
             self._launch(0, f["n"], t, lr, b1, b2, eps, sp)
             for p in ps:
                 self.state[p]["step"] += 1
-        else:                                           # torch semantics: params without grad are skipped
+        else:           # torch semantics: params without grad are skipped, every parameter has its OWN step count
             for p, off, h in zip(ps, offs, have):
                 if not h:
                     continue
@@ -122,6 +123,7 @@ class FusedAdam(torch.optim.Adam):
                 self._launch(off, (p.numel() + 3) // 4 * 4, t, lr, b1, b2, eps, sp)
                 self.state[p]["step"] += 1
         engine.bump_weight_generation()
+        self._release_grad_views()
         return loss
 
     def _launch(self, off, n, t, lr, b1, b2, eps, sp):
@@ -141,6 +143,11 @@ class FusedAdam(torch.optim.Adam):
         opt.load_state_dict(self.state_dict())
         return opt
 
+    def _release_grad_views(self) -> None:
+        for p in self._params():
+            p._amx_grad_busy = False
+
     def zero_grad(self, set_to_none: bool = True):
         # gradients are rewritten (not accumulated) by the next backward when they are None
+        self._release_grad_views()
         return super().zero_grad(set_to_none=set_to_none)

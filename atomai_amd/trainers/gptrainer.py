@@ -17,7 +17,8 @@ class dklGPTrainer:
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(seed)
         self.dimdict = {"input_dim": indim, "embedim": embedim}
-        self.device = kwargs.get("device", 'cuda:0' if torch.cuda.is_available() else 'cpu')
+        # the CURRENT device (not a hard-coded cuda:0): DKL runs as independent replicas, one per rank / GPU
+        self.device = kwargs.get("device", f'cuda:{torch.cuda.current_device()}' if torch.cuda.is_available() else 'cpu')
         precision = kwargs.get("precision", "double")
         # explicit dtype/device instead of the reference's global torch.set_default_tensor_type
         self.dtype = torch.float32 if precision == "single" else torch.float64

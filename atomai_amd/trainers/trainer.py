@@ -91,7 +91,8 @@ class BaseTrainer:
     def set_model(self, model: Type[torch.nn.Module], nb_classes: int = None) -> None:
         self.net = model
         self.net.to(self.device)
-        self.nb_classes = nb_classes
+        if self.nb_classes is None and nb_classes:           # as the reference (trainer.py:164-181): never wiped
+            self.nb_classes = nb_classes
 
     def get_loss_fn(self, loss: Union[str, Callable] = 'mse', nb_classes: int = None):
         return losses_metrics.select_loss(loss, nb_classes)
@@ -136,12 +137,20 @@ class BaseTrainer:
     def step_full(self) -> None:
         """One pass over every mini-batch of both loaders (trainer.py:253-287)."""
         tot = {"tr": [0.0, 0.0, 0], "te": [0.0, 0.0, 0]}
+        c = 0
         for feat, tar in self.train_loader:
+            if self.augment_fn is not None:                  # every mini-batch, seeded by its index (trainer.py:262-266)
+                feat, tar = self.augment_fn(feat, tar, seed=c)
+            c += 1
             res = self.train_step(feat, tar)
             tot["tr"][0] += res[0]
             tot["tr"][1] += res[1] if self.compute_accuracy else 0
             tot["tr"][2] += 1
+        c = 0
         for feat, tar in self.test_loader:
+            if self.augment_fn is not None:                  # trainer.py:272-276
+                feat, tar = self.augment_fn(feat, tar, seed=c)
+            c += 1
             res = self.test_step(feat, tar)
             tot["te"][0] += res[0]
             tot["te"][1] += res[1] if self.compute_accuracy else 0
@@ -218,7 +227,9 @@ class BaseTrainer:
         if self.training_cycles - e <= n_last:
             i_ = n_last - (self.training_cycles - e)
             self.running_weights[i_] = OrderedDict(
-                (k, copy.deepcopy(v).cpu()) for k, v in self.net.state_dict().items())
+                # the tensors are views into FusedAdam's flat buffer: deepcopy would clone the WHOLE underlying
+                # storage once per tensor; detach().cpu() copies only the view's elements
+                (k, v.detach().cpu().clone()) for k, v in self.net.state_dict().items())
 
     def data_augmentation(self, augment_fn) -> None:
         self.augment_fn = augment_fn

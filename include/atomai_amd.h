@@ -22,6 +22,12 @@
 extern "C" {
 #endif
 
+/* ---- error text: message of the last failed call on the CALLING THREAD, e.g.
+ * "conv2d_common: bad argument group (code -3)" or the hipGetErrorString of a failed launch; "" if none.
+ * The pointer stays valid for the life of the thread; amx_clear_error resets it. */
+const char* amx_last_error(void);
+int amx_clear_error(void);
+
 /* ---- convolution: nn.Conv2d(k=3|1, padding=dilation) + bias + LeakyReLU + BN batch statistics,
  * reading torch.cat([src0, src1], 1) with each source's BN affine applied on load.
  * atomai/nets/blocks.py:61-76 (ConvBlock), :122-132 (UpsampleBlock 1x1), :300-318 (DilatedBlock);
@@ -200,8 +206,10 @@ int amx_locate_label(const float* prob, int B, int H, int W, int C, int nch, flo
 int amx_locate_emit(const void* work, int B, int H, int W, int nch, int dist_edge, double* coords, int* meta,
                     long cap, void* stream);
 
-/* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218) */
-int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+/* ---- torch.optim.Adam defaults as one flat launch (trainer.py:539, vitrainer.py:218).  b1, b2 and the bias
+ * corrections bc1 = 1-b1^t, bc2 = 1-b2^t are DOUBLES: torch forms 1-beta in double before rounding to fp32
+ * (1 - float(0.999) is off by 1.3e-5 relative, a systematic error in every second moment). */
+int amx_adam_flat(float* p, const float* g, float* m, float* v, long n, float lr, double b1, double b2,
                   float eps, double bc1, double bc2, float gscale, void* stream);
 
 #ifdef __cplusplus

@@ -1,5 +1,6 @@
 """smoke(): one tiny forward + backward + Adam step of the Segmentor hot path on cuda:0, checked against
-the CPU oracle (oracle/seg_oracle.py is the checker here, never the thing executed as the product)."""
+the CPU oracle (oracle/seg_oracle.py is the checker here, never the thing executed as the product).
+Lives outside the package on purpose: nothing under atomai_amd/ imports the oracle."""
 import os
 import sys
 from collections import OrderedDict
@@ -11,7 +12,7 @@ import torch
 def run() -> None:
     if not torch.cuda.is_available():
         raise RuntimeError("smoke() needs an MI355X (cuda:0); there is no CPU fallback")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tools/ -> repo root
     if root not in sys.path:
         sys.path.insert(0, root)
     from oracle import seg_oracle as so
