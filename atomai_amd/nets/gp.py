@@ -47,12 +47,22 @@ class convFeatureExtractor(nn.Module):
         self.c2 = ConvBlock(2, 1, nb_filters, 2 * nb_filters, batch_norm=True)
         self.fc = nn.Linear(2 * nb_filters * (p // 4) ** 2, embedim)
 
+    def _apply(self, fn, *args, **kwargs):
+        """``.to(torch.float64)`` (dklGPTrainer's precision='double') converts the GP-facing Linear only: the HIP
+        convolution blocks compute in fp32 whatever precision the GP layer runs at."""
+        super()._apply(fn, *args, **kwargs)
+        for blk in (self.c1, self.c2):
+            for t in list(blk.parameters()) + list(blk.buffers()):
+                if t.is_floating_point() and t.dtype != torch.float32:
+                    t.data = t.data.float()
+        return self
+
     def forward(self, x):
         dt = x.dtype
         h = x.reshape(-1, 1, self.p, self.p).float()
         h = F.max_pool2d(self.c1(h), 2, 2)
         h = F.max_pool2d(self.c2(h), 2, 2)
-        return self.fc(h.flatten(1)).to(dt)
+        return self.fc(h.flatten(1).to(self.fc.weight.dtype)).to(dt)
 
 
 def _kernel_call(name, *tensors_and_args):
@@ -178,17 +188,46 @@ class GPRegressionModel(nn.Module):
                                           self.noise[i, 0], self.mean_constant[i, 0], self.kind)
         return tot
 
+    def _state_key(self) -> tuple:
+        """Identity of everything the training-set factorisation depends on: parameter / buffer versions (in-place
+        optimizer updates bump them), the fused optimizer's generation counter (it writes through raw pointers),
+        the training data and the train / eval mode."""
+        from ..engine import _weight_generation
+        vers = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        X, y = self.train_inputs[0], self.train_targets
+        return (vers, _weight_generation[0], X.data_ptr(), X._version, tuple(X.shape), y.data_ptr(), y._version,
+                self.training)
+
     @torch.no_grad()
-    def posterior(self, x_new: torch.Tensor, full_cov: bool = False):
-        """Latent posterior mean (q, n) and variance (q, n) [or covariance (q, n, n)] at x_new."""
+    def _posterior_factors(self):
+        """(Z_train, [(cholesky(K + noise I), alpha = K^-1 (y - mu)) per output]) — computed ONCE per model state
+        and reused by every predict batch (dklgpr.py:202-217 calls the posterior per DataLoader batch; without the
+        cache each batch redid the O(N^3) factorisation)."""
+        key = self._state_key()
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1], self._cache[2]
         Z = self.embed(self.train_inputs[0])
-        Zs = self.embed(x_new)
-        means, vars_ = [], []
+        factors = []
         for i in range(self.train_targets.shape[0]):
             ls, s2, nz, mu = self.lengthscale[i], float(self.outputscale[i]), float(self.noise[i, 0]), self.mean_constant[i, 0]
             K = kernel_matrix(Z, Z, ls, s2, self.kind, nz)
             Lc = torch.linalg.cholesky(K)
+            del K
             alpha = torch.cholesky_solve((self.train_targets[i] - mu).reshape(-1, 1), Lc)
+            factors.append((Lc, alpha))
+        self._cache = (self._state_key(), Z, factors)        # key re-read: embed() in train mode touches min/max
+        self.n_factorisations = getattr(self, "n_factorisations", 0) + 1
+        return Z, factors
+
+    @torch.no_grad()
+    def posterior(self, x_new: torch.Tensor, full_cov: bool = False):
+        """Latent posterior mean (q, n) and variance (q, n) [or covariance (q, n, n)] at x_new."""
+        Z, factors = self._posterior_factors()
+        Zs = self.embed(x_new)
+        means, vars_ = [], []
+        for i in range(self.train_targets.shape[0]):
+            ls, s2, mu = self.lengthscale[i], float(self.outputscale[i]), self.mean_constant[i, 0]
+            Lc, alpha = factors[i]
             means.append(mu + kernel_matvec(Zs, Z, ls, s2, alpha, self.kind).reshape(-1))
             Ks = kernel_matrix(Z, Zs, ls, s2, self.kind)
             v = torch.cholesky_solve(Ks, Lc)

@@ -86,3 +86,176 @@ def check_dklgpr_api():
     assert mean.shape == (2, 15)
     # a lengthscale moves after training (test/trainers/test_gptrainer.py:34-43)
     assert float((m2.gp_model.raw_lengthscale.detach() != 0).float().sum()) > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Known-answer vectors restated from gpytorch's OWN unit tests (the only pin available: gpytorch is neither vendored
+# nor installed, so these constants are recalled from its repository, not fetched — the DKL rows stay "parity
+# unpinned" in DESIGN.md):
+#   test/kernels/test_rbf_kernel.py::TestRBFKernel::test_computes_radial_basis_function
+#       a = [4, 2, 8]^T, b = [0, 2]^T, lengthscale 2  ->  exp(-0.5 * [[16, 4], [4, 0], [64, 36]] / 2^2)
+#   test/kernels/test_rbf_kernel.py::TestRBFKernel::test_ard
+#       a = [[1, 2], [2, 4]], b = [[1, 3], [0, 4]], lengthscales [1, 2]
+#   test/kernels/test_matern_kernel.py::TestMaternKernel::test_forward_nu_5_over_2
+#       same a, b, lengthscale 2: dist = sqrt(5)/2 * [[4, 2], [2, 0], [8, 6]];  (dist^2/3 + dist + 1) * exp(-dist)
+#   gpytorch/utils/grid.py::ScaleToBounds.forward
+#       (x - min) * (0.95 * (upper - lower) / (max - min)) + 0.95 * lower, min/max frozen and clamped to in eval mode
+GPYTORCH_KAT = {
+    "rbf": dict(a=[[4.0], [2.0], [8.0]], b=[[0.0], [2.0]], ls=[2.0],
+                K=np.exp(-0.5 * np.array([[16.0, 4.0], [4.0, 0.0], [64.0, 36.0]]) / 4.0)),
+    "rbf_ard": dict(a=[[1.0, 2.0], [2.0, 4.0]], b=[[1.0, 3.0], [0.0, 4.0]], ls=[1.0, 2.0],
+                    K=np.exp(-0.5 * np.array([[0.0 + 0.25, 1.0 + 1.0], [1.0 + 0.25, 4.0 + 0.0]]))),
+    "matern": dict(a=[[4.0], [2.0], [8.0]], b=[[0.0], [2.0]], ls=[2.0], K=None),
+}
+_d = np.array([[4.0, 2.0], [2.0, 0.0], [8.0, 6.0]]) * (math.sqrt(5) / 2.0)
+GPYTORCH_KAT["matern"]["K"] = (_d ** 2 / 3 + _d + 1) * np.exp(-_d)
+
+
+def check_gpytorch_known_answers_oracle():
+    from oracle import gp_oracle as go
+    for name, c in GPYTORCH_KAT.items():
+        kind = "matern" if name == "matern" else "rbf"
+        K = go.kernel_matrix(np.array(c["a"]), np.array(c["b"]), np.array(c["ls"]), 1.0, kind)
+        np.testing.assert_allclose(K, c["K"], rtol=1e-14, atol=0, err_msg=name)
+    x = np.array([[3.0, -1.0], [0.5, 7.0]])
+    np.testing.assert_allclose(go.scale_to_bounds(x), (x + 1.0) * (0.95 * 2 / 8.0) - 0.95, rtol=1e-15)
+
+
+def check_gpytorch_known_answers_kernel(device):
+    from atomai_amd.nets.gp import kernel_matrix
+    for name, c in GPYTORCH_KAT.items():
+        k = 1 if name == "matern" else 0
+        for dt, tol in ((torch.float64, 1e-14), (torch.float32, 1e-6)):
+            t = lambda a: torch.tensor(a, dtype=dt, device=device)
+            K = kernel_matrix(t(c["a"]), t(c["b"]), t(c["ls"]), 1.0, k).cpu().numpy()
+            np.testing.assert_allclose(K, c["K"], rtol=tol, atol=tol * 1e-3, err_msg=f"{name} {dt}")
+
+
+def check_scale_to_bounds_module(device):
+    """GPRegressionModel.scale_to_bounds == gpytorch's ScaleToBounds(-1, 1): train mode records min/max, eval mode
+    clamps to them."""
+    from atomai_amd.nets.gp import GPRegressionModel
+    X = torch.zeros(4, 3, dtype=torch.float64, device=device)
+    m = GPRegressionModel(X, torch.zeros(1, 4, dtype=torch.float64, device=device), torch.nn.Identity(), 3).to(device)
+    x = torch.tensor([[3.0, -1.0], [0.5, 7.0]], dtype=torch.float64, device=device)
+    m.train()
+    np.testing.assert_allclose(m.scale_to_bounds(x).cpu().numpy(), ((x.cpu() + 1) * (1.9 / 8) - 0.95).numpy(), rtol=1e-15)
+    assert float(m.min_val) == -1.0 and float(m.max_val) == 7.0
+    m.eval()
+    y = m.scale_to_bounds(torch.tensor([[-5.0, 9.0, 3.0]], dtype=torch.float64, device=device)).cpu().numpy()
+    np.testing.assert_allclose(y, [[-0.95, 0.95, 4 * 1.9 / 8 - 0.95]], rtol=1e-15)
+
+
+def check_posterior_cache(device):
+    """predict() in batches factorises the training covariance ONCE (dklgpr.py:202-217 calls the posterior per batch),
+    gives the same numbers as one big batch and as the float64 oracle, and the cache dies with the model state."""
+    import atomai_amd as aoi
+    from oracle import gp_oracle as go
+    rs = np.random.RandomState(1)
+    X, y = rs.randn(60, 6), np.sin(rs.randn(60))
+    m = aoi.models.dklGPR(6, embedim=2, precision="double", device=device)
+    m.fit(X, y, training_cycles=2)
+    Xn = rs.randn(25, 6)
+    gm = m.gp_model
+    gm.n_factorisations = 0
+    mean_b, var_b = m.predict(Xn, batch_size=4)             # 7 batches
+    assert gm.n_factorisations == 1
+    mean_1, var_1 = m.predict(Xn)
+    assert gm.n_factorisations == 1                         # still the cached factor
+    np.testing.assert_allclose(mean_b, mean_1, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var_b, var_1, rtol=1e-9, atol=1e-12)
+    Z, Zs = m.embed(X), m.embed(Xn)
+    mu, var = go.posterior(Z, y, Zs, gm.lengthscale[0].detach().cpu().numpy().reshape(-1), float(gm.outputscale[0]),
+                           float(gm.noise[0, 0]), float(gm.mean_constant[0, 0]), "rbf")
+    np.testing.assert_allclose(mean_1, mu, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(var_1, var, rtol=1e-7, atol=1e-10)
+    with torch.no_grad():                                   # any parameter update invalidates
+        gm.raw_noise.add_(0.3)
+    m.predict(Xn, batch_size=10)
+    assert gm.n_factorisations == 2
+    m.fit(X, y, training_cycles=1)                          # so does training
+    m.predict(Xn)
+    assert gm.n_factorisations == 3
+
+
+def _stock_conv_extractor(fe):
+    """Stock-torch float64 graph with the weights of a convFeatureExtractor: the reference's ConvBlock order
+    conv -> LeakyReLU(0.01) -> BatchNorm (atomai/nets/blocks.py:61-76), max-pool, Linear."""
+    import torch.nn as nn
+    nf = fe.c1.block[0].weight.shape[0]
+
+    class Ref(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Sequential(nn.Conv2d(1, nf, 3, padding=1), nn.LeakyReLU(0.01), nn.BatchNorm2d(nf))
+            self.c2 = nn.Sequential(nn.Conv2d(nf, 2 * nf, 3, padding=1), nn.LeakyReLU(0.01), nn.BatchNorm2d(2 * nf))
+            self.fc = nn.Linear(fe.fc.in_features, fe.fc.out_features)
+
+        def forward(self, x):
+            p = int(round(math.sqrt(x.shape[1])))
+            h = x.reshape(-1, 1, p, p)
+            h = torch.nn.functional.max_pool2d(self.c1(h), 2, 2)
+            h = torch.nn.functional.max_pool2d(self.c2(h), 2, 2)
+            return self.fc(h.flatten(1))
+    ref = Ref().double()
+    sd = {k.replace(".block.", "."): v.detach().cpu().double() for k, v in fe.state_dict().items()}
+    ref.load_state_dict(sd)
+    return ref
+
+
+def check_conv_feature_extractor(device, N=24, p=8, nf=4):
+    """convFeatureExtractor (BASELINE.json configs[4]'s "conv feature extractor") forward + every gradient, train and
+    eval mode, against the stock-torch float64 graph of the same weights."""
+    from atomai_amd.nets.gp import convFeatureExtractor
+    torch.manual_seed(0)
+    fe = convFeatureExtractor(p * p, 2, nb_filters=nf)
+    ref = _stock_conv_extractor(fe)
+    fe = fe.to(device)
+    rs = np.random.RandomState(5)
+    x = rs.randn(N, p * p).astype(np.float32)
+    w = rs.randn(N, 2)
+    for mode in ("train", "eval"):
+        getattr(fe, mode)()
+        getattr(ref, mode)()
+        fe.zero_grad()
+        ref.zero_grad()
+        xt = torch.from_numpy(x).to(device).requires_grad_(True)
+        xr = torch.from_numpy(x).double().requires_grad_(True)
+        out, outr = fe(xt), ref(xr)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), outr.detach().numpy(), rtol=1e-4, atol=1e-5)
+        if mode == "eval":
+            continue                                         # backward through eval-mode BatchNorm is not on the path
+        (out * torch.from_numpy(w).float().to(device)).sum().backward()
+        (outr * torch.from_numpy(w)).sum().backward()
+        gref = {k.replace(".", ".block.", 1) if k[:2] in ("c1", "c2") else k: v for k, v in
+                ((k, p_.grad) for k, p_ in ref.named_parameters())}
+        gmax = max(float(g.abs().max()) for g in gref.values())
+        for k, p_ in fe.named_parameters():
+            err = float((p_.grad.cpu().double() - gref[k]).abs().max()) / gmax
+            assert err < 1e-4, (k, err)
+        ex = float((xt.grad.cpu().double() - xr.grad).abs().max() / xr.grad.abs().max())
+        assert ex < 1e-4, ex
+    # running statistics followed the reference's BatchNorm update
+    for k in ("c1.block.2.running_mean", "c2.block.2.running_var"):
+        kr = k.replace(".block.", ".")
+        np.testing.assert_allclose(fe.state_dict()[k].cpu().numpy(), ref.state_dict()[kr].numpy(), rtol=1e-4, atol=1e-6)
+
+
+def check_dklgpr_conv_extractor(device, N=256, p=8, cycles=2, precision="single"):
+    """dklGPR(feature_extractor=convFeatureExtractor) fit + predict (config 5's shape family): loss finite and
+    decreasing over the first cycles, predictions finite, variance within [0, s2], one factorisation per predict."""
+    import atomai_amd as aoi
+    from atomai_amd.nets.gp import convFeatureExtractor
+    rs = np.random.RandomState(0)
+    X = rs.randn(N, p * p).astype(np.float32)
+    y = np.tanh(X[:, : p].sum(1)).astype(np.float32)
+    m = aoi.models.dklGPR(p * p, embedim=2, precision=precision, device=device)
+    m.fit(X, y, training_cycles=cycles, feature_extractor=convFeatureExtractor)
+    assert len(m.train_loss) == cycles and all(np.isfinite(m.train_loss))
+    m.gp_model.n_factorisations = 0
+    mean, var = m.predict(X[: min(N, 2048)], batch_size=max(64, N // 8))
+    assert m.gp_model.n_factorisations == 1
+    assert np.isfinite(mean).all() and np.isfinite(var).all()
+    s2 = float(m.gp_model.outputscale[0])
+    assert (var >= 0).all() and (var <= s2 * (1 + 1e-4)).all()
+    return m

@@ -35,3 +35,21 @@ def test_kernel_backward_and_mll(kind):
 
 def test_dklgpr_api():
     G.check_dklgpr_api()
+
+
+def test_gpytorch_known_answer_vectors():
+    G.check_gpytorch_known_answers_oracle()
+    G.check_gpytorch_known_answers_kernel("cpu")
+    G.check_scale_to_bounds_module("cpu")
+
+
+def test_posterior_is_factorised_once_per_model_state():
+    G.check_posterior_cache("cpu")
+
+
+def test_conv_feature_extractor_vs_stock_torch():
+    G.check_conv_feature_extractor("cpu")
+
+
+def test_dklgpr_with_conv_feature_extractor():
+    G.check_dklgpr_conv_extractor("cpu", N=48, p=8, cycles=2, precision="double")

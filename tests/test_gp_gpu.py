@@ -43,3 +43,24 @@ def test_config5_covariance_properties():
     assert float((y1 - y2).abs().max() / y1.abs().max()) < 1e-4
     K64 = kernel_matrix(Z.double(), Z.double(), ls.double(), s2, 0)
     assert float((K.double().sum(1) - K64.sum(1)).abs().max() / K64.sum(1).abs().max()) < 1e-5
+
+
+def test_gpytorch_known_answer_vectors():
+    G.check_gpytorch_known_answers_kernel("cuda")
+    G.check_scale_to_bounds_module("cuda")
+
+
+def test_posterior_is_factorised_once_per_model_state():
+    G.check_posterior_cache("cuda")
+
+
+def test_conv_feature_extractor_vs_stock_torch():
+    G.check_conv_feature_extractor("cuda")
+    G.check_conv_feature_extractor("cuda", N=300, p=16, nf=16)
+
+
+def test_config5_dklgpr_conv_extractor_n16384():
+    """BASELINE.json configs[4] end to end: dklGPR with the conv feature extractor on N = 16384 patches of 16x16,
+    RBF kernel, exact GP on the dense tiled covariance (fp32)."""
+    m = G.check_dklgpr_conv_extractor("cuda", N=16384, p=16, cycles=2, precision="single")
+    assert m.gp_model.train_inputs[0].shape == (16384, 256)
