@@ -105,8 +105,13 @@ class SegPredictor(BasePredictor):
         on_device = str(self.device).startswith("cuda") or L.is_test_backend()
         if (norm and device_norm and on_device and isinstance(image_data, np.ndarray)
                 and image_data.dtype == np.float32 and image_data.ndim == 3):
-            self._norm = (np.float32(image_data.min()), np.float32(np.ptp(image_data)))
+            fixed = getattr(self, "_fixed_norm", None)       # global (min, ptp) agreed across ranks
+            self._norm = fixed if fixed is not None else (np.float32(image_data.min()), np.float32(np.ptp(image_data)))
             return torch.from_numpy(np.ascontiguousarray(image_data[:, None]))
+        if norm and getattr(self, "_fixed_norm", None) is not None:
+            mn, ptp = self._fixed_norm                       # torch_format_image with the GLOBAL min / ptp
+            x = image_data[:, None] if image_data.ndim == 3 else image_data
+            return torch.from_numpy(np.ascontiguousarray((x - mn) / ptp)).float()
         return torch_format_image(image_data, norm)
 
     def forward_(self, images: torch.Tensor) -> torch.Tensor:
@@ -192,7 +197,90 @@ class SegPredictor(BasePredictor):
             collect(k)
         return out
 
+    # ------------------------------------------------------------------ multi-GPU
+    @staticmethod
+    def _dist_world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    @staticmethod
+    def frame_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+        """Contiguous frame range [lo, hi) of `rank`: frames are independent in eval mode, so the stack shards with
+        no data-path collective."""
+        return n * rank // world, n * (rank + 1) // world
+
+    def _global_min_ptp(self, local: np.ndarray):
+        """Global (min, ptp) of the stack from each rank's LOCAL frames: ONE all-reduce(MAX) of the two floats
+        (-min, max) — the only exchange of the predict path (utils/preproc.py:822-823 normalises by the min / ptp of
+        the WHOLE stack).  float32 min / max are exact, so the result equals numpy's over the full stack bit for bit."""
+        import torch.distributed as dist
+        v = [-float(local.min()), float(local.max())] if local.size else [-float("inf"), -float("inf")]
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(v, dtype=torch.float64, device=dev)      # float64 holds float32 / int32 values exactly
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ty = local.dtype.type                                      # min / ptp in the stack's own dtype, as numpy's
+        mn, mx = ty(-t[0].item()), ty(t[1].item())
+        return mn, mx - mn
+
+    def predict_distributed(self, image_data: np.ndarray, gather: bool = True, **kwargs):
+        """``predict`` with the frames of the stack sharded over the ranks of the initialised process group (one
+        process per GPU).  Every rank passes the SAME stack (or a memory-map of it) and decodes only its contiguous
+        range; normalisation uses the global min / ptp (`_global_min_ptp`).  With ``gather`` rank 0 returns the whole
+        decoded stack (other ranks return their own range); without it every rank returns (lo, decoded range)."""
+        import torch.distributed as dist
+        rank, world = self._dist_world()
+        if image_data.ndim == 2:
+            image_data = image_data[np.newaxis, ...]
+        n = len(image_data)
+        lo, hi = self.frame_range(n, rank, world)
+        local = np.ascontiguousarray(image_data[lo:hi])
+        norm = kwargs.get("norm", True)
+        fixed = None
+        if norm and world > 1:
+            fixed = self._global_min_ptp(local)
+        self._fixed_norm = fixed
+        try:
+            mine = self.predict(local, **kwargs) if hi > lo else None
+        finally:
+            self._fixed_norm = None
+        if world == 1:
+            return mine if gather else (lo, mine)
+        if not gather:
+            return lo, mine
+        # gather on rank 0: equal-sized (padded) blocks through the backend's device, a bounded number of frames at a
+        # time so that a 17 GB stack never needs a second full copy on one GPU
+        cnt = max(self.frame_range(n, r, world)[1] - self.frame_range(n, r, world)[0] for r in range(world))
+        shape = None if mine is None else mine.shape[1:]
+        shapes = [None] * world
+        dist.all_gather_object(shapes, shape)
+        shape = next(s_ for s_ in shapes if s_ is not None)
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        out = np.empty((n,) + tuple(shape), dtype=np.float32) if rank == 0 else None
+        step = max(1, (256 << 20) // (int(np.prod(shape)) * 4))
+        for s in range(0, cnt, step):
+            m = min(step, cnt - s)
+            blk = torch.zeros((m,) + tuple(shape), dtype=torch.float32, device=dev)
+            if mine is not None and s < len(mine):
+                k = min(m, len(mine) - s)
+                blk[:k] = torch.from_numpy(mine[s:s + k]).to(dev)
+            bufs = [torch.empty_like(blk) for _ in range(world)] if rank == 0 else None
+            dist.gather(blk, bufs, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    rlo, rhi = self.frame_range(n, r, world)
+                    k = min(m, (rhi - rlo) - s)
+                    if k > 0:
+                        out[rlo + s: rlo + s + k] = bufs[r][:k].cpu().numpy()
+        return out if rank == 0 else mine
+
     def predict(self, image_data: np.ndarray, return_image: bool = False, **kwargs: int):
+        if kwargs.pop("distributed", False):
+            if return_image:
+                raise NotImplementedError("return_image is not available with distributed=True")
+            return self.predict_distributed(image_data, **kwargs)
+        kwargs.pop("gather", None)
         image_data = self.preprocess(image_data, kwargs.get("norm", True), device_norm=not return_image)
         n, _, w, h = image_data.shape
         num_batches = kwargs.get("num_batches")
@@ -222,6 +310,18 @@ class SegPredictor(BasePredictor):
                 coordinates[start + i] = v
         kw = {k: v for k, v in kwargs.items() if k != "thresh"}
         decoded = self.predict(image_data, _on_chunk=on_chunk, **kw)
+        if kwargs.get("distributed", False) and self._dist_world()[1] > 1:
+            # frame indices seen by on_chunk are local to this rank's range: shift, then merge on rank 0
+            import torch.distributed as dist
+            rank, world = self._dist_world()
+            n = 1 if image_data.ndim == 2 else len(image_data)
+            lo = self.frame_range(n, rank, world)[0]
+            coordinates = {lo + i: v for i, v in coordinates.items()}
+            if kwargs.get("gather", True):
+                parts = [None] * world
+                dist.all_gather_object(parts, coordinates)
+                if rank == 0:
+                    coordinates = {k: v for part in parts for k, v in part.items()}
         coordinates = {i: coordinates[i] for i in sorted(coordinates)}
         if self.verbose:
             word = " image was " if decoded.shape[0] == 1 else " images were "
