@@ -42,6 +42,13 @@ extern "C" void amx_set_error(const char* fn, int code, const char* detail);
         }                                                         \
     } while (0)
 
+// Scheduling fence: nothing is moved across it by the instruction scheduler (used to keep operand prefetches ahead
+// of the MFMA burst they are meant to overlap with).  No code is emitted.
+static __device__ __forceinline__ void amx_sched_fence() {
+#ifndef AMX_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void amx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // XCD-aware block index: the dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup
@@ -59,6 +66,22 @@ static __device__ __forceinline__ void amx_st4_stream(float* p, float4 v) {
     *reinterpret_cast<float4*>(p) = v;
 #else
     __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+#endif
+}
+// Compute units of the current device (256 on MI355X), queried once per device.
+static inline int amx_num_cus() {
+#ifdef AMX_EMU
+    return 4;
+#else
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
 #endif
 }
 static __host__ __device__ __forceinline__ int amx_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,478 @@
+// conv_kernel.h — the NHWC direct (im2col-free) 3x3 / dilated-3x3 / 1x1 convolution kernel on fp32 MFMA, fused
+// with: BatchNorm-affine-on-load of up to two concatenated sources, bias, LeakyReLU and the per-channel batch
+// statistics (sum, M2) of the post-activation tensor.  Instantiated by conv_fwd_1x1.hip / conv_fwd_3x3.hip /
+// conv_fwd_dil.hip (three translation units so that hipcc compiles them in parallel), dispatched by conv_fwd.hip.
+//
+// Replaces, on the hot path of the reference (all ATen calls):
+//   nn.Conv2d k3 s1 p=d dil=d (+bias)  -> LeakyReLU -> [BatchNorm2d statistics]      atomai/nets/blocks.py:61-76, 300-318
+//   torch.cat([skip, up], dim=1) feeding a conv                                      atomai/nets/fcnn.py:132-138, 223
+//   BatchNorm2d normalisation of the *previous* layer (applied here, on load)        atomai/nets/blocks.py:71-75
+//   nn.Conv2d 1x1 of UpsampleBlock (evaluated at low resolution, it commutes)        atomai/nets/blocks.py:122-132
+// The same kernel is the data-gradient (dgrad) engine: a 3x3 dgrad is a 3x3 forward conv with
+// spatially flipped, in/out-transposed weights (pack.hip builds that weight image); its two
+// concatenated *outputs* (skip / upsampled halves) are written through `y` + `y1`.
+//
+// Mapping to CDNA4 (gfx950):
+//   * implicit GEMM  M = (4*MTW rows x 16) output pixels per work item, N = 16*NT output channels,
+//     K = taps x 16-channel chunks.  One wave owns MTW image rows x NT channel tiles and issues
+//     v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles): A[pixel][k], B[k][cout].
+//   * LDS operand images are laid out so that every fragment is ONE conflict-free ds_read_b128:
+//       input  tile  [kgroup][pixel slot][4 channels]   (plane stride == 0 mod 16 slots)
+//       weight tile  [tap][kgroup][cout][4 channels]
+//     a lane (p = lane&15, g = lane>>4) reads 4 consecutive channels 4g..4g+3 of pixel/cout p and
+//     feeds them to 4 consecutive MFMAs, so each MFMA contracts channels {kk, 4+kk, 8+kk, 12+kk}.
+//   * EXACT: the dilation is a template constant (1, 2, 4, 6 — every dilation the reference's nets use), so the tile
+//     geometry is compile-time: the 9 tap offsets are ds_read immediates instead of ~36 address registers.
+//   * software-pipelined fragments: tap t+1's ds_read_b128s are issued before tap t's MFMAs (AMX_CONV_SWP).
+//   * Measured and rejected in round 2 (profiles/r02_conv_persistent_ab.md): persistent workgroups walking several
+//     tiles with cross-tile register prefetch, and weight images kept resident in LDS for <= 2-chunk layers — no
+//     gain over one workgroup per tile (the hardware dispatcher hides workgroup turnover), slower where the resident
+//     weights cost a co-resident workgroup.
+//   * global->register prefetch of chunk c+1 is issued before the MFMA phase of chunk c; the BN affine and the zero
+//     padding are applied when registers are written to LDS (padding must stay zero AFTER the affine, so it cannot
+//     be folded into the weights).
+//   * epilogue: bias + LeakyReLU on the accumulators, NHWC store (64 B runs per pixel), then a
+//     two-pass (mean, M2) reduction per item: wave shuffles -> LDS -> one partial row per
+//     tile; bn.hip merges the rows with Chan's formula in fp64 (deterministic, no atomics).
+#pragma once
+#include "amx_device.h"
+#include <cstdlib>
+
+#define TILE 16          // output tile is TILE x TILE pixels
+#define KG 4             // k-groups (of 4 channels) per chunk -> 16 channels per chunk
+
+struct ConvFwdArgs {
+    const float* x0; const float* sc0; const float* sh0; int C0s;
+    const float* x1; const float* sc1; const float* sh1; int C1s;
+    float in_slope0, in_slope1;   // LeakyReLU applied AFTER the on-load affine of source 0 / 1 (1.0f == none):
+                                  // ResBlock's conv -> BatchNorm -> LeakyReLU order (atomai/nets/blocks.py:205-208)
+    const float* wpk;    // [nchunk][taps][KG][cop][4]
+    const float* bias;   // [cout] or nullptr
+    const float* addend; // optional tensor (same shape as y) added to the first output, or nullptr
+    float* y;  int Y0s;  // first  output: stored channels Y0s, receives couts [0, Y0s)
+    float* y1; int Y1s;  // second output (dgrad of a concat) receives couts [Y0s, Y0s+Y1s), or nullptr
+    float* stats;        // [tiles][2][cop] (sum, M2) or nullptr
+    // ---- backward fusions (dgrad use of this kernel)
+    const float* aux0;   // activation a of the layer whose gradient src0 (= dy) is: the loader forms
+                         // dpre = lrelu'(a) * (k1*dy + k2*a + k3) on the fly (BatchNorm + LeakyReLU backward)
+    const float* k1; const float* k2; const float* k3;   // [C0s] or nullptr (== 1, 0, 0)
+    float bslope;        // LeakyReLU slope of that layer
+    const float* ea0;    // activation aligned with output y  (or nullptr): epilogue emits per-tile
+    const float* ea1;    // activation aligned with output y1 (or nullptr): (sum dy, sum dy*a) -> bstats
+    float* bstats;       // [tiles][2][cop] or nullptr
+    int N, H, W;
+    int cout;            // real number of output channels
+    int cop;             // cout rounded up to 16
+    int nchunk;
+    int tail_kg;         // valid 4-channel k-groups in the LAST chunk (1..KG; KG == the chunk is full)
+    int dil;             // dilation (== halo) for 9 taps; ignored for 1 tap
+    float slope;         // LeakyReLU negative slope; 1.0f == no activation
+    int tiles_x, tiles_y;
+    int th;              // tile height in pixels (16 or 32)
+    int xcd;             // 1: XCD-aware tile order (neighbouring tiles share an L2)
+};
+
+// TAIL: compiled-in support for a partial last chunk (compute_tail).  It is a separate instantiation because the
+// extra unrolled tap loop costs registers — 108+16 -> 128+32 VGPR/AGPR, i.e. 4 -> 3 waves per SIMD — which slowed
+// every layer by ~10 %, including the ones (all channel counts multiples of 16) that never take that path.
+//
+// Compile-time experiment switches (tools/build_variant_lib.sh builds one library per combination for in-process A/B):
+//   AMX_CONV_SWP    1: operand fragments of tap t+1 are read into a second register set before tap t's MFMAs
+//   AMX_CONV_EXACT  1: plain 3x3 instantiations (MAXHALO == 1) use the compile-time halo instead of a.dil
+#ifndef AMX_CONV_SWP
+#define AMX_CONV_SWP 0
+#endif
+#ifndef AMX_CONV_EXACT
+#define AMX_CONV_EXACT 0
+#endif
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+    constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
+    constexpr int NB = NT * 16;
+    constexpr int MAXI = TILE + 2 * MAXHALO;
+    constexpr int XLD = ((TH + 2 * MAXHALO) * MAXI * KG + 255) / 256;          // float4 loads per thread (input)
+    constexpr int WLD = (TAPS * KG * NB + 255) / 256;            // float4 loads per thread (weights)
+    AMX_DYN_SMEM(float, smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int halo = (TAPS == 9) ? ((AMX_CONV_EXACT && MAXHALO == 1) ? 1 : a.dil) : 0;
+    const int IW = TILE + 2 * halo, IH = TH + 2 * halo;
+    const int plane = amx_round_up(IH * IW, 16);                 // slots (16 B) per k-group plane
+    // one stage = input image [KG][plane][4] + weight image [TAPS][KG][NB][4]; two stages when DBUF
+    const int stage_floats = KG * plane * 4 + TAPS * KG * NB * 4;
+    float* s_red = smem;                                         // reused after the K loop
+
+    // logical (tile, cout-block) of this workgroup: cout blocks of one tile adjacent, tiles in raster order,
+    // contiguous ranges of them per XCD
+    unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.xcd) lin = amx_xcd_remap(lin, gridDim.x * gridDim.y);
+    int t = a.xcd ? (int)(lin / gridDim.y) : (int)blockIdx.x;
+    const int ob = a.xcd ? (int)(lin % gridDim.y) : (int)blockIdx.y;
+    const int tile_id = t;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
+    const int n0 = ob * NB;                                      // first cout of this workgroup
+    const int gy0 = ty * TH - halo, gx0 = tx * TILE - halo;
+
+    // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
+    const int my_kg = tid & (KG - 1);
+    const int nslots = IH * IW;
+    int x_off[XLD];                                              // pixel offset ((n*H+y)*W+x) or -1
+    #pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+        const int pix = (tid + i * 256) >> 2;
+        int off = -1;
+        if (pix < nslots) {
+            const int iy = pix / IW, ix = pix - iy * IW;
+            const int gy = gy0 + iy, gx = gx0 + ix;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) off = (n * a.H + gy) * a.W + gx;
+        }
+        x_off[i] = off;
+    }
+
+    float4 xr[XLD];
+    float4 wr[WLD];
+    float4 r_sc, r_sh, r_k3;
+    float r_islope = 1.f;                                        // post-affine LeakyReLU slope of this thread's source
+    int r_ch = -1;                                               // FUSED: channel of this thread's group in src0
+
+    auto issue_loads = [&](int chunk) {
+        const int ch = (chunk * KG + my_kg) * 4;                 // channel in the concatenated space
+        const float* src = nullptr; const float* sc = nullptr; const float* sh = nullptr;
+        int Cs = 0, c = 0;
+        if (ch < a.C0s) { src = a.x0; sc = a.sc0; sh = a.sh0; Cs = a.C0s; c = ch; }
+        else if (ch - a.C0s < a.C1s) { src = a.x1; sc = a.sc1; sh = a.sh1; Cs = a.C1s; c = ch - a.C0s; }
+        r_sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        r_k3 = r_sh;
+        if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
+        r_islope = src == a.x1 ? a.in_slope1 : a.in_slope0;
+        if (FUSED) {
+            r_ch = src == a.x0 ? c : -1;
+            if (r_ch >= 0 && a.k1) { r_sc = amx_ld4(a.k1 + c); r_sh = amx_ld4(a.k2 + c); r_k3 = amx_ld4(a.k3 + c); }
+        }
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
+        }
+        const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
+        #pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int idx = tid + i * 256;                       // over [TAPS*KG][NB]
+            wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TAPS * KG * NB) {
+                const int row = idx / NB, col = idx - row * NB;
+                if (n0 + col < a.cop) wr[i] = amx_ld4(wsrc + ((size_t)row * a.cop + n0 + col) * 4);
+            }
+        }
+    };
+
+    auto stage_to_lds = [&](int stage) {
+        float* s_in = smem + (size_t)stage * stage_floats;
+        float* s_w = s_in + KG * plane * 4;
+        #pragma unroll
+        for (int i = 0; i < XLD; ++i) {
+            const int pix = (tid + i * 256) >> 2;
+            if (pix < nslots) {
+                float4 v = xr[i];
+                if (FUSED && a.aux0) {                           // dpre = lrelu'(a) * (k1*dy + k2*a + k3)
+                    // the saved activation is fetched here (not prefetched): keeps the register footprint, and
+                    // with it the number of co-resident workgroups, equal to the plain kernel's
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (x_off[i] >= 0 && r_ch >= 0) t = amx_ld4(a.aux0 + (size_t)x_off[i] * a.C0s + r_ch);
+                    v.x = (t.x > 0.f ? 1.f : a.bslope) * fmaf(r_sc.x, v.x, fmaf(r_sh.x, t.x, r_k3.x));
+                    v.y = (t.y > 0.f ? 1.f : a.bslope) * fmaf(r_sc.y, v.y, fmaf(r_sh.y, t.y, r_k3.y));
+                    v.z = (t.z > 0.f ? 1.f : a.bslope) * fmaf(r_sc.z, v.z, fmaf(r_sh.z, t.z, r_k3.z));
+                    v.w = (t.w > 0.f ? 1.f : a.bslope) * fmaf(r_sc.w, v.w, fmaf(r_sh.w, t.w, r_k3.w));
+                    if (x_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (x_off[i] >= 0) {                      // padding stays exactly zero
+                    v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
+                    v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                    if (r_islope != 1.f) {
+                        v.x = v.x > 0.f ? v.x : v.x * r_islope; v.y = v.y > 0.f ? v.y : v.y * r_islope;
+                        v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
+                    }
+                }
+                amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < TAPS * KG * NB) amx_st4(s_w + (size_t)idx * 4, wr[i]);
+        }
+    };
+
+    f32x4 acc[MTW][NT];
+    #pragma unroll
+    for (int m = 0; m < MTW; ++m)
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#if AMX_CONV_SWP
+    // software-pipelined operand fragments (experiment): tap t+1's ds_read_b128s are issued into a second register
+    // set before tap t's MFMAs
+    auto compute_taps = [&](int stage, int tap0, int tap1) {
+        const float* s_in = smem + (size_t)stage * stage_floats;
+        const float* s_w = s_in + KG * plane * 4;
+        auto load_frag = [&](int tap, float4* af, float4* bf) {
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * halo : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * halo : 0;
+            #pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
+                af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
+            }
+            #pragma unroll
+            for (int q = 0; q < NT; ++q)
+                bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+        };
+        #define AMX_CONV_MFMA(A_, B_, C)                                                            \
+            _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
+                _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m].C, B_[q].C, acc[m][q], 0, 0, 0);
+        #define AMX_CONV_TAP(A_, B_) AMX_CONV_MFMA(A_, B_, x) AMX_CONV_MFMA(A_, B_, y) AMX_CONV_MFMA(A_, B_, z) AMX_CONV_MFMA(A_, B_, w)
+        float4 af0[MTW], bf0[NT], af1[MTW], bf1[NT];
+        load_frag(0, af0, bf0);
+        #pragma unroll
+        for (int tap = 0; tap < TAPS; tap += 2) {
+            if (tap + 1 < TAPS) load_frag(tap + 1, af1, bf1);
+            amx_sched_fence();                                   // the reads of tap+1 stay ahead of this tap's MFMAs
+            AMX_CONV_TAP(af0, bf0)
+            if (tap + 1 < TAPS) {
+                if (tap + 2 < TAPS) load_frag(tap + 2, af0, bf0);
+                amx_sched_fence();
+                AMX_CONV_TAP(af1, bf1)
+            }
+        }
+        #undef AMX_CONV_TAP
+        #undef AMX_CONV_MFMA
+    };
+#else
+    auto compute_taps = [&](int stage, int tap0, int tap1) {
+        const float* s_in = smem + (size_t)stage * stage_floats;
+        const float* s_w = s_in + KG * plane * 4;
+        #pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (tap < tap0 || tap >= tap1) continue;
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            float4 af[MTW], bf[NT];
+            #pragma unroll
+            for (int m = 0; m < MTW; ++m) {
+                const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
+                af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
+            }
+            #pragma unroll
+            for (int q = 0; q < NT; ++q)
+                bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+            // k-subgroup outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32 MFMA has a
+            // 40-cycle dependent latency vs a 32-cycle issue interval)
+            #define AMX_CONV_MFMA(C)                                                                    \
+                _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
+                    _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
+            AMX_CONV_MFMA(x) AMX_CONV_MFMA(y) AMX_CONV_MFMA(z) AMX_CONV_MFMA(w)
+            #undef AMX_CONV_MFMA
+        }
+    };
+#endif
+
+    // Last chunk with fewer than KG valid k-groups (channel counts that are not multiples of 16, e.g. dilnet's
+    // 25 / 50 filters -> 28 / 52 stored channels): one MFMA per valid k-group and tap instead of four, with the
+    // k index of the MFMA running over the 4 channels of ONE k-group (scalar ds_read_b32, lane g = channel g).
+    auto compute_tail = [&](int nkg) {
+        const float* s_in = smem;
+        const float* s_w = s_in + KG * plane * 4;
+        #pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            #pragma unroll
+            for (int j = 0; j < KG - 1; ++j) {
+                if (j >= nkg) break;
+                float af[MTW], bf[NT];
+                #pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
+                    af[m] = s_in[((size_t)j * plane + slot) * 4 + g];
+                }
+                #pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    bf[q] = s_w[((size_t)(tap * KG + j) * NB + q * 16 + p) * 4 + g];
+                #pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    #pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[q], acc[m][q], 0, 0, 0);
+            }
+        }
+    };
+
+    issue_loads(0);
+    if (DBUF) {
+        // Software pipeline over two LDS stages: the global loads of chunk c+1 are issued before, and their
+        // LDS image is written in the middle of, the MFMA stream of chunk c -> ONE barrier per chunk and no
+        // staging gap in the matrix pipe.
+        stage_to_lds(0);
+        __syncthreads();
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            const int cur = chunk & 1;
+            const bool more = chunk + 1 < a.nchunk;
+            if (more) issue_loads(chunk + 1);
+            compute_taps(cur, 0, (TAPS + 1) / 2);
+            if (more) stage_to_lds(cur ^ 1);
+            compute_taps(cur, (TAPS + 1) / 2, TAPS);
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            stage_to_lds(0);
+            __syncthreads();
+            if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
+            if (TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
+            else compute_taps(0, 0, TAPS);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU (+addend), store, statistics ----
+    // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
+    const int oy0 = ty * TH + wave * MTW, ox0 = tx * TILE + 4 * g;
+    const int ctot = a.Y0s + a.Y1s;
+    float lsum[NT], lsum2[NT];
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int co = n0 + q * 16 + p;
+        lsum2[q] = 0.f;
+        const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+        float* dst = nullptr; int Cd = 0, cd = 0;
+        if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; }
+        else if (co < ctot) { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
+        lsum[q] = 0.f;
+        #pragma unroll
+        for (int m = 0; m < MTW; ++m)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + m, ox = ox0 + r;
+                float v = acc[m][q][r] + b;
+                v = v > 0.f ? v : v * a.slope;
+                const bool ok = (oy < a.H) && (ox < a.W) && dst;
+                if (ok) {
+                    const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
+                    if (a.addend && dst == a.y) v += a.addend[o];
+                    dst[o] = v;
+                    lsum[q] += v;
+                    if (FUSED && a.bstats) {
+                        const float* ea = dst == a.y ? a.ea0 : a.ea1;
+                        if (ea) lsum2[q] = fmaf(v, ea[o], lsum2[q]);
+                    }
+                } else {
+                    v = 0.f;
+                }
+                acc[m][q][r] = v;
+            }
+    }
+    if (FUSED && a.bstats) {
+        // backward statistics of the source layers' BatchNorm: per-tile (sum dy, sum dy*a) per channel
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            float s1 = lsum[q], s2 = lsum2[q];
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (g == 0) { s_red[wave * NB + q * 16 + p] = s1; s_red[(4 + wave) * NB + q * 16 + p] = s2; }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int which = tid / NB, c = tid - which * NB;
+            const int co = n0 + c;
+            if (co < a.cop) {
+                const float* r = s_red + which * 4 * NB;
+                a.bstats[((size_t)tile_id * 2 + which) * a.cop + co] = r[c] + r[NB + c] + r[2 * NB + c] + r[3 * NB + c];
+            }
+        }
+        return;
+    }
+    if (!a.stats) return;
+
+    const int vy = min(TH, a.H - ty * TH), vx = min(TILE, a.W - tx * TILE);
+    const float inv_cnt = 1.0f / (float)(vy * vx);
+    // pass 1: per-cout sum over the tile -> mean
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        float s = lsum[q];
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        if (g == 0) s_red[wave * NB + q * 16 + p] = s;
+    }
+    __syncthreads();
+    float mean[NT];
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int c = q * 16 + p;
+        mean[q] = (s_red[c] + s_red[NB + c] + s_red[2 * NB + c] + s_red[3 * NB + c]);
+    }
+    __syncthreads();
+    // pass 2: M2 about the tile mean
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const float mu = mean[q] * inv_cnt;
+        float s2 = 0.f;
+        #pragma unroll
+        for (int m = 0; m < MTW; ++m)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
+                const float d = acc[m][q][r] - mu;
+                s2 += ok ? d * d : 0.f;
+            }
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        if (g == 0) s_red[wave * NB + q * 16 + p] = s2;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        const int co = n0 + tid;
+        if (co < a.cop) {
+            const float m2 = s_red[tid] + s_red[NB + tid] + s_red[2 * NB + tid] + s_red[3 * NB + tid];
+            a.stats[((size_t)tile_id * 2 + 1) * a.cop + co] = m2;
+        }
+    }
+    // tile sums: every lane holds mean[q] (= tile sum) for column q*16+p; 16 lanes of wave 0 write them
+    if (wave == 0 && g == 0) {
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int co = n0 + q * 16 + p;
+            if (co < a.cop) a.stats[(size_t)tile_id * 2 * a.cop + co] = mean[q];
+        }
+    }
+}
+
+template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
+static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
+    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int I = TILE + 2 * halo;
+    const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
+    size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
+    if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
+    const size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
+    dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
+#ifndef AMX_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+#endif
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>), grid, dim3(256), lds, stream, a);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// dispatchers of the three instantiation units (nt in {1,2,4}; th in {8,16})
+int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
+int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
+int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);

@@ -34,6 +34,9 @@ struct WgradArgs {
     int co_blocks;
 };
 
+#ifndef AMX_WGRAD_EXACT
+#define AMX_WGRAD_EXACT 1        // compile-time experiment switch (tools/build_variant_lib.sh): 0 = runtime halo as in round 1
+#endif
 template <int TAPS, int NT, int WM, int MAXHALO, int TH>
 // Forcing two waves per SIMD for the wide variant (191 + 72 registers -> 256 with 6 spills) was measured in-step with
 // tools/gpu_lib_ab.py: 20.82 ms (256 workgroups) / 20.50 ms (384) against 20.34 ms for one wave per SIMD -> rejected.
@@ -50,10 +53,14 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
-    const int halo = (TAPS == 9) ? a.dil : 0;
+    // plain 3x3 (MAXHALO == 1 is dispatched for dilation 1 only): compile-time tile geometry, so the per-tile index
+    // math of the loaders divides by constants (a runtime integer division is ~25 VALU instructions, and with one
+    // wave per SIMD nothing hides the staging phase)
+    const int halo = (TAPS == 9) ? ((AMX_WGRAD_EXACT && MAXHALO == 1) ? 1 : a.dil) : 0;
     const int IW = TW + 2 * halo, IH = TH + 2 * halo;
     const int COB = 16 * NT * a.WN;
-    const int DG = COB / 4;                                       // float4 groups per pixel (dpre)
+    const int DG = COB / 4;                                       // float4 groups per pixel (dpre): 4, 8 or 16
+    const int dg_shift = DG == 4 ? 2 : (DG == 8 ? 3 : 4);
     const int SD = (COB % 32 == 16) ? COB : COB + 16;
     float* s_x = smem;                                            // [IH*IW][SX]
     float* s_d = smem + (size_t)IH * IW * SX;                     // [TH*TW][SD]
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
             dr[i] = make_float4(0, 0, 0, 0);
             d_off[i] = -1;
             if (idx < nd4) {
-                const int pix = idx / DG, dg = idx - pix * DG;
+                const int pix = idx >> dg_shift, dg = idx & (DG - 1);
                 const int iy = pix / TW, ix = pix - iy * TW;
                 const int gy = ty * TH + iy, gx = tx * TW + ix;
                 const int c = co0 + dg * 4;
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
         for (int i = 0; i < DLD_MAX; ++i) {
             const int idx = tid + i * 256;
             if (idx < nd4) {
-                const int pix = idx / DG, dg = idx - pix * DG;
+                const int pix = idx >> dg_shift, dg = idx & (DG - 1);
                 float4 v = dr[i];
                 if (a.aux) {
                     // dpre = lrelu'(a) * (k1*dy + k2*a + k3); a is fetched here rather than prefetched so that the

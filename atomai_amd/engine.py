@@ -26,15 +26,14 @@ BN_MOMENTUM = 0.1
 
 import os as _os
 # Backward fusion switches, chosen by measurement:
-#   1: dpre formed in the dgrad loader      4: dpre formed in the wgrad loader
-#   2: BN-backward sums emitted by the pool / px backward kernels that write the final dy
-#   8: BN-backward sums emitted by the dgrad epilogue that writes the final dy
-# Interleaved in-process A/B on MI355X (tools/gpu_fuse_ab.py, U-Net bs 32 512^2, ms/step, min of 3):
-#   0: 20.76   2: 20.22   10: 21.22   15: 22.40      (earlier, noisier harness: 0: 22.30  2: 22.11  8: 22.90  5: 23.35)
+#   2: BN-backward sums emitted by the pool / px backward kernels that write the final dy   (default: on)
+#   4: dpre formed in the wgrad loader (experiment; off)
+# Interleaved in-process A/B on MI355X in round 1 (U-Net bs 32 512^2, ms/step, min of 3):
+#   0: 20.76   2: 20.22   [dgrad-loader / dgrad-epilogue fusions, bits 1 and 8: 21.22 - 22.40]
 # -> moving the HBM-bound BatchNorm-backward passes INTO the MFMA kernels costs them more (registers ->
-#    fewer co-resident workgroups, exposed load latency) than the removed passes save; only the sums emitted
-#    by the pool / px backward kernels are kept by default.
-FUSE = int(_os.environ.get("AMX_FUSE", "2"))
+#    fewer co-resident workgroups, exposed load latency) than the removed passes save.  Bits 1 and 8 (fusion into the
+#    data-gradient kernel) were removed in round 2 together with their register cost in the convolution kernel.
+FUSE = int(_os.environ.get("AMX_FUSE", "2")) & 6
 
 
 def r4(c: int) -> int:
@@ -84,8 +83,9 @@ class Act:
 
     def wants_bstats(self, node, training: bool) -> bool:
         """True if `node` writes the final gradient of this activation and its producer needs BN-backward sums."""
-        bit = 8 if isinstance(node, ConvNode) else 2
-        return (bool(FUSE & bit) and training and self.producer and self.gx is None
+        if isinstance(node, ConvNode):
+            return False                                  # the data-gradient kernel emits no statistics
+        return (bool(FUSE & 2) and training and self.producer and self.gx is None
                 and self.needs_grad and self.first_consumer == id(node))
 
     @property
@@ -304,11 +304,9 @@ class ConvNode(_Node):
 
     # -------------------------------------------------------------------------------- backward
     def backward(self, tape) -> None:
-        """BatchNorm + LeakyReLU backward are FUSED into the loaders of the weight- and data-gradient kernels
-        (dpre = lrelu'(a) * (k1*dy + k2*a + k3) is formed on the fly from dy and the saved activation a), and
-        the per-channel sums BatchNorm backward needs (sum dy, sum dy*a) are emitted by whichever kernel wrote
-        the final dy (dgrad / pool / px epilogues).  The standalone reduce / apply kernels remain as the
-        fallback for DilatedBlock's extra-gradient terms."""
+        """BatchNorm backward: per-channel sums (emitted by the pool / px backward kernel that wrote the final dy, or
+        by amx_bn_bwd_reduce) -> amx_bn_bwd_finalize -> dpre = lrelu'(a) * (k1*dy + k2*a + k3) materialised by
+        amx_bn_bwd_apply; then the weight gradient (side stream) and the data gradient read dpre."""
         out = self.out
         dy = out.grad if out.grad is not None else out.gx
         if dy is None:
@@ -327,7 +325,7 @@ class ConvNode(_Node):
             L.call("amx_lrelu_bwd", L.ptr(dy), L.ptr(a), L.ptr(out.scale), L.ptr(out.shift), self.post_slope,
                    npix, cos, L.ptr(masked), None, sp)
             dy = masked
-        fused = out.gx is None and bool(FUSE & 5)
+        fused = out.gx is None and bool(FUSE & 4)
         k = None
         aux = None
         bias_part = None
@@ -350,7 +348,7 @@ class ConvNode(_Node):
             tape.add_param_grad(bn.bias, dbeta)
         needs_transform = self.bn is not None or self.slope != 1.0 or out.gx is not None
         dpre_mat = None
-        if needs_transform and fused and (FUSE & 5) != 5:
+        if needs_transform and fused:
             # experiment mode: one of the two consumers still wants a materialised dpre
             arows = L.load().amx_rows_for(npix)
             bias_part = _empty((arows, cos), a) if has_bias else None
@@ -379,8 +377,8 @@ class ConvNode(_Node):
         dw = grad_buffer(w, a)
         want_bias = has_bias and bias_part is None
         # The weight gradient (MFMA-bound) has no consumer inside backward: side stream.
-        w_in = (dpre, aux, kptr) if (dpre_mat is None or FUSE & 4) else (dpre_mat, None, (None, None, None))
-        d_in = (dpre, aux, kptr) if (dpre_mat is None or FUSE & 1) else (dpre_mat, None, (None, None, None))
+        w_in = (dpre, aux, kptr)
+        d_in = (dpre, aux, kptr) if dpre_mat is None else (dpre_mat, None, (None, None, None))
         with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
             self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         if self.x_plain is not None:
@@ -501,22 +499,9 @@ class ConvNode(_Node):
             y1 = scratch
         else:
             scratch, y1 = None, tgt[1][0]
-        # backward statistics for the sources whose final gradient this launch writes
-        ea0 = s0.t if s0.wants_bstats(self, tape.training) else None
-        ea1 = s1.t if (s1 is not None and scratch is None and s1.wants_bstats(self, tape.training)) else None
-        bstats = None
-        if ea0 is not None or ea1 is not None:
-            th = L.load().amx_conv2d_tile_h(cos, C0s + C1s, self.taps, self.dil, H)
-            tiles = L.load().amx_conv2d_num_tiles(N, H, W, th)
-            cop_d = r16(C0s + C1s)
-            bstats = _empty((tiles, 2, cop_d), dpre)
-            if ea0 is not None:
-                s0.bstats = (bstats, tiles, cop_d, 0)
-            if ea1 is not None:
-                s1.bstats = (bstats, tiles, cop_d, C0s)
-        L.call("amx_conv2d_dgrad", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope, cos,
-               L.ptr(wpk), L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, L.ptr(ea0), L.ptr(ea1),
-               L.ptr(bstats), N, H, W, self.taps, self.dil, sp)
+        assert aux is None, "the data-gradient kernel takes a materialised dpre"
+        L.call("amx_conv2d_dgrad", L.ptr(dpre), cos, L.ptr(wpk), L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s,
+               N, H, W, self.taps, self.dil, sp)
         if scratch is not None:
             L.call("amx_add_inplace", L.ptr(tgt[1][0]), L.ptr(scratch), scratch.numel(), sp)
 

@@ -146,8 +146,15 @@ class SegPredictor(BasePredictor):
         copy_in, copy_out = aux_stream(dev, 1), aux_stream(dev, 2)
         main = torch.cuda.current_stream(dev)
         NS = 3                                      # chunks in flight (host runs up to NS chunks ahead of the GPU)
-        pin_in = [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(NS)]
-        pin_out = [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(NS)]
+        # pinned staging buffers are kept on the predictor: allocating 6 x 64 MB of page-locked memory costs more
+        # than decoding a hundred frames
+        key = (tuple(data.shape[1:]), tuple(out_shape[1:]))
+        pinned = getattr(self, "_pinned", None)
+        if pinned is None or pinned[0] != key or len(pinned[1][0]) < chunk:
+            self._pinned = (key,
+                            [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(NS)],
+                            [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(NS)])
+        pin_in, pin_out = self._pinned[1], self._pinned[2]
         stage = {}                                  # chunk index -> its in-flight state
 
         # Software pipeline over chunks, NS of them in flight.  The DOWNLOAD is a copy kernel on a side stream that

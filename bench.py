@@ -94,8 +94,8 @@ class KernelTimer:
             fl = 0.0
             if name == "amx_conv2d_fwd":      # (.., C0s@3, .., C1s@7, .., N@16,H@17,W@18,cout@19,taps@20, ..)
                 fl = 2.0 * (args[3] + args[7]) * args[19] * args[20] * args[16] * args[17] * args[18]
-            elif name == "amx_conv2d_dgrad":  # (dy,aux,k1,k2,k3,bslope,Cs@6,wpk,addend,y,Y0s@10,y1,Y1s@12,..,N@16,H,W,taps@19)
-                fl = 2.0 * args[6] * (args[10] + args[12]) * args[19] * args[16] * args[17] * args[18]
+            elif name == "amx_conv2d_dgrad":  # (dpre,Cs@1,wpk,addend,y,Y0s@5,y1,Y1s@7,N@8,H@9,W@10,taps@11,dil,stream)
+                fl = 2.0 * args[1] * (args[5] + args[7]) * args[11] * args[8] * args[9] * args[10]
                 name = "amx_conv2d_fwd"       # same kernel (conv_fwd_kernel): one family
             elif name == "amx_conv2d_wgrad":  # (.., C0s@3, .., C1s@7, dpre@8, Dos@9, part@10, N@11,H,W,cout@14,taps@15)
                 fl = 2.0 * (args[3] + args[7]) * args[14] * args[15] * args[11] * args[12] * args[13]
@@ -167,8 +167,18 @@ class ClockSampler(threading.Thread):
     def __init__(self, local=0):
         super().__init__(daemon=True)
         self.samples, self._stop_ev = [], threading.Event()
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self.path = cards[min(local, len(cards) - 1)] if cards else None
+        self.path = None
+        try:                                   # the sysfs node of THIS device, found through its PCI address
+            pr = torch.cuda.get_device_properties(local)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cand = f"/sys/bus/pci/devices/{bdf}/pp_dpm_sclk"
+            if os.path.exists(cand):
+                self.path = cand
+        except Exception:
+            pass
+        if self.path is None:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+            self.path = cards[min(local, len(cards) - 1)] if cards else None
 
     def read(self):
         if not self.path:

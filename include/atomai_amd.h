@@ -39,10 +39,8 @@ int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
                    const float* wpk, const float* bias, const float* addend,
                    float* y, int Y0s, float* y1, int Y1s, float* stats,
                    int N, int H, int W, int cout, int taps, int dil, float slope, void* stream);
-int amx_conv2d_dgrad(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
-                     float bslope, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
-                     int Y1s, const float* ea0, const float* ea1, float* bstats, int N, int H, int W, int taps,
-                     int dil, void* stream);
+int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
+                     int Y1s, int N, int H, int W, int taps, int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
 

@@ -48,7 +48,7 @@ def test_launched_conv_flops_match_the_table():
         if name == "amx_conv2d_fwd":
             flops[0] += 2.0 * (a[3] + a[7]) * a[19] * a[20] * a[16] * a[17] * a[18]
         elif name == "amx_conv2d_dgrad":
-            flops[0] += 2.0 * a[6] * (a[10] + a[12]) * a[19] * a[16] * a[17] * a[18]
+            flops[0] += 2.0 * a[1] * (a[5] + a[7]) * a[11] * a[8] * a[9] * a[10]
         elif name == "amx_conv2d_wgrad_fused":
             flops[0] += 2.0 * (a[3] + a[7]) * a[20] * a[21] * a[17] * a[18] * a[19]
         return orig(name, *a)
