@@ -456,7 +456,12 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
     if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
-    const size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
+    size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
+    // occupancy experiment: AMX_CONV_MAXWG=k pads the LDS request so that at most k workgroups fit a CU
+    if (const char* e = getenv("AMX_CONV_MAXWG")) {
+        const int k = atoi(e);
+        if (k >= 1 && k <= 8) { const size_t want = (size_t)(160 * 1024 / k) / 256 * 256; if (want > lds) lds = want; }
+    }
     dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
 #ifndef AMX_EMU
     static bool attr_set = false;

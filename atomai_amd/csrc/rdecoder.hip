@@ -23,7 +23,11 @@
 #include <cstdlib>
 
 struct RDecArgs {
-    const float* coords;   // [B][n][2] transformed pixel coordinates
+    const float* coords;   // theta == nullptr: [B][n][2] transformed pixel coordinates;  else the grid [n][2]
+    const float* theta;    // [B][3] (phi, dx, dy) or nullptr: x' = x cos(phi) - y sin(phi) + dx, y' = x sin(phi) + y cos(phi) + dy
+                           // formed per pixel IN the kernel (atomai/utils/coords.py:57-83 materialises (B, n, 2))
+    float* dtheta;         // [B][3] gradient w.r.t. (phi, dx, dy)   (backward, theta mode)
+    int C;                 // output channels (xrec / dxrec are [B][n][C], Wo is [C][HID], bo is [C])
     const float* z;        // [B][L]
     const float* Wc;       // [HID][2]
     const float* bc;       // [HID]
@@ -31,16 +35,16 @@ struct RDecArgs {
     const float* W;        // [NL][HID][HID]
     const float* Wt;       // [NL][HID][HID] transposed copies (backward only)
     const float* b;        // [NL][HID]
-    const float* Wo;       // [HID]
-    const float* bo;       // [1]
-    float* xrec;           // [B][n]                     (forward)
-    const float* dxrec;    // [B][n]                     (backward)
-    float* dcoords;        // [B][n][2]
+    const float* Wo;       // [C][HID]
+    const float* bo;       // [C]
+    float* xrec;           // [B][n][C]                  (forward)
+    const float* dxrec;    // [B][n][C]                  (backward)
+    float* dcoords;        // [B][n][2]                  (backward, explicit-coordinate mode)
     float* dz;             // [B][L]
     float* pW;             // [B][NL][HID][HID] partial rows
     float* pb;             // [B][NL][HID]
-    float* pWo;            // [B][HID]
-    float* pbo;            // [B]
+    float* pWo;            // [B][C][HID]
+    float* pbo;            // [B][C]
     float* pWc;            // [B][HID][2]
     float* pbc;            // [B][HID]
     float* pWz;            // [B][HID][L]
@@ -48,6 +52,7 @@ struct RDecArgs {
 };
 
 #define MAXL 8
+#define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
 
 // tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware exp / reciprocal units: 5 VALU instructions instead of the ~35 of
 // the library tanhf, which otherwise costs as many issue cycles per tile as the layer's MFMAs (48 tanh per lane and
@@ -78,7 +83,7 @@ struct Geo {
 // h0 tile -> dst (KG layout).  Also stores x',y' per pixel when s_xy != nullptr.
 template <int HID, int MT>
 __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix0, const float* s_zc,
-                                            float* dst, float* s_xy, int tid) {
+                                            float* dst, float* s_xy, const float* s_th, int tid) {
     using G = Geo<HID, MT>;
     #pragma unroll
     for (int i = 0; i < G::SPT; ++i) {
@@ -87,8 +92,15 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
         const int q = pix0 + p;
         float4 h = make_float4(0, 0, 0, 0);
         if (q < a.n) {
-            const float xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
-            const float yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+            float xx, yy;
+            if (s_th) {                                    // rotate + translate the shared grid point
+                const float gx = a.coords[(size_t)q * 2 + 0], gy = a.coords[(size_t)q * 2 + 1];
+                xx = gx * s_th[0] - gy * s_th[1] + s_th[2];
+                yy = gx * s_th[1] + gy * s_th[0] + s_th[3];
+            } else {
+                xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
+                yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+            }
             if (s_xy && kg == 0) { s_xy[2 * p] = xx; s_xy[2 * p + 1] = yy; }
             const int f = kg * 4;
             h.x = fmaf(a.Wc[2 * f + 0], xx, fmaf(a.Wc[2 * f + 1], yy, s_zc[f + 0]));
@@ -142,33 +154,41 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
     }
 }
 
-// out[p] = Wo . h[p] + bo for the tile; result left in s_out[0..MT)
+// out[p][c] = Wo[c] . h[p] + bo[c] for the tile; result left in s_out[c * MT + p]
 template <int HID, int MT>
 __device__ __forceinline__ void output_layer(const RDecArgs& a, const float* h, float* s_part, float* s_out,
                                              int tid) {
     using G = Geo<HID, MT>;
     const int p = tid % MT, part = tid / MT;
-    float acc = 0.f;
-    for (int kg = part; kg < G::KG; kg += G::TPP) {
-        const float4 v = amx_ld4(h + ((size_t)kg * MT + p) * 4);
-        const float4 w = amx_ld4(a.Wo + kg * 4);
-        acc = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc))));
+    for (int c = 0; c < a.C; ++c) {
+        float acc = 0.f;
+        for (int kg = part; kg < G::KG; kg += G::TPP) {
+            const float4 v = amx_ld4(h + ((size_t)kg * MT + p) * 4);
+            const float4 w = amx_ld4(a.Wo + (size_t)c * HID + kg * 4);
+            acc = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc))));
+        }
+        s_part[part * MT + p] = acc;
+        __syncthreads();
+        if (tid < MT) {
+            float t = a.bo[c];
+            #pragma unroll
+            for (int q = 0; q < G::TPP; ++q) t += s_part[q * MT + tid];
+            s_out[c * MT + tid] = t;
+        }
+        __syncthreads();
     }
-    s_part[part * MT + p] = acc;
-    __syncthreads();
-    if (tid < MT) {
-        float t = a.bo[0];
-        #pragma unroll
-        for (int q = 0; q < G::TPP; ++q) t += s_part[q * MT + tid];
-        s_out[tid] = t;
-    }
-    __syncthreads();
 }
 
 // zc[f] = bc[f] + sum_l Wz[f][l] z[l]
 template <int HID>
-__device__ __forceinline__ void latent_bias(const RDecArgs& a, int bidx, float* s_zc, float* s_z, int tid) {
+__device__ __forceinline__ void latent_bias(const RDecArgs& a, int bidx, float* s_zc, float* s_z, float* s_th,
+                                            int tid) {
     if (tid < a.L) s_z[tid] = a.z[(size_t)bidx * a.L + tid];
+    if (a.theta && tid == 0) {                   // (cos phi, sin phi, dx, dy) of this sample
+        const float phi = a.theta[(size_t)bidx * 3];
+        s_th[0] = cosf(phi); s_th[1] = sinf(phi);
+        s_th[2] = a.theta[(size_t)bidx * 3 + 1]; s_th[3] = a.theta[(size_t)bidx * 3 + 2];
+    }
     __syncthreads();
     if (tid < HID) {
         float v = a.bc[tid];
@@ -189,13 +209,15 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     float* s_zc = buf1 + G::BUF * (a.skip ? 2 : 1);
     float* s_z = s_zc + HID;
     float* s_part = s_z + MAXL;
-    float* s_out = s_part + G::TPP * MT;
+    float* s_out = s_part + G::TPP * MT;              // [MAXC][MT]
+    float* s_th = s_out + MAXC * MT;                  // [4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bidx = blockIdx.x;
-    latent_bias<HID>(a, bidx, s_zc, s_z, tid);
+    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid);
+    const float* th = a.theta ? s_th : nullptr;
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         float* h0 = a.skip ? buf2 : buf0;
-        coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, tid);
+        coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid);
         __syncthreads();
         const float* src = h0;
         for (int l = 0; l < a.NL; ++l) {
@@ -206,7 +228,10 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
             src = dst;
         }
         output_layer<HID, MT>(a, src, s_part, s_out, tid);
-        if (tid < MT && pix0 + tid < a.n) a.xrec[(size_t)bidx * a.n + pix0 + tid] = s_out[tid];
+        for (int e = tid; e < MT * a.C; e += G::NT) {                 // xrec[b][pixel][channel]
+            const int pp = e / a.C, c = e - pp * a.C;
+            if (pix0 + pp < a.n) a.xrec[((size_t)bidx * a.n + pix0 + pp) * a.C + c] = s_out[c * MT + pp];
+        }
         __syncthreads();
     }
 }
@@ -223,13 +248,16 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     float* s_zc = smem + (size_t)(NL + 1 + (a.skip ? 1 : 0)) * G::BUF;
     float* s_z = s_zc + HID;
     float* s_part = s_z + MAXL;
-    float* s_out = s_part + G::TPP * MT;           // x_rec, then dout
-    float* s_xy = s_out + MT;                      // [MT][2]
+    float* s_out = s_part + G::TPP * MT;           // dout [MAXC][MT]
+    float* s_xy = s_out + MAXC * MT;               // [MT][2]
     float* s_red = s_xy + 2 * MT;                  // [NT] float4 scratch for the final reductions
+    float* s_th = s_red + 4 * G::NT;               // [4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
     const int bidx = blockIdx.x;
-    latent_bias<HID>(a, bidx, s_zc, s_z, tid);
+    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid);
+    const float* th = a.theta ? s_th : nullptr;
+    float a_phi = 0.f, a_tr = 0.f;                 // theta mode: thread (pixel slot, component) partial sums
 
     // persistent accumulators
     f32x4 accW[NL][HID / 16];
@@ -241,12 +269,14 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         for (int c = 0; c < HID / 16; ++c) accW[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // per-feature accumulators owned by thread f = tid < HID (kept out of the MFMA waves' register budget)
-    float aWo = 0.f, aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
-    float abo = 0.f;
+    float aWo[MAXC], aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
+    float abo[MAXC];
+    #pragma unroll
+    for (int c = 0; c < MAXC; ++c) { aWo[c] = 0.f; abo[c] = 0.f; }
 
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
-        coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, tid);
+        coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
         __syncthreads();
         #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -255,26 +285,36 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             __syncthreads();
         }
         // ---- output layer backward: dout, dWo, dbo, ga_NL (in place over H[NL])
-        if (tid < MT) {
-            const int q = pix0 + tid;
-            s_out[tid] = q < a.n ? a.dxrec[(size_t)bidx * a.n + q] : 0.f;
+        for (int e = tid; e < MT * a.C; e += G::NT) {
+            const int pp = e / a.C, c = e - pp * a.C;
+            const int q = pix0 + pp;
+            s_out[c * MT + pp] = q < a.n ? a.dxrec[((size_t)bidx * a.n + q) * a.C + c] : 0.f;
         }
         __syncthreads();
-        if (tid < MT) abo += s_out[tid];
-        if (tid < HID) {                         // dWo[f] += sum_p dout[p] * h_NL[p][f]
-            const float* hf = H[NL] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
-            #pragma unroll 8
-            for (int pp = 0; pp < MT; ++pp) aWo = fmaf(s_out[pp], hf[pp * 4], aWo);
+        #pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c >= a.C) break;
+            if (tid < MT) abo[c] += s_out[c * MT + tid];
+            if (tid < HID) {                     // dWo[c][f] += sum_p dout[p][c] * h_NL[p][f]
+                const float* hf = H[NL] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
+                float t = aWo[c];
+                #pragma unroll 8
+                for (int pp = 0; pp < MT; ++pp) t = fmaf(s_out[c * MT + pp], hf[pp * 4], t);
+                aWo[c] = t;
+            }
         }
         __syncthreads();
         #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
             const int s = tid + i * G::NT;
             const int kg = s / MT, pp = s - kg * MT;
-            const float d = s_out[pp];
             float4 h = amx_ld4(H[NL] + (size_t)s * 4);
-            const float4 w = amx_ld4(a.Wo + kg * 4);
-            float4 gh = make_float4(d * w.x, d * w.y, d * w.z, d * w.w);
+            float4 gh = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < a.C; ++c) {
+                const float d = s_out[c * MT + pp];
+                const float4 w = amx_ld4(a.Wo + (size_t)c * HID + kg * 4);
+                gh.x = fmaf(d, w.x, gh.x); gh.y = fmaf(d, w.y, gh.y); gh.z = fmaf(d, w.z, gh.z); gh.w = fmaf(d, w.w, gh.w);
+            }
             if (a.skip) {
                 const float4 r = amx_ld4(H[0] + (size_t)s * 4);
                 amx_st4(GR + (size_t)s * 4, gh);                        // g_res = gh_NL
@@ -382,7 +422,27 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             const int pp = tid >> 1, comp = tid & 1;
             float t = 0.f;
             for (int kg = 0; kg < G::KG; ++kg) t += s_g[((size_t)kg * MT + pp) * 2 + comp];
-            if (pix0 + pp < a.n) a.dcoords[((size_t)bidx * a.n + pix0 + pp) * 2 + comp] = t;
+            if (pix0 + pp < a.n) {
+                if (th) {
+                    // d/dphi of (x', y') = (-(y' - dy), x' - dx);  d/d(dx, dy) = identity
+                    a_tr += t;
+                    a_phi += comp == 0 ? -t * (s_xy[2 * pp + 1] - th[3]) : t * (s_xy[2 * pp] - th[2]);
+                } else {
+                    a.dcoords[((size_t)bidx * a.n + pix0 + pp) * 2 + comp] = t;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (th) {                                     // fixed-order sums over the 2*MT (pixel slot, component) threads
+        __syncthreads();
+        if (tid < 2 * MT) { s_red[2 * tid] = a_phi; s_red[2 * tid + 1] = a_tr; }
+        __syncthreads();
+        if (tid < 3) {
+            float t = 0.f;
+            if (tid == 0) { for (int q = 0; q < 2 * MT; ++q) t += s_red[2 * q]; }
+            else { for (int q = tid - 1; q < 2 * MT; q += 2) t += s_red[2 * q + 1]; }
+            a.dtheta[(size_t)bidx * 3 + tid] = t;
         }
         __syncthreads();
     }
@@ -401,7 +461,8 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     }
     __syncthreads();
     if (tid < HID) {
-        a.pWo[(size_t)bidx * HID + tid] = aWo;
+        #pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < a.C) a.pWo[((size_t)bidx * a.C + c) * HID + tid] = aWo[c];
         a.pWc[((size_t)bidx * HID + tid) * 2 + 0] = aWc0;
         a.pWc[((size_t)bidx * HID + tid) * 2 + 1] = aWc1;
         a.pbc[(size_t)bidx * HID + tid] = aZc;
@@ -409,9 +470,14 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     }
     // dbo
     __syncthreads();
-    s_red[tid] = tid < MT ? abo : 0.f;
-    __syncthreads();
-    if (tid == 0) { float t = 0.f; for (int q = 0; q < MT; ++q) t += s_red[q]; a.pbo[bidx] = t; }
+    #pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (c >= a.C) break;
+        s_red[tid] = tid < MT ? abo[c] : 0.f;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int q = 0; q < MT; ++q) t += s_red[q]; a.pbo[(size_t)bidx * a.C + c] = t; }
+        __syncthreads();
+    }
     // dWz[f][l] = dzc[f] * z[l];  dz[l] = sum_f Wz[f][l] dzc[f]     (s_zc now holds dzc)
     __syncthreads();
     if (tid < HID)
@@ -427,12 +493,12 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
 template <int HID, int MT>
 static size_t fwd_lds(int skip) {
     using G = Geo<HID, MT>;
-    return ((size_t)G::BUF * (skip ? 3 : 2) + HID + MAXL + G::TPP * MT + MT) * sizeof(float);
+    return ((size_t)G::BUF * (skip ? 3 : 2) + HID + MAXL + G::TPP * MT + MAXC * MT + 4) * sizeof(float);
 }
 template <int HID, int MT, int NL>
 static size_t bwd_lds(int skip) {
     using G = Geo<HID, MT>;
-    return ((size_t)G::BUF * (NL + 1 + (skip ? 1 : 0)) + HID + MAXL + G::TPP * MT + MT + 2 * MT + 4 * G::NT) * sizeof(float);
+    return ((size_t)G::BUF * (NL + 1 + (skip ? 1 : 0)) + HID + MAXL + G::TPP * MT + MAXC * MT + 2 * MT + 4 * G::NT + 4) * sizeof(float);
 }
 
 template <int HID, int MT>
@@ -473,18 +539,19 @@ static int launch_bwd(const RDecArgs& a, hipStream_t s) {
 
 static int check_common(const RDecArgs& a, int hid) {
     if (!a.coords || !a.z || !a.Wc || !a.bc || !a.Wz || !a.W || !a.b || !a.Wo || !a.bo) AMX_BADARG(1);
-    if (a.B <= 0 || a.n <= 0 || a.L < 1 || a.L > MAXL || a.NL < 1 || a.NL > 3) AMX_BADARG(2);
+    if (a.B <= 0 || a.n <= 0 || a.L < 1 || a.L > MAXL || a.NL < 1 || a.NL > 5) AMX_BADARG(2);
     if (hid != 32 && hid != 64 && hid != 128) AMX_BADARG(3);
+    if (a.C < 1 || a.C > MAXC) AMX_BADARG(5);
     return 0;
 }
 
-extern "C" int amx_rdecoder_fwd(const float* coords, const float* z, const float* Wc, const float* bc,
-                                const float* Wz, const float* W, const float* b, const float* Wo,
+extern "C" int amx_rdecoder_fwd(const float* coords, const float* theta, const float* z, const float* Wc,
+                                const float* bc, const float* Wz, const float* W, const float* b, const float* Wo,
                                 const float* bo, float* xrec, int B, int n, int L, int hid, int NL, int skip,
-                                void* stream) {
+                                int C, void* stream) {
     RDecArgs a = {};
-    a.coords = coords; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.b = b; a.Wo = Wo; a.bo = bo;
-    a.xrec = xrec; a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip;
+    a.coords = coords; a.theta = theta; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.b = b; a.Wo = Wo;
+    a.bo = bo; a.xrec = xrec; a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip; a.C = C;
     const int rc = check_common(a, hid);
     if (rc) return rc;
     if (!xrec) AMX_BADARG(4);
@@ -496,24 +563,31 @@ extern "C" int amx_rdecoder_fwd(const float* coords, const float* z, const float
     return (skip || mt == 64) ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
 }
 
-extern "C" int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const float* bc,
-                                const float* Wz, const float* W, const float* Wt, const float* b,
+extern "C" int amx_rdecoder_bwd(const float* coords, const float* theta, const float* z, const float* Wc,
+                                const float* bc, const float* Wz, const float* W, const float* Wt, const float* b,
                                 const float* Wo, const float* bo, const float* dxrec, float* dcoords,
-                                float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc, float* pbc,
-                                float* pWz, int B, int n, int L, int hid, int NL, int skip, void* stream) {
+                                float* dtheta, float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc,
+                                float* pbc, float* pWz, int B, int n, int L, int hid, int NL, int skip, int C,
+                                void* stream) {
     RDecArgs a = {};
-    a.coords = coords; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.Wt = Wt; a.b = b; a.Wo = Wo; a.bo = bo;
-    a.dxrec = dxrec; a.dcoords = dcoords; a.dz = dz;
+    a.coords = coords; a.theta = theta; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.Wt = Wt; a.b = b;
+    a.Wo = Wo; a.bo = bo; a.dxrec = dxrec; a.dcoords = dcoords; a.dtheta = dtheta; a.dz = dz;
     a.pW = pW; a.pb = pb; a.pWo = pWo; a.pbo = pbo; a.pWc = pWc; a.pbc = pbc; a.pWz = pWz;
-    a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip;
+    a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip; a.C = C;
     const int rc = check_common(a, hid);
     if (rc) return rc;
-    if (!Wt || !dxrec || !dcoords || !dz || !pW || !pb || !pWo || !pbo || !pWc || !pbc || !pWz) AMX_BADARG(4);
+    if (!Wt || !dxrec || !dz || !pW || !pb || !pWo || !pbo || !pWc || !pbc || !pWz) AMX_BADARG(4);
+    if (theta ? !dtheta : !dcoords) AMX_BADARG(6);
     hipStream_t s = (hipStream_t)stream;
+    // LDS holds NL + 1 (+1 with skip) activation images of HID x MT floats: the tile shrinks as the decoder deepens
 #define RD_BWD(HID_, MT_)                                               \
-    if (NL == 1) return launch_bwd<HID_, MT_, 1>(a, s);                 \
-    if (NL == 2) return launch_bwd<HID_, MT_, 2>(a, s);                 \
-    return launch_bwd<HID_, MT_, 3>(a, s);
+    switch (NL) {                                                       \
+        case 1: return launch_bwd<HID_, MT_, 1>(a, s);                  \
+        case 2: return launch_bwd<HID_, MT_, 2>(a, s);                  \
+        case 3: return launch_bwd<HID_, MT_, 3>(a, s);                  \
+        case 4: return launch_bwd<HID_, MT_, 4>(a, s);                  \
+        default: return launch_bwd<HID_, MT_, 5>(a, s);                 \
+    }
     if (hid == 32) { RD_BWD(32, 64) }
     if (hid == 64) { RD_BWD(64, 64) }
     int mt = 64;

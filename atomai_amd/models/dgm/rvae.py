@@ -5,8 +5,7 @@ from typing import Optional
 import torch
 
 from ...losses_metrics import rvae_loss
-from ...utils import set_train_rng
-from ...utils.coords import transform_coordinates
+from ...utils import set_train_rng, to_onehot
 from .vae import BaseVAE
 
 
@@ -31,23 +30,24 @@ class rVAE(BaseVAE):
 
     def forward_compute_elbo(self, x: torch.Tensor, y: Optional[torch.Tensor] = None,
                              mode: str = "train") -> torch.Tensor:
-        """Same dataflow as rvae.py:110-147: encoder -> reparameterise -> split (phi, dx, z) -> rotate/translate
-        the coordinate grid -> spatial decoder -> ELBO."""
-        x_coord_ = self.x_coord.expand(x.size(0), *self.x_coord.size())
+        """Same dataflow as rvae.py:110-147: encoder -> reparameterise -> split (phi, dx, z) [-> append the one-hot
+        class] -> rotate/translate the coordinate grid -> spatial decoder -> ELBO."""
         with torch.set_grad_enabled(mode != "eval"):
             z_mean, z_logsd = self.encoder_net(x)
             if mode != "eval":
                 self.kdict_["num_iter"] += 1
             z = self.reparameterize(z_mean, torch.exp(z_logsd))
-            phi = z[:, 0]
+            phi = z[:, :1]
             if self.translation:
-                dx = (z[:, 1:3] * self.dx_prior).unsqueeze(1)
+                theta = torch.cat((phi, z[:, 1:3] * self.dx_prior), 1)
                 z = z[:, 3:]
             else:
-                dx = 0
+                theta = torch.cat((phi, torch.zeros_like(z[:, :2])), 1)
                 z = z[:, 1:]
-            x_coord_ = transform_coordinates(x_coord_, phi, dx)
-            x_reconstr = self.decoder_net(x_coord_, z)
+            if y is not None:
+                z = torch.cat((z, to_onehot(y, self.nb_classes)), -1)
+            # transform_coordinates(x_coord, phi, dx) is applied per pixel inside the decoder kernels
+            x_reconstr = self.decoder_net.forward_grid(self.x_coord, theta, z)
             return self.elbo_fn(x, x_reconstr, z_mean, z_logsd, **self.kdict_)
 
     def fit(self, X_train, y_train=None, X_test=None, y_test=None, loss: str = "mse", **kwargs) -> None:

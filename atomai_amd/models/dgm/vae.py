@@ -8,7 +8,7 @@ import torch
 from ...losses_metrics import vae_loss
 from ...nets import init_VAE_nets
 from ...trainers import viBaseTrainer
-from ...utils import set_train_rng
+from ...utils import set_train_rng, to_onehot
 from ...utils.coords import imcoordgrid
 
 
@@ -24,8 +24,6 @@ class BaseVAE(viBaseTrainer):
             raise AssertionError(msg)
         if isinstance(in_dim, tuple) and not isinstance(in_dim[0], int):
             raise AssertionError(msg)
-        if nb_classes:
-            raise NotImplementedError("class-conditioned VAEs are outside this build's hot path")
         set_train_rng(seed)              # NB: the nets are always drawn under BaseVAE's own seed (default 0)
         self.in_dim = in_dim
         self.z_dim = latent_dim
@@ -65,13 +63,19 @@ class BaseVAE(viBaseTrainer):
 
     def decode(self, z_sample, y=None) -> np.ndarray:
         """Maps latent point(s) to data space with the trained generative model (vae.py:178-221)."""
-        if y is not None:
-            raise NotImplementedError("class-conditioned decoding is outside this build's hot path")
         if isinstance(z_sample, np.ndarray):
             z_sample = torch.from_numpy(z_sample).float()
         if z_sample.dim() == 1:
             z_sample = z_sample[None, ...]
         z_sample = z_sample.to(self.device)
+        if y is not None:                                    # class-conditioned decoding (vae.py:200-209)
+            if isinstance(y, int):
+                y = torch.tensor(y)
+            elif isinstance(y, np.ndarray):
+                y = torch.from_numpy(y)
+            if y.dim() == 0:
+                y = y.unsqueeze(0)
+            z_sample = torch.cat((z_sample, to_onehot(y.to(self.device), self.nb_classes)), dim=-1)
         self.decoder_net.to(self.device).eval()
         with torch.no_grad():
             if self.coord:
@@ -86,14 +90,20 @@ class BaseVAE(viBaseTrainer):
     def reconstruct(self, x_new, **kwargs) -> np.ndarray:
         """Decodes ``num_samples`` draws from the encoded distribution of ONE input (vae.py:223-271; regular VAE:
         the coordinate latents are dropped)."""
-        if kwargs.get("label") is not None:
-            raise NotImplementedError("class-conditioned decoding is outside this build's hot path")
         num_samples = kwargs.get("num_samples", 32)
+        label = kwargs.get("label")
         z_mean, z_sd = self.encode(x_new)
         z_mean = torch.from_numpy(z_mean[:, self.coord:])
         z_sd = torch.from_numpy(z_sd[:, self.coord:])
         ndist = torch.distributions.Normal(z_mean, torch.exp(z_sd))
-        return np.concatenate([self.decode(ndist.rsample().view(1, -1)) for _ in range(num_samples)], axis=0)
+        alphas = None if label is None else to_onehot(torch.tensor(label).unsqueeze(0), self.nb_classes)
+        out = []
+        for _ in range(num_samples):
+            z_sample = ndist.rsample().view(1, -1)
+            if alphas is not None:                           # class to be reconstructed (vae.py:255-267)
+                z_sample = torch.cat([z_sample, alphas], dim=1)
+            out.append(self.decode(z_sample))
+        return np.concatenate(out, axis=0)
 
     def encode_image_(self, img: np.ndarray, **kwargs) -> Tuple[np.ndarray, np.ndarray]:
         """Encodes the training-window-sized sub-image around EVERY pixel of a 2-D image (vae.py:300-344); returns the
@@ -139,8 +149,18 @@ class BaseVAE(viBaseTrainer):
         if X_test is not None and self.in_dim != X_test.shape[1:]:
             raise RuntimeError("The values of input dimensions you specified do not match "
                                "the test data dimensions")
-        if y_train is not None or y_test is not None:
-            raise NotImplementedError("class-conditioned VAEs are outside this build's hot path")
+        if y_train is not None and self.nb_classes == 0:     # vae.py:563-578
+            raise RuntimeError("You must have forgotten to specify number of classes during the initialization. "
+                               "Example of correct usage: vae = VAE(in_dim=(28, 28), nb_classes=10)); "
+                               "vae.fit(train_data, train_labels).")
+        lbl_match = True
+        if y_train is not None and y_test is None:
+            lbl_match = self.nb_classes == len(np.unique(y_train))
+        elif y_train is not None and y_test is not None:
+            lbl_match = self.nb_classes == len(np.unique(y_train)) == len(np.unique(y_test))
+        if not lbl_match:
+            raise RuntimeError("The number of classes specified at initialization must be "
+                               "equal the the number of classes in train and test labels")
 
     def update_metadict(self):
         self.metadict["num_epochs"] = self.current_epoch
@@ -178,6 +198,8 @@ class VAE(BaseVAE):
             if mode != "eval":
                 self.kdict_["num_iter"] += 1
             z = self.reparameterize(z_mean, torch.exp(z_logsd))
+            if y is not None:                                # vae.py:677-680
+                z = torch.cat((z, to_onehot(y, self.nb_classes)), -1)
             x_reconstr = self.decoder_net(z)
             return self.elbo_fn(x, x_reconstr, z_mean, z_logsd, **self.kdict_)
 

@@ -86,10 +86,17 @@ def _zero_pad(t: torch.Tensor, shape) -> torch.Tensor:
 
 
 class _RDecoderFn(torch.autograd.Function):
+    """Fused spatial decoder.  ``theta is None``: ``x_coord`` is the explicit (B, n, 2) coordinate tensor of the
+    reference's forward; otherwise ``x_coord`` is the shared (n, 2) grid and ``theta`` = (B, 3) (phi, dx, dy):
+    the rotation / translation of atomai/utils/coords.py:57-83 happens inside the kernel and the backward returns
+    d theta instead of a (B, n, 2) coordinate gradient."""
+
     @staticmethod
-    def forward(ctx, net, x_coord, z, *params):
-        B, n = x_coord.shape[:2]
-        hid0, NL, Ldim = net.hidden_dim, net.num_layers, z.shape[1]
+    def forward(ctx, net, x_coord, theta, z, *params):
+        fused = theta is not None
+        B = z.shape[0]
+        n = x_coord.shape[0] if fused else x_coord.shape[1]
+        hid0, NL, Ldim, C = net.hidden_dim, net.num_layers, z.shape[1], net.channels
         hid = next(w for w in _RDEC_WIDTHS if w >= hid0)
         Wc, bc, Wz = params[0], params[1], params[2]
         Ws, bs = params[3:3 + 2 * NL:2], params[4:4 + 2 * NL:2]
@@ -97,35 +104,41 @@ class _RDecoderFn(torch.autograd.Function):
         W = _zero_pad(torch.stack([w.detach() for w in Ws]), (NL, hid, hid))
         b = _zero_pad(torch.stack([v.detach() for v in bs]), (NL, hid))
         Wc, bc, Wz = _zero_pad(Wc, (hid, 2)), _zero_pad(bc, (hid,)), _zero_pad(Wz, (hid, Ldim))
-        Wo = _zero_pad(Wo, (1, hid))
+        Wo = _zero_pad(Wo, (C, hid))
         coords = x_coord.detach().contiguous()
+        th = theta.detach().contiguous() if fused else None
         zz = z.detach().contiguous()
-        xrec = torch.empty(B, n, dtype=torch.float32, device=coords.device)
+        xrec = torch.empty(B, n, C, dtype=torch.float32, device=coords.device)
         sp = L.stream_ptr(coords)
-        L.call("amx_rdecoder_fwd", L.ptr(coords), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
-               L.ptr(Wz.detach().contiguous()), L.ptr(W), L.ptr(b), L.ptr(Wo.detach().reshape(-1)),
-               L.ptr(bo.detach()), L.ptr(xrec), B, n, Ldim, hid, NL, int(net.skip), sp)
-        ctx.net, ctx.hid = net, hid
-        ctx.save_for_backward(coords, zz, W, b, *[p.detach() for p in (Wc, bc, Wz, Wo, bo)])
+        L.call("amx_rdecoder_fwd", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
+               L.ptr(Wz.detach().contiguous()), L.ptr(W), L.ptr(b), L.ptr(Wo.detach().contiguous()),
+               L.ptr(bo.detach().contiguous()), L.ptr(xrec), B, n, Ldim, hid, NL, int(net.skip), C, sp)
+        ctx.net, ctx.hid, ctx.fused = net, hid, fused
+        saved = [coords, zz, W, b] + [p.detach() for p in (Wc, bc, Wz, Wo, bo)] + ([th] if fused else [])
+        ctx.save_for_backward(*saved)
         return xrec
 
     @staticmethod
     def backward(ctx, dxrec):
         net = ctx.net
-        coords, zz, W, b, Wc, bc, Wz, Wo, bo = ctx.saved_tensors
-        B, n = coords.shape[:2]
-        hid, hid0, NL, Ldim = ctx.hid, net.hidden_dim, net.num_layers, zz.shape[1]
+        coords, zz, W, b, Wc, bc, Wz, Wo, bo = ctx.saved_tensors[:9]
+        th = ctx.saved_tensors[9] if ctx.fused else None
+        B = zz.shape[0]
+        n = coords.shape[0] if ctx.fused else coords.shape[1]
+        hid, hid0, NL, Ldim, C = ctx.hid, net.hidden_dim, net.num_layers, zz.shape[1], net.channels
         dev = coords.device
         Wt = W.transpose(1, 2).contiguous()
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        dcoords, dz = e(B, n, 2), e(B, Ldim)
-        pW, pb, pWo, pbo = e(B, NL * hid * hid), e(B, NL * hid), e(B, hid), e(B, 1)
+        dcoords = None if ctx.fused else e(B, n, 2)
+        dtheta = e(B, 3) if ctx.fused else None
+        dz = e(B, Ldim)
+        pW, pb, pWo, pbo = e(B, NL * hid * hid), e(B, NL * hid), e(B, C * hid), e(B, C)
         pWc, pbc, pWz = e(B, hid * 2), e(B, hid), e(B, hid * Ldim)
         sp = L.stream_ptr(coords)
-        L.call("amx_rdecoder_bwd", L.ptr(coords), L.ptr(zz), L.ptr(Wc), L.ptr(bc), L.ptr(Wz.contiguous()),
-               L.ptr(W), L.ptr(Wt), L.ptr(b), L.ptr(Wo.reshape(-1)), L.ptr(bo), L.ptr(dxrec.contiguous()),
-               L.ptr(dcoords), L.ptr(dz), L.ptr(pW), L.ptr(pb), L.ptr(pWo), L.ptr(pbo), L.ptr(pWc),
-               L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), sp)
+        L.call("amx_rdecoder_bwd", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc), L.ptr(bc), L.ptr(Wz.contiguous()),
+               L.ptr(W), L.ptr(Wt), L.ptr(b), L.ptr(Wo.contiguous()), L.ptr(bo.contiguous()),
+               L.ptr(dxrec.contiguous()), L.ptr(dcoords), L.ptr(dtheta), L.ptr(dz), L.ptr(pW), L.ptr(pb), L.ptr(pWo),
+               L.ptr(pbo), L.ptr(pWc), L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), C, sp)
 
         def rsum(part, shape):
             cols = part.shape[1]
@@ -143,12 +156,21 @@ class _RDecoderFn(torch.autograd.Function):
         grads = [rsum(pWc, (hid, 2))[:hid0], rsum(pbc, (hid,))[:hid0], rsum(pWz, (hid, Ldim))[:hid0]]
         for l in range(NL):
             grads += [gW[l], gb[l]]
-        grads += [rsum(pWo, (1, hid))[:, :hid0], rsum(pbo, (1,))]
-        return (None, dcoords, dz) + tuple(grads)
+        grads += [rsum(pWo, (C, hid))[:, :hid0], rsum(pbo, (C,))]
+        return (None, dcoords, dtheta, dz) + tuple(grads)
+
+
+_RDEC_MAX_LAYERS = 5
+_RDEC_MAX_CHANNELS = 4
 
 
 class rDecoderNet(nn.Module):
-    """Spatial decoder with (optional) skip connections (ed.py:583-642) on the fused HIP kernels."""
+    """Spatial decoder with (optional) skip connections (ed.py:583-642) on the fused HIP kernels.
+
+    Limits of the fused kernels (each raises): hidden_dim <= 128 — one wave owns 16 hidden units and keeps its slice
+    of every weight matrix and weight-gradient accumulator in registers, which at 256 units would need 16 waves x
+    ~330 registers; 1-5 hidden layers (LDS holds one activation image per layer in the backward pass); 1-4 output
+    channels."""
 
     def __init__(self, out_dim: Tuple[int], latent_dim: int, num_layers: int, hidden_dim: int,
                  skip: bool = False) -> None:
@@ -168,20 +190,29 @@ class rDecoderNet(nn.Module):
         self.out = nn.Linear(hidden_dim, c)
         self.hidden_dim, self.num_layers, self.channels = hidden_dim, num_layers, c
 
-    def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
-        if self.channels != 1:
-            raise NotImplementedError("multi-channel spatial decoding is outside this build's hot path")
-        if self.hidden_dim > _RDEC_WIDTHS[-1] or not 1 <= self.num_layers <= 3:
-            raise NotImplementedError("fused rDecoderNet supports hidden_dim <= 128 and 1-3 layers")
-        batch_dim = x_coord.size(0)
+    def _params(self):
+        if not 1 <= self.channels <= _RDEC_MAX_CHANNELS:
+            raise NotImplementedError(f"fused rDecoderNet supports 1-{_RDEC_MAX_CHANNELS} output channels")
+        if self.hidden_dim > _RDEC_WIDTHS[-1] or not 1 <= self.num_layers <= _RDEC_MAX_LAYERS:
+            raise NotImplementedError(f"fused rDecoderNet supports hidden_dim <= {_RDEC_WIDTHS[-1]} and "
+                                      f"1-{_RDEC_MAX_LAYERS} layers")
         params = [self.coord_latent.fc_coord.weight, self.coord_latent.fc_coord.bias,
                   self.coord_latent.fc_latent.weight]
         for m in self.fc_decoder:
             if isinstance(m, nn.Linear):
                 params += [m.weight, m.bias]
-        params += [self.out.weight, self.out.bias]
-        h = _RDecoderFn.apply(self, x_coord, z, *params)
-        return h.reshape(batch_dim, *self.reshape_)
+        return params + [self.out.weight, self.out.bias]
+
+    def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """The reference's signature: explicit (B, n, 2) coordinates."""
+        h = _RDecoderFn.apply(self, x_coord, None, z, *self._params())
+        return h.reshape(x_coord.size(0), *self.reshape_)
+
+    def forward_grid(self, grid: torch.Tensor, theta: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """Decodes at ``transform_coordinates(grid, theta[:, 0], theta[:, 1:3])`` without materialising the (B, n, 2)
+        coordinates: ``grid`` is the shared (n, 2) ``imcoordgrid``, ``theta`` = (B, 3) (angle, dx, dy)."""
+        h = _RDecoderFn.apply(self, grid, theta, z, *self._params())
+        return h.reshape(z.size(0), *self.reshape_)
 
 
 class convEncoderNet(nn.Module):

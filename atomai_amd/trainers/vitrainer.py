@@ -54,9 +54,9 @@ class viBaseTrainer:
 
     def _2torch(self, X, y=None):
         if isinstance(X, np.ndarray):
-            X = torch.from_numpy(X)
+            X = torch.from_numpy(X).float()
         if isinstance(y, np.ndarray):
-            y = torch.from_numpy(y)
+            y = torch.from_numpy(y).long()                   # class labels (vae.py:580-592)
         return X, y
 
     def _set_data(self, X, y=None, store_on_cpu: bool = False):

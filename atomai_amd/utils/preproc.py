@@ -108,3 +108,16 @@ def torch_format_image(image_data: np.ndarray, norm: bool = True) -> torch.Tenso
     if norm:
         image_data = (image_data - image_data.min()) / np.ptp(image_data)
     return torch.from_numpy(np.ascontiguousarray(image_data)).float()
+
+
+def to_onehot(idx: torch.Tensor, n: int) -> torch.Tensor:
+    """One-hot encoding of integer labels (reference: atomai/utils/preproc.py:915-928; the reference allocates on
+    'cuda' whenever CUDA exists, here the result lives on the labels' own device)."""
+    if torch.max(idx).item() >= n:
+        raise AssertionError("Labelling must start from 0 and "
+                             "maximum label value must be less than total number of classes")
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(1)
+    onehot = torch.zeros(idx.size(0), int(n), device=idx.device)
+    onehot.scatter_(1, idx.long(), 1)
+    return onehot

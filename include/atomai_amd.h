@@ -162,15 +162,21 @@ int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, fl
                     long numel, void* stream);
 
 /* ---- rVAE spatial decoder (rDecoderNet + coord_latent, atomai/nets/ed.py:583-687): per-pixel MLP with all
- * hidden activations kept in LDS; backward recomputes per tile and emits per-sample partial rows. */
-int amx_rdecoder_fwd(const float* coords, const float* z, const float* Wc, const float* bc, const float* Wz,
-                     const float* W, const float* b, const float* Wo, const float* bo, float* xrec, int B,
-                     int n, int L, int hid, int NL, int skip, void* stream);
-int amx_rdecoder_bwd(const float* coords, const float* z, const float* Wc, const float* bc, const float* Wz,
-                     const float* W, const float* Wt, const float* b, const float* Wo, const float* bo,
-                     const float* dxrec, float* dcoords, float* dz, float* pW, float* pb, float* pWo,
-                     float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L, int hid, int NL,
-                     int skip, void* stream);
+ * hidden activations kept in LDS; backward recomputes per tile and emits per-sample partial rows.
+ * Coordinates: theta == NULL -> coords is the explicit [B][n][2] tensor the reference's forward takes (gradient
+ * in dcoords); theta = [B][3] (phi, dx, dy) -> coords is the shared grid [n][2] (imcoordgrid,
+ * atomai/utils/coords.py:37-54) and transform_coordinates (:57-83: rotation by phi, then translation) is applied per
+ * pixel in the kernel, its gradient reduced per sample into dtheta [B][3] — no (B, n, 2) tensor exists in either
+ * direction.  C output channels (<= 4): xrec / dxrec are [B][n][C] (channel-last, as ed.py:639-642 reshapes),
+ * Wo [C][hid], bo [C], pWo [B][C][hid], pbo [B][C].  hid in {32, 64, 128}, 1 <= NL <= 5. */
+int amx_rdecoder_fwd(const float* coords, const float* theta, const float* z, const float* Wc, const float* bc,
+                     const float* Wz, const float* W, const float* b, const float* Wo, const float* bo, float* xrec,
+                     int B, int n, int L, int hid, int NL, int skip, int C, void* stream);
+int amx_rdecoder_bwd(const float* coords, const float* theta, const float* z, const float* Wc, const float* bc,
+                     const float* Wz, const float* W, const float* Wt, const float* b, const float* Wo,
+                     const float* bo, const float* dxrec, float* dcoords, float* dtheta, float* dz, float* pW,
+                     float* pb, float* pWo, float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L,
+                     int hid, int NL, int skip, int C, void* stream);
 
 /* ---- ELBO terms of vae_loss / rvae_loss with 'mse' (atomai/losses_metrics/vi_losses.py:13-137), fwd and bwd */
 int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd, int B, int n,

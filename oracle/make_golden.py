@@ -207,10 +207,15 @@ def make_predict(aoi):
     print("predict ok", out["Unet|probs"].shape, out["dilnet|probs"].shape)
 
 
-def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3):
+def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3, nb_classes=0):
     x = rs.rand(B, *in_dim).astype(np.float32)
     eps_all = rs.randn(steps, B, 8).astype(np.float32)
     out[f"{name}|x"], out[f"{name}|eps"] = x, eps_all
+    y = None
+    if nb_classes:
+        y = np.arange(B) % nb_classes
+        rs.shuffle(y)
+        out[f"{name}|y"] = y
     for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         m = ctor()
         if tag == "f32":
@@ -228,7 +233,8 @@ def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3):
         if "capacity" in fit_kw:
             m.kdict_["capacity"] = fit_kw["capacity"]
         m.loss = "mse"
-        m.compile_trainer((x, None), None, batch_size=B)
+        m.compile_trainer((x, y), None, batch_size=B)
+        yt = None if y is None else torch.from_numpy(y).long()
         state = {"i": 0}
 
         def reparam(z_mean, z_sd, st=state, e=eps_all, d=dt):
@@ -241,7 +247,7 @@ def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3):
             state["i"] = s
             m.encoder_net.train(), m.decoder_net.train()
             m.optim.zero_grad()
-            elbo = m.forward_compute_elbo(xt)
+            elbo = m.forward_compute_elbo(xt) if yt is None else m.forward_compute_elbo(xt, yt)
             (-elbo).backward()
             if s == 0:
                 for k, p in m.encoder_net.named_parameters():
@@ -259,6 +265,12 @@ def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3):
         with torch.no_grad():
             zm, zs = m.encoder_net(xt)
         out[f"{name}|zmean|{tag}"], out[f"{name}|zlogsd|{tag}"] = zm.numpy(), zs.numpy()
+        if tag == "f64":                                      # decode API on the trained generative model
+            m.encoder_net.float(), m.decoder_net.float()
+            if hasattr(m, "x_coord"):
+                m.x_coord = m.x_coord.float()
+            zq = np.array([[0.3, -0.2], [1.0, 0.5], [-0.7, 0.1]], dtype=np.float32)
+            out[f"{name}|decode"] = m.decode(zq) if not nb_classes else m.decode(zq, np.array([2, 0, 1]))
     print(name, "elbo f32", out[f"{name}|elbo|f32"], "f64", out[f"{name}|elbo|f64"])
 
 
@@ -296,6 +308,29 @@ def make_vae(aoi):
     finally:
         os.chdir(cwd)
     np.savez_compressed(os.path.join(GOLD, "vae.npz"), **out)
+
+
+def make_vae_cond(aoi):
+    """Class-conditioned (r)VAE (rvae.py:131-138, vae.py:677-680), a multi-channel / 4-layer spatial decoder."""
+    out = {}
+    rs = np.random.RandomState(11)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        _vae_run(out, rs, "crvae16", lambda: aoi.models.rVAE((16, 16), latent_dim=2, nb_classes=3, seed=0,
+                                                             numhidden_encoder=32, numhidden_decoder=32),
+                 dict(), (16, 16), 6, nb_classes=3)
+        _vae_run(out, rs, "cvae16", lambda: aoi.models.VAE((16, 16), latent_dim=2, nb_classes=3, seed=0,
+                                                           numhidden_encoder=32, numhidden_decoder=32),
+                 dict(), (16, 16), 6, nb_classes=3)
+        _vae_run(out, rs, "rvae12_rgb", lambda: aoi.models.rVAE((12, 12, 3), latent_dim=2, seed=0,
+                                                                numhidden_encoder=32, numhidden_decoder=64,
+                                                                numlayers_decoder=4),
+                 dict(), (12, 12, 3), 4)
+    finally:
+        os.chdir(cwd)
+    out = {k: v for k, v in out.items() if "_after|" not in k}          # not asserted on: keep the fixture small
+    np.savez_compressed(os.path.join(GOLD, "vae_cond.npz"), **out)
 
 
 def make_vae_conv(aoi):
@@ -455,10 +490,10 @@ def make_vae_api(aoi):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond}[w](aoi)
     print("done ->", GOLD)

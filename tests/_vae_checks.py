@@ -14,6 +14,14 @@ CASES = {
     "vae16": dict(cls="VAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32), fit=dict()),
     "rvae16_conv": dict(cls="rVAE", ctor=dict(conv_encoder=True, numhidden_encoder=8, numhidden_decoder=32),
                         fit=dict(), file="vae_conv.npz"),
+    # class-conditioned models (one-hot label appended to the content latents: rvae.py:131-138, vae.py:677-680)
+    "crvae16": dict(cls="rVAE", ctor=dict(nb_classes=3, numhidden_encoder=32, numhidden_decoder=32), fit=dict(),
+                    file="vae_cond.npz"),
+    "cvae16": dict(cls="VAE", ctor=dict(nb_classes=3, numhidden_encoder=32, numhidden_decoder=32), fit=dict(),
+                   file="vae_cond.npz"),
+    # 3-channel patches, 4 hidden layers of 64 units in the spatial decoder
+    "rvae12_rgb": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=64, numlayers_decoder=4),
+                       fit=dict(), file="vae_cond.npz", in_dim=(12, 12, 3)),
 }
 
 
@@ -21,7 +29,8 @@ def check_vae_case(name, device):
     import atomai_amd as aoi
     c = CASES[name]
     g = np.load(os.path.join(GOLD, c.get("file", "vae.npz")))
-    m = getattr(aoi.models, c["cls"])((16, 16), latent_dim=2, seed=0, **c["ctor"])
+    in_dim = c.get("in_dim", (16, 16))
+    m = getattr(aoi.models, c["cls"])(in_dim, latent_dim=2, seed=0, **c["ctor"])
     for k, v in m.encoder_net.state_dict().items():        # RNG-order initialisation == reference
         assert np.array_equal(v.cpu().numpy(), g[f"{name}|enc|{k}"]), k
     for k, v in m.decoder_net.state_dict().items():
@@ -33,7 +42,9 @@ def check_vae_case(name, device):
         m.kdict_["phi_prior"] = 0.1
     if "capacity" in c["fit"]:
         m.kdict_["capacity"] = c["fit"]["capacity"]
-    m.compile_trainer((x, None), None, batch_size=x.shape[0])
+    y = g[f"{name}|y"] if f"{name}|y" in g.files else None
+    m.compile_trainer((x, y), None, batch_size=x.shape[0])
+    yt = None if y is None else torch.from_numpy(y).long().to(device)
     state = {"i": 0}
     m.reparameterize = lambda zm, zs: zm + zs * eps_all[state["i"]][:, :zm.shape[1]]
     xt = torch.from_numpy(x).to(device)
@@ -42,7 +53,7 @@ def check_vae_case(name, device):
         state["i"] = s
         m.encoder_net.train(), m.decoder_net.train()
         m.optim.zero_grad()
-        elbo = m.forward_compute_elbo(xt)
+        elbo = m.forward_compute_elbo(xt) if yt is None else m.forward_compute_elbo(xt, yt)
         (-elbo).backward()
         if s == 0:
             for which, net in (("enc", m.encoder_net), ("dec", m.decoder_net)):
@@ -58,7 +69,70 @@ def check_vae_case(name, device):
         zm, zl = m.encoder_net(xt)
     np.testing.assert_allclose(zm.cpu().numpy(), g[f"{name}|zmean|f64"], rtol=2e-3, atol=2e-4)
     # decode API: shapes as in the reference tests (test/models/test_vae.py)
-    dec = m.decode(np.zeros((3, 2), dtype=np.float32))
-    assert dec.shape == (3, 16, 16)
+    if y is None:
+        dec = m.decode(np.zeros((3, 2), dtype=np.float32))
+        assert dec.shape == (3, *in_dim)
+    if f"{name}|decode" in g.files:                          # decode (with labels) after the three steps
+        zq = np.array([[0.3, -0.2], [1.0, 0.5], [-0.7, 0.1]], dtype=np.float32)
+        dec = m.decode(zq) if y is None else m.decode(zq, np.array([2, 0, 1]))
+        ref = g[f"{name}|decode"]
+        assert dec.shape == ref.shape
+        assert np.abs(dec - ref).max() / np.abs(ref).max() < 20 * REL_TOL      # weights differ at the 1e-4 level
     zmean, zsd = m.encode(x)
     assert zmean.shape == (x.shape[0], m.z_dim) and zsd.shape == zmean.shape
+
+
+def check_rdecoder_shapes(device, hid, nl, skip, hw, B=2):
+    """Other decoder widths / depths / channel counts, a pixel count that is not a multiple of the tile, skip
+    connections — in BOTH coordinate modes: explicit (B, n, 2) coordinates (the reference's signature) and the
+    in-kernel rotation / translation of the shared grid (forward_grid), whose gradient w.r.t. (phi, dx, dy) must equal
+    autograd through transform_coordinates (atomai/utils/coords.py:57-83)."""
+    from collections import OrderedDict
+    from oracle import vae_oracle as vo
+    from atomai_amd.nets import rDecoderNet
+    torch.manual_seed(0)
+    net = rDecoderNet(hw, 2, nl, hid, bool(skip))
+    P = OrderedDict((k, v.double().clone().requires_grad_(True)) for k, v in net.state_dict().items())
+    net.to(device)
+    grid = vo.imcoordgrid(hw[:2])
+    phi, dxy = torch.randn(B), torch.randn(B, 1, 2) * 0.1
+    z = torch.randn(B, 2)
+    gy = None
+
+    def oracle():
+        for v in P.values():
+            v.grad = None
+        ph, dd = phi.detach().double().clone().requires_grad_(True), dxy.detach().double().clone().requires_grad_(True)
+        c2 = vo.transform_coordinates(grid.double().expand(B, *grid.shape), ph, dd)
+        c2.retain_grad()
+        z2 = z.detach().double().clone().requires_grad_(True)
+        yr = vo.r_decoder(P, c2, z2, hw, nl, bool(skip))
+        return yr, c2, z2, ph, dd
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach()).abs().max() / b.detach().abs().max())
+
+    # ---- explicit coordinates
+    yr, c2, z2, _, _ = oracle()
+    coords = c2.detach().float().to(device).contiguous().requires_grad_(True)
+    zt = z.detach().clone().to(device).requires_grad_(True)
+    y = net(coords, zt)
+    assert y.shape == yr.shape and rel(y, yr) < REL_TOL
+    gy = torch.randn(*y.shape)
+    y.backward(gy.to(device))
+    yr.backward(gy.double())
+    for a, b in [(coords.grad, c2.grad), (zt.grad, z2.grad)] + [(p.grad, P[k].grad) for k, p in net.named_parameters()]:
+        assert rel(a, b) < REL_TOL
+    # ---- rotation / translation inside the kernel
+    net.zero_grad()
+    yr, c2, z2, ph, dd = oracle()
+    theta = torch.cat((phi[:, None], dxy[:, 0]), 1).detach().clone().to(device).requires_grad_(True)
+    zt = z.detach().clone().to(device).requires_grad_(True)
+    y = net.forward_grid(grid.to(device), theta, zt)
+    assert rel(y, yr) < REL_TOL
+    y.backward(gy.to(device))
+    yr.backward(gy.double())
+    ref_theta = torch.cat((ph.grad[:, None], dd.grad[:, 0]), 1)
+    assert rel(theta.grad, ref_theta) < REL_TOL
+    for a, b in [(zt.grad, z2.grad)] + [(p.grad, P[k].grad) for k, p in net.named_parameters()]:
+        assert rel(a, b) < REL_TOL

@@ -23,28 +23,10 @@ def test_elbo_grads_adam(name):
     V.check_vae_case(name, "cpu")
 
 
-@pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (12, 12)), (128, 3, 1, (8, 8))])
+@pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (12, 12)), (128, 3, 1, (8, 8)),
+                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (6, 6, 3))])
 def test_rdecoder_shapes(hid, nl, skip, hw):
-    """Other decoder widths/depths, a pixel count that is not a multiple of the tile, skip connections."""
-    from collections import OrderedDict
-    from oracle import vae_oracle as vo
-    from atomai_amd.nets import rDecoderNet
-    torch.manual_seed(0)
-    B = 2
-    net = rDecoderNet(hw, 2, nl, hid, bool(skip))
-    P = OrderedDict((k, v.double().clone().requires_grad_(True)) for k, v in net.state_dict().items())
-    grid = vo.imcoordgrid(hw)
-    coords = vo.transform_coordinates(grid.expand(B, *grid.shape), torch.randn(B), torch.randn(B, 1, 2) * 0.1)
-    coords = coords.contiguous().requires_grad_(True)
-    z = torch.randn(B, 2, requires_grad=True)
-    c2, z2 = coords.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
-    y, yr = net(coords, z), vo.r_decoder(P, c2, z2, hw, nl, bool(skip))
-    assert float((y.detach().double() - yr.detach()).abs().max() / yr.detach().abs().max()) < V.REL_TOL
-    gy = torch.randn_like(y)
-    y.backward(gy)
-    yr.backward(gy.double())
-    for a, b in [(coords.grad, c2.grad), (z.grad, z2.grad)] + [(p.grad, P[k].grad) for k, p in net.named_parameters()]:
-        assert float((a.double() - b).abs().max() / b.abs().max()) < V.REL_TOL
+    V.check_rdecoder_shapes("cpu", hid, nl, skip, hw)
 
 
 def test_rvae_fit_api(tmp_path):

@@ -15,12 +15,19 @@ def test_elbo_grads_adam(name):
     V.check_vae_case(name, "cuda")
 
 
-def test_rvae_config4_vs_oracle_on_device():
-    """BASELINE.json configs[3] shape (rVAE latent_dim=2, 64x64 windows, default 128-wide nets) at bs=128:
-    ELBO and every gradient against the oracle graph executed with stock torch ops on the same GPU."""
+@pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (64, 64)), (128, 3, 1, (24, 24)),
+                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (33, 31, 3))])
+def test_rdecoder_shapes(hid, nl, skip, hw):
+    """Both coordinate modes (explicit / rotated in the kernel), 1-5 layers, 1-3 channels, odd pixel counts."""
+    V.check_rdecoder_shapes("cuda", hid, nl, skip, hw, B=3)
+
+
+@pytest.mark.parametrize("B", [128, 512])
+def test_rvae_config4_vs_oracle_on_device(B):
+    """BASELINE.json configs[3] shape (rVAE latent_dim=2, 64x64 windows, default 128-wide nets) at bs=128 and at the
+    FULL bs=512: ELBO and every gradient against the oracle graph executed with stock torch ops on the same GPU."""
     import atomai_amd as aoi
     from oracle import vae_oracle as vo
-    B = 128
     m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
     m.dx_prior, m.kdict_["phi_prior"] = 0.1, 0.1
     rs = np.random.RandomState(0)

@@ -115,5 +115,13 @@ if "dilnet" in what:
         taps = 9 if d else 1
         d = max(d, 1)
         out.append(probe(f"dil{d} {C0}+{C1}->{Co} @{H}", B, H, C0, C1, Co, taps, d, stats_on=False, iters=10))
+if "occ" in what:
+    print("== occupancy sweep (AMX_CONV_MAXWG = max workgroups per CU through an LDS pad), product library only")
+    LIBS = {"cur": new}
+    for (H, C0, C1, Co) in [(256, 32, 0, 32), (512, 16, 16, 16), (128, 64, 0, 64), (64, 128, 0, 128)]:
+        for k in ("1", "2", "3", "4", "5", ""):
+            if k: os.environ["AMX_CONV_MAXWG"] = k
+            else: os.environ.pop("AMX_CONV_MAXWG", None)
+            out.append(probe(f"maxwg={k or 'none'} {C0}+{C1}->{Co} @{H}", 32, H, C0, C1, Co))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/r02_probe_conv.json", "w"), indent=1)

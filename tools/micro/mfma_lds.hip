@@ -89,3 +89,38 @@ extern "C" double mfma_lds_tflops(int mode, int wgs_per_cu, int iters, int reps)
         default: return run<4>(wgs_per_cu, iters, reps);
     }
 }
+
+// ---- mode 5/6: the pure-MFMA ceiling with RANDOM operands (bit toggling costs power; the part clocks to its
+// power budget), mode 6 = all-zero operands for contrast
+__global__ __launch_bounds__(256) void k_rand(float* out, const float* src, int iters) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = src[(threadIdx.x * 8 + i) & 4095]; b[i] = src[(threadIdx.x * 8 + i + 2048) & 4095]; }
+    for (int it = 0; it < iters; ++it) {
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[(i + it) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456f) out[0] = s;
+}
+
+extern "C" double mfma_rand_tflops(int zero, int wgs_per_cu, int iters, int reps) {
+    float* out; float* src;
+    hipMalloc(&out, 4); hipMalloc(&src, 4096 * 4);
+    float h[4096];
+    unsigned x = 12345u;
+    for (int i = 0; i < 4096; ++i) { x = x * 1664525u + 1013904223u; h[i] = zero ? 0.f : ((x >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+    hipMemcpy(src, h, sizeof(h), hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int wgs = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(k_rand, dim3(wgs), dim3(256), 0, 0, out, src, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_rand, dim3(wgs), dim3(256), 0, 0, out, src, iters);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipFree(out); hipFree(src);
+    return (double)reps * wgs * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
+}

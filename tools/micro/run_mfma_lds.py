@@ -16,3 +16,10 @@ for mode in range(5):
         tf = lib.mfma_lds_tflops(mode, occ, 400, 3)
         row.append(f"occ{occ} {tf:6.1f}")
     print(f"mode {mode} {names[mode]:30s} " + "  ".join(row) + "  TFLOP/s", flush=True)
+lib.mfma_rand_tflops.restype = ctypes.c_double
+lib.mfma_rand_tflops.argtypes = [ctypes.c_int] * 4
+for zero in (0, 1):
+    for iters, reps in ((20000, 3), (200000, 3)):
+        tf = lib.mfma_rand_tflops(zero, 4, iters, reps)
+        print(f"pure MFMA, {'zero' if zero else 'random'} operands, 4 wg/CU, {iters} iters x {reps}: {tf:6.1f} TFLOP/s "
+              f"(effective clock {tf / 157.3 * 2.4:.2f} GHz)", flush=True)
