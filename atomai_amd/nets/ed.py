@@ -1,8 +1,8 @@
 """VAE encoder / decoder networks (reference: atomai/nets/ed.py:292-343, 530-687, 725-790).
 
-* ``fcEncoderNet`` / ``fcDecoderNet`` are plain dense layers on (B x features) matrices: they stay stock
-  ``nn.Linear`` modules, i.e. library GEMMs (rocBLAS/hipBLASLt through PyTorch-ROCm) — they are <1 % of the
-  rVAE step's FLOPs.
+* ``fcEncoderNet`` / ``fcDecoderNet`` are dense layers on (B x features) matrices: their ``nn.Linear`` children are
+  parameter containers only, the arithmetic (GEMM + bias + Tanh, forward and both gradients) runs on the fp32-MFMA
+  GEMM of csrc/linear.hip (``nets/_linear.py``).
 * ``rDecoderNet`` — the per-pixel spatial decoder where the step spends its time — runs the fused HIP
   kernels of csrc/rdecoder.hip (all hidden activations stay in LDS, forward and backward).
 Module trees / state-dict keys / RNG-order initialisation are those of the reference.
@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from ._linear import linear, run_dense
 
 
 class fcEncoderNet(nn.Module):
@@ -34,8 +35,8 @@ class fcEncoderNet(nn.Module):
 
     def forward(self, x: torch.Tensor):
         x = x.reshape(-1, int(np.prod(x.size()[1:])))
-        x = self.dense(x).reshape(-1, self.reshape_)
-        return self.fc11(x), self._out(self.fc12(x))
+        x = run_dense(self.dense, x).reshape(-1, self.reshape_)
+        return linear(x, self.fc11.weight, self.fc11.bias), self._out(linear(x, self.fc12.weight, self.fc12.bias))
 
 
 class fcDecoderNet(nn.Module):
@@ -56,7 +57,7 @@ class fcDecoderNet(nn.Module):
         self.out_dim = (c, *out_dim[:2])
 
     def forward(self, z: torch.Tensor) -> torch.Tensor:
-        h = self.out(self.decoder(z)).reshape(-1, *self.out_dim)
+        h = linear(run_dense(self.decoder, z), self.out.weight, self.out.bias).reshape(-1, *self.out_dim)
         return h.squeeze(1) if h.size(1) == 1 else h.permute(0, 2, 3, 1)
 
 
@@ -242,7 +243,8 @@ class convEncoderNet(nn.Module):
     def forward(self, x: torch.Tensor):
         x = x.unsqueeze(1) if x.ndim in (2, 3) else x.permute(0, -1, 1, 2)
         feats = self.conv(x.contiguous()).reshape(-1, self.reshape_)
-        return self.fc11(feats), self._out(self.fc12(feats))
+        return (linear(feats, self.fc11.weight, self.fc11.bias),
+                self._out(linear(feats, self.fc12.weight, self.fc12.bias)))
 
 
 def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_dim: Optional[List] = None,

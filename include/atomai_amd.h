@@ -161,6 +161,16 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
 
+/* ---- dense layers (nn.Linear + Tanh / ReLU of fcEncoderNet / fcDecoderNet / the convEncoderNet heads,
+ * atomai/nets/ed.py:231-343, 530-580, and of fcFeatureExtractor, atomai/nets/gp.py:14-26): one fp32-MFMA GEMM
+ * C[M][N] = act(A * B + bias) with operand strides — element (m, k) of A at A[m*sam + k*sak], (k, n) of B at
+ * B[k*sbk + n*sbn], (m, n) of C at C[m*scm + n] — so that forward (x W^T), data gradient (dpre W) and weight
+ * gradient (dpre^T x) are the same entry point.  act: 0 none, 1 tanh, 2 relu (applied after the bias).
+ * amx_act_bwd: dpre = dy * act'(y) from the layer OUTPUT y (tanh: 1 - y^2, relu: y > 0). */
+int amx_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
+                 const float* bias, int M, int N, int K, int act, void* stream);
+int amx_act_bwd(const float* dy, const float* y, float* out, long n, int act, void* stream);
+
 /* ---- rVAE spatial decoder (rDecoderNet + coord_latent, atomai/nets/ed.py:583-687): per-pixel MLP with all
  * hidden activations kept in LDS; backward recomputes per tile and emits per-sample partial rows.
  * Coordinates: theta == NULL -> coords is the explicit [B][n][2] tensor the reference's forward takes (gradient

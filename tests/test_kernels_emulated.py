@@ -143,3 +143,13 @@ def test_two_tapes_before_one_backward_do_not_alias_the_gradient_bucket():
     opt.zero_grad()
     blk(x1).square().sum().backward()
     assert blk.block[0].weight.grad.data_ptr() == blk.block[0].weight._amx_grad.data_ptr()
+
+
+def test_dense_gemm_strides_and_activations():
+    import _linear_checks as C
+    C.check_gemm_strides("cpu", sizes=((37, 5, 259), (64, 64, 16), (70, 33, 17), (1, 1, 1)))
+
+
+def test_dense_layer_autograd():
+    import _linear_checks as C
+    C.check_linear_autograd("cpu")
