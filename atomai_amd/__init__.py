@@ -7,7 +7,7 @@ Host side: Python on PyTorch-ROCm (device memory, streams, torch.distributed = R
 hand-written HIP kernels for gfx950 in atomai_amd/csrc, reached through the C ABI of
 include/atomai_amd.h.  There is no CPU fallback.
 """
-from . import losses_metrics, models, nets, predictors, trainers, utils  # noqa: F401
+from . import losses_metrics, models, nets, predictors, trainers, transforms, utils  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 
 __version__ = "0.1.0"

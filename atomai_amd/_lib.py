@@ -103,12 +103,20 @@ def stream_ptr(t: torch.Tensor):
     return C.c_void_p(0)
 
 
+class _Ptr(C.c_void_p):
+    """Device pointer that keeps its tensor referenced: an argument such as ``L.ptr(x.contiguous())`` must stay alive
+    until the launch that reads it has been enqueued (after that the caching allocator's stream order protects it)."""
+    keep = None
+
+
 def ptr(t):
     if t is None:
         return C.c_void_p(0)
     assert t.is_contiguous(), "atomai_amd kernels need contiguous tensors"
     assert t.dtype in (torch.float32, torch.int64, torch.uint8, torch.int32, torch.float64)
-    return C.c_void_p(t.data_ptr())
+    p = _Ptr(t.data_ptr())
+    p.keep = t
+    return p
 
 
 def last_error() -> str:

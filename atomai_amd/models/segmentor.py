@@ -5,6 +5,7 @@ import torch
 
 from ..predictors import SegPredictor
 from ..trainers import SegTrainer
+from ..transforms import seg_augmentor
 from ..utils import get_downsample_factor
 
 
@@ -19,16 +20,12 @@ class Segmentor(SegTrainer):
     def fit(self, X_train, y_train, X_test=None, y_test=None, loss: str = 'ce', optimizer=None,
             training_cycles: int = 1000, batch_size: int = 32, compute_accuracy: bool = False,
             full_epoch: bool = False, swa: bool = False, perturb_weights: bool = False, **kwargs):
-        """Compiles the trainer and trains (segmentor.py:61-149).  On-the-fly augmentation kwargs
-        (cv2/skimage on the CPU in the reference) are not part of this build: passing one raises."""
-        aug = [k for k in kwargs if k in ("rotation", "zoom", "gauss_noise", "poisson_noise", "salt_and_pepper",
-                                          "blur", "contrast", "background", "jitter", "resize", "custom_transform")]
-        if aug:
-            raise NotImplementedError(f"on-the-fly augmentation {aug} is outside the MI355X hot path "
-                                      "of this build (SURVEY.md §8-f rank 3)")
+        """Compiles the trainer and trains (segmentor.py:61-149).  On-the-fly augmentation keywords (rotation,
+        gauss_noise, poisson_noise, salt_and_pepper, blur, contrast, background) run as HIP kernels on the resident
+        batch (transforms/imaug.py); zoom / resize / jitter / custom_transform raise."""
         self.compile_trainer((X_train, y_train, X_test, y_test), loss, optimizer, training_cycles,
                              batch_size, compute_accuracy, full_epoch, swa, perturb_weights, **kwargs)
-        self.augment_fn = None
+        self.augment_fn = seg_augmentor(self.nb_classes, **kwargs)
         _ = self.run()
 
     def predict(self, imgdata, refine: bool = False, logits: bool = True, resize: Tuple[int, int] = None,

@@ -1,0 +1,204 @@
+"""On-the-fly augmentation of the device-resident mini-batch (reference: atomai/transforms/imaug.py:20-432).
+
+The reference runs numpy / skimage / scipy / cv2 in float64 on the CPU for every mini-batch and re-uploads the result
+(hook: atomai/trainers/trainer.py:339-341); at > 1 k images/s that would starve the GPU.  Here the batch stays in HBM
+and the steps are HIP kernels (csrc/aug.hip).  Same step order and parameter ranges as ``datatransform.run``:
+
+    (x - min) / ptp -> rotation -> gauss_noise -> poisson_noise -> salt_and_pepper -> blur -> contrast -> background
+    -> [drop image-label pairs that lost a class] -> (x - min) / ptp
+
+* The per-image scalar parameters (flip type, noise level, gamma, background centre / widths / amplitude) are drawn on
+  the host from ``np.random.RandomState(seed)`` in the reference's order — with the same seed they are the reference's
+  values, except after ``poisson_noise``, whose per-pixel ``np.random.poisson`` draws consume the reference's global
+  stream by an amount that cannot be reproduced.
+* Per-pixel randomness comes from a counter-based Philox generator in the kernel (skimage draws its own from an unseeded
+  ``default_rng``, so the reference is not reproducible there either); ``fields=`` injects explicit noise fields so that
+  the arithmetic can be compared with the reference element by element (tests/golden/augment.npz).
+* Not available (their arithmetic lives in cv2, which is absent here and cannot be pinned): ``zoom``, ``resize``;
+  also ``jitter`` and ``custom_transform`` (arbitrary host code).  Passing one raises.
+"""
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+_NP = 12
+_UNSUPPORTED = ("zoom", "resize", "jitter", "custom_transform")
+
+
+def _minmax(x: torch.Tensor) -> torch.Tensor:
+    n = x.numel()
+    work = torch.empty(2 * L.load().amx_aug_minmax_blocks(n), dtype=torch.float32, device=x.device)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    L.call("amx_aug_minmax", L.ptr(x), n, L.ptr(work), L.ptr(out), L.stream_ptr(x))
+    return out
+
+
+def _unique_counts(x: torch.Tensor) -> np.ndarray:
+    """len(np.unique(image)) per image (imaug.py:145) — a library sort, host read-back of N integers."""
+    s, _ = torch.sort(x.reshape(x.shape[0], -1), dim=1)
+    return (1 + (s[:, 1:] != s[:, :-1]).sum(1)).cpu().numpy()
+
+
+class datatransform:
+    """Device-side counterpart of the reference's ``datatransform`` for (N, H, W) image batches and integer / binary
+    label maps.  ``run(images, labels, fields=None)`` returns the augmented (images (N', 1, H, W), labels)."""
+
+    def __init__(self, n_channels: int = None, seed: Optional[int] = None, **kwargs) -> None:
+        bad = [k for k in _UNSUPPORTED if kwargs.get(k)]
+        if bad:
+            raise NotImplementedError(f"augmentation {bad} is not available on the device path (cv2 / host-code "
+                                      "transforms, see atomai_amd/transforms/imaug.py)")
+        self.ch = n_channels
+        rng = lambda key, dflt: (dflt if kwargs.get(key) is True else kwargs.get(key))   # noqa: E731
+        self.rotation = kwargs.get("rotation")
+        self.background = kwargs.get("background")
+        self.gauss = rng("gauss_noise", [0, 50])
+        self.poisson = rng("poisson_noise", [30, 40])
+        self.salt_and_pepper = rng("salt_and_pepper", [0, 50])
+        self.blur = rng("blur", [1, 50])
+        self.contrast = rng("contrast", [5, 20])
+        self.rs = np.random.RandomState(seed)                 # np.random.seed(seed) of imaug.py:106
+        self.seed = 0 if seed is None else int(seed)
+        self.params = None
+
+    @staticmethod
+    def _is_range(v) -> bool:
+        return isinstance(v, (list, tuple))
+
+    # ------------------------------------------------------------------ host: scalar draws in the reference's order
+    def draw(self, n: int, h: int, w: int):
+        rs = self.rs
+        P = np.zeros((n, _NP), dtype=np.float64)        # float64 here (the oracle's input), fp32 on the device
+        P[:, 0] = 4
+        extra = {}
+        if self.rotation:
+            for i in range(n):
+                ft = rs.randint(-1, 3)                       # 3 is never drawn (imaug.py:267); 2 = rot90 ccw if square
+                P[i, 0] = ft if (ft != 2 or h == w) else 1   # cv2.flip(img, 2) on a non-square image flips horizontally
+        if self._is_range(self.gauss):
+            for i in range(n):
+                P[i, 1] = np.sqrt(1e-4 * rs.randint(self.gauss[0], self.gauss[1]))
+        if self._is_range(self.poisson):
+            extra["poisson_l"] = np.array([rs.randint(self.poisson[0], self.poisson[1]) for _ in range(n)])
+        if self._is_range(self.salt_and_pepper):
+            for i in range(n):
+                P[i, 3] = rs.randint(self.salt_and_pepper[0], self.salt_and_pepper[1]) * 1e-3
+        if self._is_range(self.blur):
+            extra["blur_sigma"] = np.array([rs.randint(self.blur[0], self.blur[1]) * 5e-2 for _ in range(n)])
+        if self._is_range(self.contrast):
+            for i in range(n):
+                P[i, 4] = rs.randint(self.contrast[0], self.contrast[1]) / 10
+        if self.background:
+            for i in range(n):
+                x0 = rs.randint(0, h - h // 4)
+                y0 = rs.randint(0, w - w // 4)
+                a, b = rs.randint(10, 20, 2) / 10
+                fwhm = rs.randint(min(h, w) // 4, min(h, w) - min(h, w) // 2)
+                amp = 0.05 * rs.randint(-10, 10)
+                P[i, 5:11] = (x0, y0, a, b, fwhm, amp)
+        return P, extra
+
+    # ------------------------------------------------------------------ device
+    def _point(self, x, P, mnmx=None, fields=None):
+        fields = fields or {}
+        N, H, W = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        Pd = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float32)).to(dev)
+        f = lambda k: None if fields.get(k) is None else fields[k].to(dev).float().contiguous()   # noqa: E731
+        keep = [f("gauss"), f("poisson"), f("sp_flip"), f("sp_salt")]
+        L.call("amx_aug_point", L.ptr(x), L.ptr(y), L.ptr(Pd), L.ptr(mnmx), L.ptr(keep[0]), L.ptr(keep[1]),
+               L.ptr(keep[2]), L.ptr(keep[3]), N, H, W, self.seed, L.stream_ptr(x))
+        return y
+
+    def run(self, images: torch.Tensor, targets: torch.Tensor, fields: dict = None) -> Tuple[torch.Tensor]:
+        """images (N, H, W) or (N, 1, H, W) fp32 on the device; targets (N, H, W) int64 class maps or (N, 1, H, W)
+        fp32 binary masks.  ``fields`` (tests): {'gauss','poisson','sp_flip','sp_salt'} -> (N, H, W) tensors."""
+        x = images[:, 0] if images.ndim == 4 else images
+        x = x.float().contiguous()
+        N, H, W = x.shape
+        P, extra = self.draw(N, H, W)
+        self.params, self.extra = P, extra
+        fields = dict(fields or {})
+        zero = np.zeros_like(P)
+        zero[:, 0] = 4
+        # ---- pass A: normalise, rotate, gaussian noise
+        PA = zero.copy()
+        PA[:, 0:2] = P[:, 0:2]
+        rest = P.copy()
+        rest[:, 0] = 4
+        rest[:, 1] = 0
+        need_split = "poisson_l" in extra or "blur_sigma" in extra
+        if not need_split:
+            PA = P                                            # everything in ONE pass
+        x = self._point(x, PA, _minmax(x), fields)
+        if need_split:
+            # ---- pass B: poisson (its scale needs the number of distinct values of the image so far), salt & pepper
+            PB = zero.copy()
+            PB[:, 3] = rest[:, 3]
+            if "poisson_l" in extra:
+                vals = _unique_counts(x)
+                PB[:, 2] = (50.0 / extra["poisson_l"]) ** np.ceil(np.log2(vals))
+                extra["poisson_vals"] = PB[:, 2].copy()
+            if PB[:, 2:4].any():
+                x = self._point(x, PB, None, fields)
+            if "blur_sigma" in extra:
+                sg = torch.from_numpy(extra["blur_sigma"].astype(np.float32)).to(x.device)
+                t = torch.empty_like(x)
+                L.call("amx_aug_blur", L.ptr(x), L.ptr(t), L.ptr(sg), N, H, W, 0, L.stream_ptr(x))
+                L.call("amx_aug_blur", L.ptr(t), L.ptr(x), L.ptr(sg), N, H, W, 1, L.stream_ptr(x))
+            # ---- pass C: contrast, background
+            PC = zero.copy()
+            PC[:, 4:] = rest[:, 4:]
+            if PC[:, 4].any() or PC[:, 10].any():
+                x = self._point(x, PC, None, None)
+        # ---- labels: same flips / rotations; drop pairs in which a class disappeared (squeeze_channels)
+        keep = None
+        if targets.dtype == torch.int64:
+            t = targets.contiguous()
+            out_t = torch.empty_like(t)
+            present = torch.zeros(N, dtype=torch.int32, device=t.device)
+            Pd = torch.from_numpy(P.astype(np.float32)).to(t.device)
+            L.call("amx_aug_labels", L.ptr(t), L.ptr(out_t), L.ptr(Pd), L.ptr(present), N, H, W, L.stream_ptr(t))
+            targets = out_t
+            if self.ch and self.ch > 1:
+                full = (1 << self.ch) - 1
+                keep = (present.cpu().numpy() & full) == full         # host sync: the batch size may change
+        else:
+            t = (targets[:, 0] if targets.ndim == 4 else targets).float().contiguous()
+            PF = zero.copy()
+            PF[:, 0] = P[:, 0]
+            t = self._point(t, PF, None, None)
+            targets = t[:, None] if targets.ndim == 4 else t
+        if keep is not None and not keep.all():
+            idx = torch.from_numpy(np.nonzero(keep)[0]).to(x.device)
+            x, targets = x.index_select(0, idx).contiguous(), targets.index_select(0, idx).contiguous()
+        if x.shape[0]:
+            mm = _minmax(x)                                   # kept referenced until the launch is enqueued
+            L.call("amx_aug_renorm", L.ptr(x), x.numel(), L.ptr(mm), L.stream_ptr(x))
+        return x[:, None], targets
+
+
+def seg_augmentor(nb_classes: int, **kwargs) -> Optional[Callable]:
+    """``augmentor(images, labels, seed)`` for BaseTrainer.data_augmentation / Segmentor.fit(..., rotation=True, ...)
+    (imaug.py:398-432); None when no augmentation keyword is given."""
+    auglist = ["custom_transform", "zoom", "gauss_noise", "jitter", "poisson_noise", "contrast", "salt_and_pepper",
+               "blur", "resize", "rotation", "background"]
+    augdict = {k: kwargs[k] for k in auglist if k in kwargs}
+    if len(augdict) == 0:
+        return None
+    datatransform(nb_classes, 0, **augdict)                  # unsupported keys raise now, not at the first batch
+
+    def augmentor(images, labels, seed):
+        if not images.is_cuda and torch.cuda.is_available():      # batches kept on the host (memory_alloc exceeded)
+            images = images.cuda()
+        dev = images.device
+        if not (images.is_cuda or L.is_test_backend()):
+            raise L.AmxError("on-device augmentation needs the batch on the MI355X")
+        dt = datatransform(nb_classes, seed, **augdict)
+        return dt.run(images, labels.to(dev))
+
+    return augmentor

@@ -161,6 +161,26 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
 
+/* ---- on-the-fly augmentation of the resident batch (datatransform.run and its apply_* steps,
+ * atomai/transforms/imaug.py:108-358; hook atomai/trainers/trainer.py:339-341).  x / y are [N][H][W] fp32.
+ * amx_aug_minmax: out = (min, max) of x (work: 2 * amx_aug_minmax_blocks(n) floats).
+ * amx_aug_point: flip / 90-degree rotation, (x - min) / ptp, gaussian noise + clip, poisson, salt & pepper, gamma,
+ *   2-D gaussian background in one pass; params [N][12] per image = (flip code -1|0|1|2 ccw|3 cw|4 none, gauss sigma,
+ *   poisson scale, s&p amount, gamma, bg x0, y0, a, b, fwhm, bg amplitude, 0); 0 switches a step off.  Per-pixel
+ *   randomness: Philox4x32-10 keyed by (seed, image, pixel, step), or the caller's fields f_* ([N][H][W]; NULL = use
+ *   the generator): standard normals, poisson draws, and the two uniforms of salt & pepper.
+ * amx_aug_blur: one axis (0 rows, 1 columns) of scipy.ndimage.gaussian_filter(sigma[n], mode='reflect', truncate=4).
+ * amx_aug_labels: the same flip / rotation on int64 class maps; present[n] |= 1 << class (caller zeroes it). */
+int amx_aug_minmax_blocks(long n);
+int amx_aug_minmax(const float* x, long n, float* work, float* out, void* stream);
+int amx_aug_point(const float* x, float* y, const float* params, const float* mnmx, const float* f_gauss,
+                  const float* f_pois, const float* f_sp1, const float* f_sp2, int N, int H, int W, long seed,
+                  void* stream);
+int amx_aug_renorm(float* x, long n, const float* mnmx, void* stream);
+int amx_aug_blur(const float* x, float* y, const float* sigma, int N, int H, int W, int axis, void* stream);
+int amx_aug_labels(const long long* t, long long* out, const float* params, int* present, int N, int H, int W,
+                   void* stream);
+
 /* ---- dense layers (nn.Linear + Tanh / ReLU of fcEncoderNet / fcDecoderNet / the convEncoderNet heads,
  * atomai/nets/ed.py:231-343, 530-580, and of fcFeatureExtractor, atomai/nets/gp.py:14-26): one fp32-MFMA GEMM
  * C[M][N] = act(A * B + bias) with operand strides — element (m, k) of A at A[m*sam + k*sak], (k, n) of B at

@@ -333,6 +333,39 @@ def make_vae_cond(aoi):
     np.savez_compressed(os.path.join(GOLD, "vae_cond.npz"), **out)
 
 
+def make_augment(aoi):
+    """datatransform.run of the real reference for the steps that are pure numpy / scipy there (poisson, blur,
+    background, the two min-max normalisations); per-pixel poisson draws are recorded by wrapping np.random.poisson."""
+    from atomai.transforms import datatransform
+    out = {}
+    rs = np.random.RandomState(3)
+    # (1) blur + background on a batch: every scalar draw is reproducible from the seed
+    X = rs.rand(3, 20, 28)
+    y = (rs.rand(3, 20, 28, 1) > 0.5).astype(np.float64)
+    dt = datatransform(1, "channel_last", "channel_first", False, 7, blur=[1, 50], background=True)
+    Xa, ya = dt.run(X.copy(), y.copy())
+    out["bb|X"], out["bb|out"], out["bb|seed"] = X, Xa, np.array(7)
+    # (2) poisson on ONE image (the per-pixel draws consume the global stream, so only the first image's level is
+    # reproducible from the seed); the draws themselves are captured
+    X1 = rs.rand(1, 24, 24)
+    rec = []
+    orig = np.random.poisson
+
+    def wrapped(lam, *a, **k):
+        r = orig(lam, *a, **k)
+        rec.append(np.array(r))
+        return r
+    np.random.poisson = wrapped
+    try:
+        dt = datatransform(1, "channel_last", "channel_first", False, 11, poisson_noise=[30, 40])
+        Xp, _ = dt.run(X1.copy(), y[:1, :24, :24].copy())
+    finally:
+        np.random.poisson = orig
+    out["po|X"], out["po|out"], out["po|draws"], out["po|seed"] = X1, Xp, rec[0].astype(np.float64)[None], np.array(11)
+    np.savez_compressed(os.path.join(GOLD, "augment.npz"), **out)
+    print("augment ok", Xa.shape, Xp.shape)
+
+
 def make_vae_conv(aoi):
     """rVAE with the opt-in convolutional encoder (ed.py:231-289): ConvBlock(lrelu 0.1, no BN) + two Linear."""
     out = {}
@@ -490,10 +523,10 @@ def make_vae_api(aoi):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment}[w](aoi)
     print("done ->", GOLD)

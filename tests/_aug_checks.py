@@ -1,0 +1,120 @@
+"""Shared bodies of the augmentation tests (emulator tier / gpu tier)."""
+import os
+
+import numpy as np
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def check_oracle_vs_reference_golden():
+    """oracle/aug_oracle.py == the real reference's datatransform.run for the numpy / scipy steps."""
+    from oracle import aug_oracle as ao
+    from atomai_amd.transforms import datatransform
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    X = g["bb|X"]
+    dt = datatransform(1, int(g["bb|seed"]), blur=[1, 50], background=True)
+    P, extra = dt.draw(*X.shape)                              # the reference's scalar draws, reproduced from the seed
+    ref = ao.run(X, P, blur_sigma=extra["blur_sigma"])
+    np.testing.assert_allclose(ref[:, None], g["bb|out"], rtol=0, atol=1e-12)
+    X1 = g["po|X"]
+    dt = datatransform(1, int(g["po|seed"]), poisson_noise=[30, 40])
+    P, extra = dt.draw(*X1.shape)
+    xn = ao.normalize(X1)
+    vals = (50 / extra["poisson_l"]) ** np.ceil(np.log2([len(np.unique(xn[0]))]))
+    ref = ao.run(X1, P, fields={"poisson": g["po|draws"]}, poisson_vals=vals)
+    np.testing.assert_allclose(ref[:, None], g["po|out"], rtol=0, atol=1e-12)
+
+
+def check_kernels_vs_reference_golden(device):
+    """The HIP path end to end (datatransform.run on the device) against the reference's output."""
+    from atomai_amd.transforms import datatransform
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    X = torch.from_numpy(g["bb|X"]).float().to(device)
+    y = torch.zeros(3, 1, 20, 28, device=device)
+    out, _ = datatransform(1, int(g["bb|seed"]), blur=[1, 50], background=True).run(X, y)
+    assert out.shape == g["bb|out"].shape
+    assert np.abs(out.cpu().numpy() - g["bb|out"]).max() < 2e-5
+    X1 = torch.from_numpy(g["po|X"]).float().to(device)
+    dt = datatransform(1, int(g["po|seed"]), poisson_noise=[30, 40])
+    out, _ = dt.run(X1, torch.zeros(1, 1, 24, 24, device=device),
+                    fields={"poisson": torch.from_numpy(g["po|draws"])})
+    assert np.abs(out.cpu().numpy() - g["po|out"]).max() < 2e-5
+
+
+def check_kernels_vs_oracle_all_steps(device, N=5, H=24, W=24):
+    """Every step (also the skimage / cv2-owned ones, restated in the oracle) with injected noise fields."""
+    from oracle import aug_oracle as ao
+    from atomai_amd.transforms import datatransform
+    rs = np.random.RandomState(0)
+    X = rs.rand(N, H, W)
+    lab = rs.randint(0, 3, (N, H, W))
+    fields = {"gauss": rs.randn(N, H, W), "sp_flip": rs.rand(N, H, W), "sp_salt": rs.rand(N, H, W)}
+    dt = datatransform(3, 5, rotation=True, gauss_noise=True, salt_and_pepper=[20, 50], contrast=True, background=True)
+    out, tl = dt.run(torch.from_numpy(X).float().to(device), torch.from_numpy(lab).to(device),
+                     fields={k: torch.from_numpy(v) for k, v in fields.items()})
+    P = dt.params
+    assert set(P[:, 0]) <= {-1, 0, 1, 2} and (P[:, 1] > 0).any() and (P[:, 4] > 0).all()
+    # rotated noise fields: the kernel indexes its fields by OUTPUT pixel, as the reference applies noise after rotating
+    ref = ao.run(X, P, fields=fields)
+    assert out.shape == (N, 1, H, W)
+    assert np.abs(out[:, 0].cpu().numpy() - ref).max() < 3e-5
+    for i in range(N):
+        assert np.array_equal(tl[i].cpu().numpy(), ao.flip(lab[i], int(P[i, 0])))
+
+
+def check_generator_statistics(device, N=4, H=64, W=64):
+    """The in-kernel Philox sampler: gaussian mean / variance, poisson mean / variance (small and large rates), salt &
+    pepper fractions; determinism for equal seeds, different fields for different seeds."""
+    from atomai_amd import _lib as L
+    x = torch.full((N, H, W), 0.5, device=device)
+    P = np.zeros((N, 12), np.float32)
+    P[:, 0] = 4
+
+    def point(P_, seed):
+        y = torch.empty_like(x)
+        Pd = torch.from_numpy(P_).to(device)
+        L.call("amx_aug_point", L.ptr(x), L.ptr(y), L.ptr(Pd), None, None, None, None, None, N, H, W, seed,
+               L.stream_ptr(x))
+        return y.cpu().numpy()
+    Pg = P.copy(); Pg[:, 1] = 0.05
+    a, b, c = point(Pg, 1), point(Pg, 1), point(Pg, 2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    z = (a - 0.5) / 0.05
+    assert abs(z.mean()) < 0.03 and abs(z.var() - 1) < 0.05
+    assert abs(np.corrcoef(z[0].ravel(), z[1].ravel())[0, 1]) < 0.05          # images get independent streams
+    for scale in (6.0, 400.0):                                                # lambda = 3 and 200
+        Pp = P.copy(); Pp[:, 2] = scale
+        k = point(Pp, 3) * scale
+        lam = 0.5 * scale
+        assert np.allclose(k, np.round(k), atol=1e-3)
+        assert abs(k.mean() - lam) < 0.04 * lam and abs(k.var() - lam) < 0.08 * lam
+    Ps = P.copy(); Ps[:, 3] = 0.2
+    s = point(Ps, 4)
+    salt, pepper = (s == 1).mean(), (s == 0).mean()
+    assert abs(salt - 0.1) < 0.01 and abs(pepper - 0.1) < 0.01
+
+
+def check_class_drop_and_trainer_hook(device):
+    """Pairs in which a class is absent are dropped (squeeze_channels); seg_augmentor plugs into the trainer."""
+    import atomai_amd as aoi
+    from atomai_amd.transforms import datatransform, seg_augmentor
+    rs = np.random.RandomState(1)
+    X = torch.from_numpy(rs.rand(4, 16, 16).astype(np.float32)).to(device)
+    lab = rs.randint(0, 3, (4, 16, 16))
+    lab[2][lab[2] == 1] = 0                                   # image 2 has no class 1
+    out, tl = datatransform(3, 0, rotation=True).run(X, torch.from_numpy(lab).to(device))
+    assert out.shape == (3, 1, 16, 16) and tl.shape == (3, 16, 16) and tl.dtype == torch.int64
+    assert float(out.min()) == 0.0 and float(out.max()) == 1.0
+    assert seg_augmentor(3) is None
+    try:
+        seg_augmentor(3, zoom=True)
+        raise AssertionError("zoom must raise")
+    except NotImplementedError:
+        pass
+    Xn = rs.rand(8, 16, 16).astype(np.float32)
+    yn = rs.randint(0, 3, (8, 16, 16))
+    m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, seed=1)
+    m.fit(Xn, yn, Xn[:4], yn[:4], training_cycles=3, batch_size=4, rotation=True, gauss_noise=[20, 40], contrast=True,
+          background=True, plot_training_history=False)
+    assert len(m.loss_acc["train_loss"]) == 3 and all(np.isfinite(m.loss_acc["train_loss"]))
