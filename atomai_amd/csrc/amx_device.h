@@ -42,6 +42,18 @@ extern "C" void amx_set_error(const char* fn, int code, const char* detail);
         }                                                         \
     } while (0)
 
+// Wave-level ordering point between LDS writes and reads of OTHER lanes of the same wave.  The hardware executes a
+// wave's instructions in lock step, so only the compiler must be kept from reordering (wave_barrier emits no code);
+// the CPU emulator runs one lane at a time and needs a real rendezvous.
+static __device__ __forceinline__ void amx_wave_sync() {
+#ifdef AMX_EMU
+    (void)__shfl_xor(0.f, 1);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 // Scheduling fence: nothing is moved across it by the instruction scheduler (used to keep operand prefetches ahead
 // of the MFMA burst they are meant to overlap with).  No code is emitted.
 static __device__ __forceinline__ void amx_sched_fence() {

@@ -2,6 +2,11 @@
 // conv_fwd_1x1.hip, conv_fwd_3x3.hip, conv_fwd_dil.hip).
 #include "conv_kernel.h"
 
+#ifdef AMX_CONV_PROFILE
+static void* amx_conv_profile_buffer = nullptr;
+extern "C" int amx_conv_set_profile_buffer(void* buf) { amx_conv_profile_buffer = buf; return 0; }
+#endif
+
 struct ConvPlan { int nt, th; };
 
 // Tile plan, from the per-shape measurements in profiles/r01_conv_variants.md: this kernel is fastest with MANY
@@ -19,6 +24,8 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
     else { pl.nt = 2; pl.th = small ? 8 : 16; }
     if (const char* e = getenv("AMX_CONV_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && v * 16 <= cop) pl.nt = v; }
     if (const char* e = getenv("AMX_CONV_TH")) { const int v = atoi(e); if (v == 16 || (v == 8 && small)) pl.th = v; }
+    // experiment: 8-row tiles for the 64-cout dilated variant (AMX_CONV_DIL_TH=8)
+    if (taps == 9 && dil > 1 && pl.nt == 4) { if (const char* e = getenv("AMX_CONV_DIL_TH")) { if (atoi(e) == 8) pl.th = 8; } }
     return pl;
 }
 
@@ -37,6 +44,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     if ((x1 == nullptr) != (C1s == 0)) AMX_BADARG(6);
     if ((y1 == nullptr) != (Y1s == 0)) AMX_BADARG(7);
     if ((long)N * H * W >= 2147483647L) AMX_BADARG(2);           // pixel offsets are 32-bit
+    if (stats && addend) AMX_BADARG(10);                          // statistics describe the un-accumulated output
     ConvFwdArgs a;
     a.x0 = x0; a.sc0 = sc0; a.sh0 = sh0; a.C0s = C0s;
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
@@ -45,6 +53,9 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
     a.aux0 = nullptr; a.k1 = a.k2 = a.k3 = nullptr; a.bslope = 1.f;      // loader / epilogue fusions of the backward
     a.ea0 = a.ea1 = nullptr; a.bstats = nullptr;                         // experiment (round 1): not instantiated
+#ifdef AMX_CONV_PROFILE
+    a.bstats = (float*)amx_conv_profile_buffer;                          // dev build: per-wave phase timestamps
+#endif
     a.xcd = 0;
     a.N = N; a.H = H; a.W = W;
     a.cout = cout;
@@ -97,10 +108,10 @@ extern "C" int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, con
                          Y1s, nullptr, N, H, W, Y0s + Y1s, taps, dil, 1.f, stream);
 }
 
-// Tile height (8 or 16) amx_conv2d_fwd will use for this layer, and the number of partial-statistics rows
-// (tiles) it then writes: rows x 2 x round_up(cout,16).
+// Height (in image rows) of the 16-pixel-wide strip one partial-statistics row of amx_conv2d_fwd covers for this
+// layer, and the number of such rows it writes: rows x 2 x round_up(cout,16).
 extern "C" int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H) {
-    return plan_conv(Cin_s, cout, taps, dil, H).th;
+    return plan_conv(Cin_s, cout, taps, dil, H).th / 4;      // one statistics row per WAVE: a strip of th/4 image rows
 }
 extern "C" int amx_conv2d_num_tiles(int N, int H, int W, int th) {
     return amx_ceil_div(W, TILE) * amx_ceil_div(H, th) * N;

@@ -78,15 +78,37 @@ struct ConvFwdArgs {
 //
 // Compile-time experiment switches (tools/build_variant_lib.sh builds one library per combination for in-process A/B):
 //   AMX_CONV_SWP    1: operand fragments of tap t+1 are read into a second register set before tap t's MFMAs
-//   AMX_CONV_EXACT  1: plain 3x3 instantiations (MAXHALO == 1) use the compile-time halo instead of a.dil
+//   AMX_CONV_EXACT  0: instantiations marked EXACT still read the dilation from the arguments (round-1 behaviour)
 #ifndef AMX_CONV_SWP
 #define AMX_CONV_SWP 0
 #endif
 #ifndef AMX_CONV_EXACT
-#define AMX_CONV_EXACT 0
+#define AMX_CONV_EXACT 1
 #endif
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
+// AMX_CONV_PROFILE (dev builds only, tools/gpu_conv_phases.py): every wave records the shader clock at its phase
+// boundaries into the buffer passed through a.bstats: [workgroup][wave][16] 64-bit ticks.
+#ifdef AMX_CONV_PROFILE
+#define AMX_TICK(slot)                                                                                          \
+    do {                                                                                                        \
+        if (a.bstats && lane == 0)                                                                              \
+            reinterpret_cast<unsigned long long*>(a.bstats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (slot)] = \
+                __builtin_amdgcn_s_memtime();                                                                   \
+    } while (0)
+#else
+#define AMX_TICK(slot) do { } while (0)
+#endif
+// Waves per SIMD the plain-3x3 instantiations are built for.  Co-resident waves are what keeps the matrix pipe fed
+// (utilisation ~ N * t_mfma / (t_mfma + t_other) per SIMD, profiles/r02_conv_phases.md), and these variants sit a
+// handful of registers above the next allocation step: the bound makes the allocator take the step.
+template <int TAPS, int NT, int MAXHALO, int MTW, bool TAIL>
+struct ConvWaves {
+    static constexpr int value = (TAPS == 9 && MAXHALO == 1 && !TAIL)
+                                     ? ((MTW == 2 && NT <= 2) ? 4 : ((MTW == 4 && NT == 1) ? 3 : 1))
+                                     : 1;
+};
+
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false>
+__global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
     constexpr int MAXI = TILE + 2 * MAXHALO;
@@ -97,10 +119,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
-    const int halo = (TAPS == 9) ? ((AMX_CONV_EXACT && MAXHALO == 1) ? 1 : a.dil) : 0;
+    AMX_TICK(0);
+    // EXACT: the dilation equals MAXHALO (1, 2, 4, 6 — every dilation the reference's nets use) and the whole tile
+    // geometry is compile-time: the slot index math of the loaders divides by constants instead of running a ~40
+    // instruction integer division per slot, and the 9 tap offsets of the fragment reads are immediates.
+    const int halo = (TAPS == 9) ? ((AMX_CONV_EXACT && EXACT) ? MAXHALO : a.dil) : 0;
     const int IW = TILE + 2 * halo, IH = TH + 2 * halo;
     const int plane = amx_round_up(IH * IW, 16);                 // slots (16 B) per k-group plane
-    // one stage = input image [KG][plane][4] + weight image [TAPS][KG][NB][4]; two stages when DBUF
+    // one stage = input image [KG][plane][4] + weight image [TAPS][KG][NB][4]
     const int stage_floats = KG * plane * 4 + TAPS * KG * NB * 4;
     float* s_red = smem;                                         // reused after the K loop
 
@@ -116,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
     const int n0 = ob * NB;                                      // first cout of this workgroup
     const int gy0 = ty * TH - halo, gx0 = tx * TILE - halo;
 
+    AMX_TICK(14);
     // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
     const int my_kg = tid & (KG - 1);
     const int nslots = IH * IW;
@@ -131,6 +158,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
         x_off[i] = off;
     }
+    AMX_TICK(15);
 
     float4 xr[XLD];
     float4 wr[WLD];
@@ -159,6 +187,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
             if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
         }
         const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
+#ifdef AMX_CONV_NOWLOAD      // TIMING EXPERIMENT ONLY (wrong results): what would a resident weight image save?
+        if (chunk > 0 || blockIdx.x > 4096) return;
+#endif
         #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int idx = tid + i * 256;                       // over [TAPS*KG][NB]
@@ -199,6 +230,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
                 amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
             }
         }
+#ifdef AMX_CONV_NOWLOAD
+        if (blockIdx.x > 4096) return;
+#endif
         #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int idx = tid + i * 256;
@@ -258,8 +292,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             if (tap < tap0 || tap >= tap1) continue;
-            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
-            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * halo : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * halo : 0;
             float4 af[MTW], bf[NT];
             #pragma unroll
             for (int m = 0; m < MTW; ++m) {
@@ -289,8 +323,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         const float* s_w = s_in + KG * plane * 4;
         #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = (TAPS == 9) ? (tap / 3 - 1) * a.dil : 0;
-            const int dx = (TAPS == 9) ? (tap % 3 - 1) * a.dil : 0;
+            const int dy = (TAPS == 9) ? (tap / 3 - 1) * halo : 0;
+            const int dx = (TAPS == 9) ? (tap % 3 - 1) * halo : 0;
             #pragma unroll
             for (int j = 0; j < KG - 1; ++j) {
                 if (j >= nkg) break;
@@ -312,151 +346,135 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvFwdArgs a) {
         }
     };
 
-    issue_loads(0);
-    if (DBUF) {
-        // Software pipeline over two LDS stages: the global loads of chunk c+1 are issued before, and their
-        // LDS image is written in the middle of, the MFMA stream of chunk c -> ONE barrier per chunk and no
-        // staging gap in the matrix pipe.
-        stage_to_lds(0);
-        __syncthreads();
-        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-            const int cur = chunk & 1;
-            const bool more = chunk + 1 < a.nchunk;
-            if (more) issue_loads(chunk + 1);
-            compute_taps(cur, 0, (TAPS + 1) / 2);
-            if (more) stage_to_lds(cur ^ 1);
-            compute_taps(cur, (TAPS + 1) / 2, TAPS);
-            __syncthreads();
-        }
-    } else {
-        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-            stage_to_lds(0);
-            __syncthreads();
-            if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
-            if (TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
-            else compute_taps(0, 0, TAPS);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: bias + LeakyReLU (+addend), store, statistics ----
-    // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
-    const int oy0 = ty * TH + wave * MTW, ox0 = tx * TILE + 4 * g;
-    const int ctot = a.Y0s + a.Y1s;
-    float lsum[NT], lsum2[NT];
+    // the bias is fetched up front: a global load at the head of the epilogue would expose a full memory round trip
+    // (not for the widest tile: 4 more live registers would push it past 256 = one workgroup per CU instead of two)
+    constexpr bool PREB = !(NT == 4 && MTW == 4);
+    float bias_q[NT];
     #pragma unroll
     for (int q = 0; q < NT; ++q) {
         const int co = n0 + q * 16 + p;
-        lsum2[q] = 0.f;
-        const float b = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
-        float* dst = nullptr; int Cd = 0, cd = 0;
-        if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; }
-        else if (co < ctot) { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
+        bias_q[q] = (PREB && a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+    issue_loads(0);
+    AMX_TICK(1);
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        stage_to_lds(0);
+        if (chunk < 2) AMX_TICK(2 + 5 * chunk);
+        __syncthreads();
+        if (chunk < 2) AMX_TICK(3 + 5 * chunk);
+        if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
+        if (chunk < 2) AMX_TICK(4 + 5 * chunk);
+        if (TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
+        else compute_taps(0, 0, TAPS);
+        if (chunk < 2) AMX_TICK(5 + 5 * chunk);
+        __syncthreads();
+        if (chunk < 2) AMX_TICK(6 + 5 * chunk);
+    }
+
+    // ---- epilogue: bias + LeakyReLU in registers, per-WAVE statistics (shuffles only: no LDS, no
+    // workgroup barrier), then the accumulators are transposed through a wave-private LDS region and leave as 16-byte
+    // stores along the channel axis.  Measured with per-phase shader-clock stamps (tools/gpu_conv_phases.py): the 16
+    // scalar stores per lane of the direct form cost ~600 cycles EACH under load (the vector-memory issue path is the
+    // contended resource, not bandwidth) and the three barriers of the workgroup-level statistics another ~5 k cycles:
+    // together a third of a wave's lifetime on the <= 32-channel layers.
+    // C/D fragment: column (cout) = lane&15 = p, row (pixel x) = 4*g + reg.
+    const int oy0 = ty * TH + wave * MTW, ox0 = tx * TILE + 4 * g;
+    const int ctot = a.Y0s + a.Y1s;
+    float lsum[NT];
+    #pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int co = n0 + q * 16 + p;
+        const float b = PREB ? bias_q[q] : ((a.bias && co < a.cout) ? a.bias[co] : 0.f);
         lsum[q] = 0.f;
         #pragma unroll
         for (int m = 0; m < MTW; ++m)
             #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int oy = oy0 + m, ox = ox0 + r;
                 float v = acc[m][q][r] + b;
                 v = v > 0.f ? v : v * a.slope;
-                const bool ok = (oy < a.H) && (ox < a.W) && dst;
-                if (ok) {
-                    const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
-                    if (a.addend && dst == a.y) v += a.addend[o];
-                    dst[o] = v;
-                    lsum[q] += v;
-                    if (FUSED && a.bstats) {
-                        const float* ea = dst == a.y ? a.ea0 : a.ea1;
-                        if (ea) lsum2[q] = fmaf(v, ea[o], lsum2[q]);
-                    }
-                } else {
-                    v = 0.f;
-                }
+                const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W) && co < ctot;
+                v = ok ? v : 0.f;
+                lsum[q] += v;
                 acc[m][q][r] = v;
             }
     }
-    if (FUSED && a.bstats) {
-        // backward statistics of the source layers' BatchNorm: per-tile (sum dy, sum dy*a) per channel
+    AMX_TICK(12);
+    if (a.stats && oy0 < a.H) {
+        // one statistics row per wave: (sum, M2 about the wave's own mean) over its MTW x 16 pixel strip; the host
+        // sees MTW as the "tile height" (amx_conv2d_tile_h) and the merge kernels weight rows by their pixel counts
+        const int vy = min(MTW, a.H - oy0), vx = min(TILE, a.W - tx * TILE);
+        const float inv_cnt = 1.0f / (float)(vy * vx);
+        const int sub_y = ty * 4 + wave, subs_y = amx_ceil_div(a.H, MTW);
+        const size_t row = ((size_t)n * subs_y + sub_y) * a.tiles_x + tx;
         #pragma unroll
         for (int q = 0; q < NT; ++q) {
-            float s1 = lsum[q], s2 = lsum2[q];
-            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-            if (g == 0) { s_red[wave * NB + q * 16 + p] = s1; s_red[(4 + wave) * NB + q * 16 + p] = s2; }
-        }
-        __syncthreads();
-        if (tid < 2 * NB) {
-            const int which = tid / NB, c = tid - which * NB;
-            const int co = n0 + c;
-            if (co < a.cop) {
-                const float* r = s_red + which * 4 * NB;
-                a.bstats[((size_t)tile_id * 2 + which) * a.cop + co] = r[c] + r[NB + c] + r[2 * NB + c] + r[3 * NB + c];
-            }
-        }
-        return;
-    }
-    if (!a.stats) return;
-
-    const int vy = min(TH, a.H - ty * TH), vx = min(TILE, a.W - tx * TILE);
-    const float inv_cnt = 1.0f / (float)(vy * vx);
-    // pass 1: per-cout sum over the tile -> mean
-    #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        float s = lsum[q];
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        if (g == 0) s_red[wave * NB + q * 16 + p] = s;
-    }
-    __syncthreads();
-    float mean[NT];
-    #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int c = q * 16 + p;
-        mean[q] = (s_red[c] + s_red[NB + c] + s_red[2 * NB + c] + s_red[3 * NB + c]);
-    }
-    __syncthreads();
-    // pass 2: M2 about the tile mean
-    #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const float mu = mean[q] * inv_cnt;
-        float s2 = 0.f;
-        #pragma unroll
-        for (int m = 0; m < MTW; ++m)
+            float sm = lsum[q];
+            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+            const float mu = sm * inv_cnt;
+            float s2 = 0.f;
             #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
-                const float d = acc[m][q][r] - mu;
-                s2 += ok ? d * d : 0.f;
-            }
-        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-        if (g == 0) s_red[wave * NB + q * 16 + p] = s2;
-    }
-    __syncthreads();
-    if (tid < NB) {
-        const int co = n0 + tid;
-        if (co < a.cop) {
-            const float m2 = s_red[tid] + s_red[NB + tid] + s_red[2 * NB + tid] + s_red[3 * NB + tid];
-            a.stats[((size_t)tile_id * 2 + 1) * a.cop + co] = m2;
-        }
-    }
-    // tile sums: every lane holds mean[q] (= tile sum) for column q*16+p; 16 lanes of wave 0 write them
-    if (wave == 0 && g == 0) {
-        #pragma unroll
-        for (int q = 0; q < NT; ++q) {
+            for (int m = 0; m < MTW; ++m)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
+                    const float d = acc[m][q][r] - mu;
+                    s2 += ok ? d * d : 0.f;
+                }
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
             const int co = n0 + q * 16 + p;
-            if (co < a.cop) a.stats[(size_t)tile_id * 2 * a.cop + co] = mean[q];
+            if (g == 0 && co < a.cop) {
+                a.stats[(row * 2) * a.cop + co] = sm;
+                a.stats[(row * 2 + 1) * a.cop + co] = s2;
+            }
         }
     }
+    // transpose: [row m][pixel x][cout] in this wave's LDS region, MH rows at a time
+    constexpr int MH = MTW < 2 ? MTW : 2;
+    constexpr int CG = NB / 4;                                   // float4 groups per pixel
+    float* s_epi = smem + (size_t)wave * (MH * TILE * NB);
+    #pragma unroll
+    for (int m0 = 0; m0 < MTW; m0 += MH) {
+        #pragma unroll
+        for (int mm = 0; mm < MH; ++mm)
+            #pragma unroll
+            for (int q = 0; q < NT; ++q)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_epi[(mm * TILE + 4 * g + r) * NB + q * 16 + p] = acc[m0 + mm][q][r];
+        amx_wave_sync();                                         // wave-private region: no workgroup barrier needed
+        #pragma unroll
+        for (int it = 0; it < MH * TILE * CG / 64; ++it) {
+            const int e = it * 64 + lane;
+            const int pix = e / CG, cgp = e - pix * CG;
+            const int mm = pix / TILE, x = pix - mm * TILE;
+            const int oy = oy0 + m0 + mm, ox = tx * TILE + x;
+            const int co = n0 + cgp * 4;
+            if (oy < a.H && ox < a.W && co < ctot) {
+                float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
+                float* dst; int Cd, cd;
+                if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; } else { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
+                const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
+                if (a.addend && dst == a.y) { const float4 ad = amx_ld4(a.addend + o); v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
+                amx_st4(dst + o, v);
+            }
+        }
+        if (m0 + MH < MTW) amx_wave_sync();                      // the region is rewritten by the next pair of rows
+    }
+    AMX_TICK(13);
 }
 
-template <int TAPS, int NT, int MAXHALO, bool DBUF, int MTW, bool FUSED, bool TAIL = false>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? a.dil : 0;
     const int I = TILE + 2 * halo;
     const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
     if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
-    size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) * (DBUF ? 2 : 1);
+    size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) ;
+    {   // the epilogue's transposition buffers: 4 waves x min(MTW, 2) rows x 16 pixels x NB couts
+        const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * NT * 16 * sizeof(float);
+        if (lds < epi) lds = epi;
+    }
     // occupancy experiment: AMX_CONV_MAXWG=k pads the LDS request so that at most k workgroups fit a CU
     if (const char* e = getenv("AMX_CONV_MAXWG")) {
         const int k = atoi(e);
@@ -466,13 +484,13 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, DBUF, MTW, FUSED, TAIL>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -29,6 +29,17 @@ template <> __device__ __forceinline__ float km_sqrt<float>(float x) { return sq
 template <> __device__ __forceinline__ double km_sqrt<double>(double x) { return sqrt(x); }
 
 // value and radial factor:  k = s2 * f(r2);  returns also w with  dk/d(diff_d) = -w * s_d^2 * diff_d
+// fp32 builder only: exp on the hardware transcendental unit (v_exp_f32 = 2^x, ~1 ulp; the argument product adds
+// |x| * 9e-8 relative error — below the fp32 tolerance of the path for every |x| that does not underflow anyway).
+// The library expf costs ~20 VALU instructions per element, which at 2.7e8 elements is as long as the 1 GB write.
+static __device__ __forceinline__ float km_fast_exp(float x) {
+#ifdef AMX_EMU
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ T km_eval(T r2, T s2, int kind, T* w) {
     if (kind == 0) {
@@ -80,7 +91,9 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
                 r2 += df * df;
             }
             T w;
-            T k = km_eval<T>(r2, s2, kind, &w);
+            T k;
+            if (sizeof(T) == 4 && kind == 0 && (getenv_nt & 2)) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2));
+            else k = km_eval<T>(r2, s2, kind, &w);
             if (gi == col0 + c) k += noise;
             out[v] = k;
         }
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
         T* dst = K + (size_t)gi * M + gc;
         if (gc + V <= M && ((M * sizeof(T)) % 16 == 0)) {
             if (V == 4) {
-                if (getenv_nt) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
+                if (getenv_nt & 1) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
                 else *reinterpret_cast<float4*>(dst) = *reinterpret_cast<float4*>(out);
             }
             else { dst[0] = out[0]; dst[1] = out[1]; }
@@ -105,7 +118,7 @@ static int launch_km(const void* X1, const void* X2, const void* inv_ls, double 
     constexpr int COLS = 64 * Vec16<T>::N;
     dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KM_ROWS));
     AMX_LAUNCH(kernel_matrix_kernel<T>, grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
-               (T)s2, kind, (T)noise, N, M, D, (T*)K, getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 1);   // streaming stores: +6..9 % (4.0-4.5 TB/s)
+               (T)s2, kind, (T)noise, N, M, D, (T*)K, getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 3);   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp
     AMX_CHECK_LAUNCH();
     return 0;
 }

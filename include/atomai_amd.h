@@ -32,8 +32,9 @@ int amx_clear_error(void);
  * reading torch.cat([src0, src1], 1) with each source's BN affine applied on load.
  * atomai/nets/blocks.py:61-76 (ConvBlock), :122-132 (UpsampleBlock 1x1), :300-318 (DilatedBlock);
  * atomai/nets/fcnn.py:132-138,223 (cat).  Also the data-gradient engine (weights packed with mode 1):
- * y/y1 are then the gradients w.r.t. src0/src1.  stats: [amx_conv2d_num_tiles][2][round_up(cout,16)], one row per
- * 16-wide x th-high tile (th = amx_conv2d_tile_h); amx_bn_finalize / amx_bn_stats_merge take th in rows_pix (mode 0). */
+ * y/y1 are then the gradients w.r.t. src0/src1.  stats: [amx_conv2d_num_tiles][2][round_up(cout,16)], one row
+ * (sum, M2) per 16-wide x th-high pixel strip (th = amx_conv2d_tile_h: the rows one wave owns); amx_bn_finalize /
+ * amx_bn_stats_merge take th in rows_pix (mode 0).  stats and addend are mutually exclusive. */
 int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
                    const float* x1, const float* sc1, const float* sh1, int C1s,
                    const float* wpk, const float* bias, const float* addend,

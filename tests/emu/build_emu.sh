@@ -13,7 +13,9 @@ NEED_LINK=0
 [ -f libatomai_amd_emu.so ] || NEED_LINK=1
 for f in $SRC/*.hip; do
   o=build/$(basename $f .hip).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ hip_emu.h -nt $o ] || [ $SRC/amx_device.h -nt $o ]; then
+  STALE=0
+  for h in hip_emu.h $SRC/*.h; do [ $h -nt $o ] && STALE=1; done      # any kernel header (conv_kernel.h, ...)
+  if [ ! -f $o ] || [ $f -nt $o ] || [ $STALE = 1 ]; then
     g++ -O2 -g -std=c++17 -Wno-psabi -fPIC -DAMX_EMU -I. -I$SRC -x c++ -c $f -o $o &
     NEED_LINK=1
   fi

@@ -85,6 +85,8 @@ def probe(tag, N, H, C0, C1, Cout, taps=9, dil=1, stats_on=True, iters=20):
         row[name] = ms
         if y0 is None:
             y0, s0 = y, st
+        elif name.startswith("x_"):
+            pass                                             # timing-only experiment libraries: results are not valid
         else:
             assert torch.equal(y, y0), (tag, name, float((y - y0).abs().max()))
             if st is not None and s0 is not None and st.shape == s0.shape:

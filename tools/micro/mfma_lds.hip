@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_rand(float* out, const float* src, int 
     for (int i = 0; i < 8; ++i) { a[i] = src[(threadIdx.x * 8 + i) & 4095]; b[i] = src[(threadIdx.x * 8 + i + 2048) & 4095]; }
     for (int it = 0; it < iters; ++it) {
         #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[(i + it) & 7], acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc[i], 0, 0, 0);
     }
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
