@@ -44,6 +44,9 @@ def r16(c: int) -> int:
     return (c + 15) // 16 * 16
 
 
+# TEST HOOK: callable(shape, p) -> mask tensor (values 0 or 1/(1-p)) used instead of the in-kernel generator
+DROPOUT_MASK_HOOK = [None]
+
 # generation counter bumped by the fused optimizer (it writes weights through raw pointers, which does
 # not touch torch's version counters); part of the packed-weight cache key
 _weight_generation = [0]
@@ -203,9 +206,14 @@ class _Node:
 class ConvNode(_Node):
     """conv (3x3 / dilated / 1x1) [+bias] [+LeakyReLU] [+BatchNorm statistics] over 1 or 2 sources."""
 
-    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None, post_slope: float = 1.0):
+    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None, post_slope: float = 1.0,
+                 drop_p: float = 0.0):
         self.srcs = list(srcs)
         self.conv, self.bn, self.slope = conv, bn, float(slope)
+        # training-mode nn.Dropout between the convolution and its LeakyReLU (blocks.py:68-69): applied after the fused
+        # conv + activation (dropout.hip); the mask is kept for backward
+        self.drop_p = float(drop_p) if tape.training else 0.0
+        self.mask = None
         # activation AFTER the BatchNorm (ResBlock): without a BatchNorm it is simply the epilogue activation
         self.post_slope = float(post_slope)
         if self.post_slope != 1.0 and bn is None:
@@ -235,6 +243,10 @@ class ConvNode(_Node):
         w, b = self.conv.weight, self.conv.bias
         cos, cop = r4(self.cout), r16(self.cout)
         training_bn = self.bn is not None and tape.training
+        drop = self.drop_p > 0.0
+        want_stats = training_bn
+        if drop:
+            training_bn = False                              # the statistics are those of the MASKED tensor (below)
         if self.x_plain is not None:
             x = self.x_plain
             N, _, H, W = x.shape
@@ -275,6 +287,19 @@ class ConvNode(_Node):
                        L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
                        self.slope, _sp(y))
             stat_mode = 0
+        if drop:
+            npix = N * H * W
+            self.rows = L.load().amx_rows_for(npix)
+            self.rows_pix = L.load().amx_rows_pix(npix)
+            stats = _empty((self.rows, 2, cop), y) if want_stats else None
+            self.mask = _empty(y.shape, y)
+            hook = DROPOUT_MASK_HOOK[0]
+            mask_in = hook(tuple(y.shape), self.drop_p).to(y.device).float().contiguous() if hook else None
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: reproducible under manual_seed
+            L.call("amx_dropout_fwd", L.ptr(y), L.ptr(self.mask), L.ptr(mask_in), self.drop_p, seed, L.ptr(stats),
+                   npix, cos, cop, self.rows, self.rows_pix, _sp(y))
+            stat_mode = 1
+            training_bn = want_stats
         scale = shift = None
         if self.bn is not None:
             bn = self.bn
@@ -283,7 +308,7 @@ class ConvNode(_Node):
                 self.save_mean, self.save_invstd = _empty((cos,), y), _empty((cos,), y)
                 mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
                 nrows = self.rows
-                if nrows > 512:          # two-stage merge: coalesced chunk merge first, then per channel
+                if nrows > 512 and not drop:   # two-stage merge: coalesced chunk merge first, then per channel
                     nch = min(1024, nrows // 32)
                     merged = _empty((nch, 3, cop), y)
                     L.call("amx_bn_stats_merge", L.ptr(stats), nrows, cop, stat_mode, N, H, W,
@@ -325,7 +350,7 @@ class ConvNode(_Node):
             L.call("amx_lrelu_bwd", L.ptr(dy), L.ptr(a), L.ptr(out.scale), L.ptr(out.shift), self.post_slope,
                    npix, cos, L.ptr(masked), None, sp)
             dy = masked
-        fused = out.gx is None and bool(FUSE & 4)
+        fused = out.gx is None and bool(FUSE & 4) and self.mask is None
         k = None
         aux = None
         bias_part = None
@@ -360,13 +385,26 @@ class ConvNode(_Node):
             aux, dpre = a, dy                               # transformed on load inside wgrad / dgrad
         elif needs_transform:
             arows = L.load().amx_rows_for(npix)
-            bias_part = _empty((arows, cos), a) if has_bias else None
+            bias_part = _empty((arows, cos), a) if (has_bias and self.mask is None) else None
             dpre = _empty(a.shape, a)
             kk = (L.ptr(k[0]), L.ptr(k[1]), L.ptr(k[2])) if k is not None else (None, None, None)
             L.call("amx_bn_bwd_apply", L.ptr(dy), L.ptr(a), L.ptr(out.gx), *kk, self.slope, npix, cos,
                    L.ptr(dpre), L.ptr(bias_part), sp)
             k = None
+            if self.mask is not None:
+                # d conv = mask * lrelu'(.) * (...): the saved activation is already masked, so the sign test of
+                # bn_bwd_apply is right wherever the mask is non-zero, and the mask zeroes the rest
+                L.call("amx_dropout_bwd", L.ptr(dpre), L.ptr(self.mask), dpre.numel(), sp)
+                if has_bias:                                  # bias gradient = column sums of the masked dpre
+                    nch = 128 if npix >= 1024 else 1
+                    tmp = _empty((nch, cos), a)
+                    L.call("amx_reduce_rows_chunked", L.ptr(dpre), npix, cos, nch, L.ptr(tmp), sp)
+                    db = grad_buffer(self.conv.bias, a)
+                    L.call("amx_reduce_rows", L.ptr(tmp), -(-npix // -(-npix // nch)), cos, self.cout, 1.0, L.ptr(db), sp)
+                    tape.add_param_grad(self.conv.bias, db)
+                    has_bias = False                          # done: neither bias_part nor the wgrad kernel adds it
         else:
+            assert self.mask is None, "dropout without an activation is not a layer of the reference's blocks"
             dpre = dy                                       # linear convolution (1x1 of UpsampleBlock)
         if bias_part is not None:
             db = grad_buffer(self.conv.bias, a)
@@ -817,14 +855,15 @@ class Tape:
     def input(self, x: torch.Tensor) -> InputNode:
         return self._push(InputNode(self, x))
 
-    def conv(self, srcs, conv, bn=None, slope: float = 1.0, post_slope: float = 1.0) -> Act:
-        return self._push(ConvNode(self, srcs, conv, bn, slope, post_slope=post_slope)).out
+    def conv(self, srcs, conv, bn=None, slope: float = 1.0, post_slope: float = 1.0, drop_p: float = 0.0) -> Act:
+        return self._push(ConvNode(self, srcs, conv, bn, slope, post_slope=post_slope, drop_p=drop_p)).out
 
     def res_out(self, t: Act, r: Act, slope: float) -> Act:
         return self._push(ResOutNode(self, t, r, slope)).out
 
-    def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0) -> Act:
-        return self._push(ConvNode(self, [], conv, bn, slope, x_plain=x_plain.detach().contiguous())).out
+    def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0, drop_p: float = 0.0) -> Act:
+        return self._push(ConvNode(self, [], conv, bn, slope, x_plain=x_plain.detach().contiguous(),
+                                   drop_p=drop_p)).out
 
     def pool(self, src: Act) -> Act:
         return self._push(PoolNode(self, src)).out

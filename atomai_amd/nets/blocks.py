@@ -36,9 +36,14 @@ def _layers(seq: nn.Sequential):
 
 
 def _check_dropout(drop, training):
+    """DilatedBlock only: its output sums EVERY sub-layer's output, the Dropout layer's included (blocks.py:321-329)."""
     if drop is not None and drop.p > 0 and training:
-        raise NotImplementedError("training-mode Dropout is not on the MI355X hot path yet "
-                                  "(the reference default is dropout=False)")
+        raise NotImplementedError("training-mode Dropout inside DilatedBlock is not on the MI355X hot path "
+                                  "(ConvBlock's is; the reference default is dropout=False)")
+
+
+def _drop_p(drop) -> float:
+    return float(drop.p) if drop is not None else 0.0
 
 
 class _HipBlock(nn.Module):
@@ -88,8 +93,7 @@ class ConvBlock(_HipBlock):
 
     def _emit(self, tape, srcs):
         for conv, slope, bn, drop in _layers(self.block):
-            _check_dropout(drop, tape.training)
-            srcs = [tape.conv(srcs, conv, bn, slope)]
+            srcs = [tape.conv(srcs, conv, bn, slope, drop_p=_drop_p(drop))]
         return srcs[0]
 
     def _emit_input(self, tape, x):
@@ -99,11 +103,9 @@ class ConvBlock(_HipBlock):
                 and not (x.requires_grad and tape.need_grad))
         if not fast:
             return super()._emit_input(tape, x)
-        _check_dropout(layers[0][3], tape.training)
-        act = tape.conv_first(x, conv0, layers[0][2], layers[0][1])
+        act = tape.conv_first(x, conv0, layers[0][2], layers[0][1], drop_p=_drop_p(layers[0][3]))
         for conv, slope, bn, drop in layers[1:]:
-            _check_dropout(drop, tape.training)
-            act = tape.conv([act], conv, bn, slope)
+            act = tape.conv([act], conv, bn, slope, drop_p=_drop_p(drop))
         return None, act
 
 

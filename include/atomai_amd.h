@@ -162,6 +162,16 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
 
+/* ---- training-mode nn.Dropout of ConvBlock (Conv2d -> Dropout(p) -> LeakyReLU -> BatchNorm2d, atomai/nets/blocks.py:
+ * 59-76): applied AFTER the fused conv + LeakyReLU (LeakyReLU is positively homogeneous, the mask multiplier is >= 0).
+ * amx_dropout_fwd: a *= mask in place ([npix][Cs]), mask (values 0 or 1/(1-p)) kept for backward; mask_in != NULL
+ * replaces the Philox generator (tests); stats != NULL: BatchNorm (sum, M2) rows of the MASKED tensor in the
+ * rows_pix-pixels-per-row layout (amx_bn_finalize mode 1; rows = amx_rows_for(npix), rows_pix = amx_rows_pix(npix)).
+ * amx_dropout_bwd: dpre *= mask in place. */
+int amx_dropout_fwd(float* a, float* mask, const float* mask_in, float p, long seed, float* stats, long npix, int Cs,
+                    int cop, int rows, int rows_pix, void* stream);
+int amx_dropout_bwd(float* dpre, const float* mask, long n, void* stream);
+
 /* ---- on-the-fly augmentation of the resident batch (datatransform.run and its apply_* steps,
  * atomai/transforms/imaug.py:108-358; hook atomai/trainers/trainer.py:339-341).  x / y are [N][H][W] fp32.
  * amx_aug_minmax: out = (min, max) of x (work: 2 * amx_aug_minmax_blocks(n) floats).

@@ -153,3 +153,9 @@ def test_dense_gemm_strides_and_activations():
 def test_dense_layer_autograd():
     import _linear_checks as C
     C.check_linear_autograd("cpu")
+
+
+@pytest.mark.parametrize("bn", [True, False])
+def test_convblock_training_dropout(bn):
+    import _dropout_checks as D
+    D.check_convblock_dropout("cpu", batch_norm=bn)

@@ -187,3 +187,36 @@ def test_config3_dilnet_predict_full_size_vs_oracle_on_device():
     assert C.relmax(out, ref.astype(np.float64)) < C.REL_TOL
     p.chunk_bytes = 64 << 20                                  # one chunk
     assert np.array_equal(p.run(stack, compute_coords=False), out)
+
+
+def test_config3_dilnet_predict_64_frames_properties():
+    """BASELINE.json configs[2] on a 64-frame 1024x1024 stack (the full 4096 frames are the same pipeline repeated):
+    size-independent properties — frames are independent in eval mode (a shuffled stack gives the shuffled output, bit
+    for bit, also across chunk boundaries), the result does not depend on the chunking, every probability lies in
+    [0, 1], and the first frames equal the oracle's eval graph under the GLOBAL min-max normalisation of the stack."""
+    import atomai_amd as aoi
+    from oracle import seg_oracle as so
+    torch.manual_seed(3)
+    net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
+    sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
+    rs = np.random.RandomState(6)
+    stack = rs.rand(64, 1024, 1024).astype(np.float32)
+    stack[17] *= 1.5                                          # the global maximum lives in one frame
+    p = aoi.predictors.SegPredictor(net, use_gpu=True, nb_classes=1, downsampling=2, verbose=False)
+    out = p.run(stack, compute_coords=False)
+    assert out.shape == (64, 1024, 1024, 1)
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and np.isfinite(out).all()
+    perm = rs.permutation(64)
+    assert np.array_equal(p.run(stack[perm], compute_coords=False), out[perm])
+    p.chunk_bytes = 20 << 20                                  # 5 frames per chunk: ragged last chunk
+    assert np.array_equal(p.run(stack, compute_coords=False), out)
+    x = ((stack[:3] - stack.min()) / np.ptp(stack))[:, None]
+    ref = so.predict_probs("dilnet", OrderedDict((k, v.cuda()) for k, v in sd.items()), torch.from_numpy(x).cuda(), 1)
+    assert C.relmax(out[:3], ref.cpu().numpy().astype(np.float64)) < C.REL_TOL
+
+
+@pytest.mark.parametrize("bn", [True, False])
+def test_convblock_training_dropout(bn):
+    import _dropout_checks as D
+    D.check_convblock_dropout("cuda", batch_norm=bn)
+    D.check_convblock_dropout("cuda", N=3, Cin=16, Cout=40, H=70, W=50, p=0.5, batch_norm=bn)
