@@ -247,6 +247,40 @@ class convEncoderNet(nn.Module):
                 self._out(linear(feats, self.fc12.weight, self.fc12.bias)))
 
 
+class convDecoderNet(nn.Module):
+    """Convolutional decoder of the plain VAE (reference: atomai/nets/ed.py:471-527): bias-free Linear(latent ->
+    hidden*H*W) on the MFMA GEMM -> reshape (B, hidden, H, W) -> ConvBlock(num_layers x [3x3 conv -> LeakyReLU(0.1)])
+    -> 1x1 conv to the image channels, the two convolution stages in ONE tape of the HIP engine."""
+
+    def __init__(self, out_dim: Tuple[int], latent_dim: int, num_layers: int = 2, hidden_dim: int = 32,
+                 **kwargs: float) -> None:
+        super().__init__()
+        if len(out_dim) not in (1, 2, 3):
+            raise ValueError("The output dimensions must be (length,) for 1D data and "
+                             "(height, width) or (height, width, channel) for 2D data")
+        if len(out_dim) == 1:
+            raise NotImplementedError("1-D (spectral) decoders are outside the MI355X hot path")
+        from .blocks import ConvBlock
+        c = out_dim[-1] if len(out_dim) > 2 else 1
+        self.fc_linear = nn.Linear(latent_dim, int(hidden_dim * np.prod(out_dim[:2])), bias=False)
+        self.reshape_ = (hidden_dim, *out_dim[:2])
+        self.decoder = ConvBlock(2, num_layers, hidden_dim, hidden_dim, lrelu_a=kwargs.get("lrelu_a", 0.1))
+        self.conv_1x1 = nn.Conv2d(hidden_dim, c, 1, 1, 0)
+        self.out_dim = (c, *out_dim[:2])
+
+    def forward(self, z: torch.Tensor) -> torch.Tensor:
+        from ._function import run_tape
+        h0 = linear(z, self.fc_linear.weight, None).reshape(-1, *self.reshape_)
+
+        def build(tape, xin):
+            node = tape.input(xin)
+            act = self.decoder._emit(tape, [node.out])
+            return node, tape.output(tape.conv([act], self.conv_1x1, None, 1.0))
+        params = list(self.decoder.parameters()) + list(self.conv_1x1.parameters())
+        h = run_tape(build, h0.contiguous(), params, self.training).reshape(-1, *self.out_dim)
+        return h.squeeze(1) if h.size(1) == 1 else h.permute(0, 2, 3, 1)
+
+
 def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_dim: Optional[List] = None,
                   nb_classes: int = 0, **kwargs):
     """Encoder / decoder factory + metadict with the reference's keys (ed.py:725-790)."""
@@ -261,11 +295,9 @@ def init_VAE_nets(in_dim: Tuple[int], latent_dim: int, coord: int = 0, discrete_
     softplus_out = kwargs.get("softplus_out")
     if discrete_dim:
         raise NotImplementedError("joint (discrete) VAEs are outside the MI355X hot path of this build")
-    if conv_d:
-        raise NotImplementedError("convDecoderNet is outside the MI355X hot path (SURVEY.md section 8a lists "
-                                  "the fc/rDecoder and the opt-in conv *encoder* only)")
     if not coord:
-        decoder_net = fcDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d)
+        dnet = convDecoderNet if conv_d else fcDecoderNet
+        decoder_net = dnet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d)
     else:
         decoder_net = rDecoderNet(in_dim, latent_dim + nb_classes, numlayers_d, numhidden_d, skip)
     enc_cls = convEncoderNet if conv_e else fcEncoderNet

@@ -323,6 +323,9 @@ def make_vae_cond(aoi):
         _vae_run(out, rs, "cvae16", lambda: aoi.models.VAE((16, 16), latent_dim=2, nb_classes=3, seed=0,
                                                            numhidden_encoder=32, numhidden_decoder=32),
                  dict(), (16, 16), 6, nb_classes=3)
+        _vae_run(out, rs, "vae12_convdec", lambda: aoi.models.VAE((12, 12), latent_dim=2, seed=0, conv_decoder=True,
+                                                                  numhidden_encoder=32, numhidden_decoder=8),
+                 dict(), (12, 12), 4)
         _vae_run(out, rs, "rvae12_rgb", lambda: aoi.models.rVAE((12, 12, 3), latent_dim=2, seed=0,
                                                                 numhidden_encoder=32, numhidden_decoder=64,
                                                                 numlayers_decoder=4),

@@ -19,6 +19,9 @@ CASES = {
                     file="vae_cond.npz"),
     "cvae16": dict(cls="VAE", ctor=dict(nb_classes=3, numhidden_encoder=32, numhidden_decoder=32), fit=dict(),
                    file="vae_cond.npz"),
+    # plain VAE with the convolutional decoder (Linear -> ConvBlock -> 1x1 conv)
+    "vae12_convdec": dict(cls="VAE", ctor=dict(conv_decoder=True, numhidden_encoder=32, numhidden_decoder=8), fit=dict(),
+                          file="vae_cond.npz", in_dim=(12, 12)),
     # 3-channel patches, 4 hidden layers of 64 units in the spatial decoder
     "rvae12_rgb": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=64, numlayers_decoder=4),
                        fit=dict(), file="vae_cond.npz", in_dim=(12, 12, 3)),
