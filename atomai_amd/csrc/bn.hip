@@ -323,14 +323,17 @@ extern "C" int amx_reduce_rows(const float* part, int rows, int stride, int C, f
 // ------------------------------------------------------------------ stage-1 merges (coalesced, parallel)
 // Merges chunks of (sum, M2) rows into [RB][3][cop] rows (sum, M2 about the chunk mean, count) with Chan's
 // formula in fp64, so that amx_bn_finalize (mode 2) only has to walk RB rows per channel.
+// mode 3: rows of a lattice-mode convolution, [n][ry][rx][strip][tx] over the lat*lat residue-class sub-images
+// (conv_kernel.h); strips of residue classes with a shorter sub-image hold no pixel and are skipped.
 __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ stats, int rows,
                                                             int cop, int mode, int N, int H, int W,
-                                                            int rows_pix, int chunk,
+                                                            int rows_pix, int lat, int chunk,
                                                             float* __restrict__ out) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= cop) return;
-    const int th = (mode == 0 && rows_pix > 0) ? rows_pix : 16;
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + th - 1) / th;
+    const int th = ((mode == 0 || mode == 3) && rows_pix > 0) ? rows_pix : 16;
+    const int d = mode == 3 ? lat : 1;
+    const int tiles_x = ((W + d - 1) / d + 15) / 16, tiles_y = ((H + d - 1) / d + th - 1) / th;
     const long P = (long)N * H * W;
     const int r0 = blockIdx.y * chunk;
     const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
@@ -340,6 +343,14 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
         if (mode == 0) {
             const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
             nr = (double)(min(16, W - tx * 16) * min(th, H - ty * th));
+        } else if (mode == 3) {
+            int q = r;
+            const int tx = q % tiles_x; q /= tiles_x;
+            const int sy = q % tiles_y; q /= tiles_y;
+            const int rx = q % d, ry = (q / d) % d;
+            const int Hs = (H - ry + d - 1) / d, Ws = (W - rx + d - 1) / d;
+            nr = (double)(max(0, min(16, Ws - tx * 16)) * max(0, min(th, Hs - sy * th)));
+            if (nr <= 0.0) continue;
         } else {
             const long left = P - (long)r * rows_pix;
             nr = (double)(left < rows_pix ? left : rows_pix);
@@ -357,11 +368,12 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
 }
 
 extern "C" int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W,
-                                  int rows_pix, int nchunks, float* out, void* stream) {
-    if (!stats || !out || rows <= 0 || cop <= 0 || nchunks <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
+                                  int rows_pix, int lat, int nchunks, float* out, void* stream) {
+    if (!stats || !out || rows <= 0 || cop <= 0 || nchunks <= 0 || (mode != 0 && mode != 1 && mode != 3)) AMX_BADARG(1);
+    if (mode == 3 && (lat < 1 || rows_pix <= 0)) AMX_BADARG(2);
     const int chunk = amx_ceil_div(rows, nchunks);
     AMX_LAUNCH(bn_stats_merge_kernel, dim3(amx_ceil_div(cop, 64), amx_ceil_div(rows, chunk)), dim3(64), 0,
-               (hipStream_t)stream, stats, rows, cop, mode, N, H, W, rows_pix, chunk, out);
+               (hipStream_t)stream, stats, rows, cop, mode, N, H, W, rows_pix, lat, chunk, out);
     AMX_CHECK_LAUNCH();
     return 0;
 }

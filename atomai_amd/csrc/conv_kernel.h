@@ -23,17 +23,24 @@
 //     feeds them to 4 consecutive MFMAs, so each MFMA contracts channels {kk, 4+kk, 8+kk, 12+kk}.
 //   * EXACT: the dilation is a template constant (1, 2, 4, 6 — every dilation the reference's nets use), so the tile
 //     geometry is compile-time: the 9 tap offsets are ds_read immediates instead of ~36 address registers.
-//   * software-pipelined fragments: tap t+1's ds_read_b128s are issued before tap t's MFMAs (AMX_CONV_SWP).
+//   * LAT (lattice mode, dilations 2 / 4 / 6): a 3x3 convolution with dilation d only ever combines pixels of the same
+//     residue class (y mod d, x mod d), i.e. it is d*d independent PLAIN 3x3 convolutions on the sub-images
+//     x[ry::d, rx::d].  A workgroup therefore owns a TH x 16 tile of ONE sub-lattice: its input tile has a halo of one
+//     lattice step instead of d pixels ((TH+2) x 18 slots instead of (TH+2d) x (16+2d): 1.4x instead of 3.1-4.4x
+//     over-fetch at d = 6), the LDS image is that of the plain kernel (3-4 workgroups per CU instead of 1-2) and the
+//     compile-time geometry / launch bounds of the plain classes apply.  NHWC makes the strided gather free: the
+//     unit of a global access is one pixel's 64-byte channel group either way.
 //   * Measured and rejected in round 2 (profiles/r02_conv_persistent_ab.md): persistent workgroups walking several
-//     tiles with cross-tile register prefetch, and weight images kept resident in LDS for <= 2-chunk layers — no
-//     gain over one workgroup per tile (the hardware dispatcher hides workgroup turnover), slower where the resident
-//     weights cost a co-resident workgroup.
+//     tiles with cross-tile register prefetch, weight images kept resident in LDS for <= 2-chunk layers, and operand
+//     fragments software-pipelined across taps (AMX_CONV_SWP) — no gain over one workgroup per tile (the hardware
+//     dispatcher hides workgroup turnover), slower where the extra state costs a co-resident workgroup.
 //   * global->register prefetch of chunk c+1 is issued before the MFMA phase of chunk c; the BN affine and the zero
 //     padding are applied when registers are written to LDS (padding must stay zero AFTER the affine, so it cannot
 //     be folded into the weights).
-//   * epilogue: bias + LeakyReLU on the accumulators, NHWC store (64 B runs per pixel), then a
-//     two-pass (mean, M2) reduction per item: wave shuffles -> LDS -> one partial row per
-//     tile; bn.hip merges the rows with Chan's formula in fp64 (deterministic, no atomics).
+//   * epilogue (per wave, no workgroup barrier): bias + LeakyReLU on the accumulators, (sum, M2 about the wave's own
+//     mean) of the wave's MTW x 16 pixel strip by shuffles -> one partial-statistics row per wave (bn.hip merges the
+//     rows with Chan's formula in fp64: deterministic, no atomics), transpose through a wave-private LDS region,
+//     16-byte NHWC stores (+ optional residual addend).
 #pragma once
 #include "amx_device.h"
 #include <cstdlib>
@@ -107,8 +114,9 @@ struct ConvWaves {
                                      : 1;
 };
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false, int LAT = 0>
 __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
+    static_assert(LAT == 0 || (TAPS == 9 && MAXHALO == 1 && EXACT), "lattice mode runs the plain 3x3 geometry");
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
     constexpr int MAXI = TILE + 2 * MAXHALO;
@@ -136,7 +144,11 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     if (a.xcd) lin = amx_xcd_remap(lin, gridDim.x * gridDim.y);
     int t = a.xcd ? (int)(lin / gridDim.y) : (int)blockIdx.x;
     const int ob = a.xcd ? (int)(lin % gridDim.y) : (int)blockIdx.y;
-    const int tile_id = t;
+    // lattice mode: the d*d residue classes of one tile position are adjacent workgroups (they share cache lines);
+    // all tile coordinates below are then LATTICE coordinates: image (y, x) = (ry + ly*LAT, rx + lx*LAT)
+    constexpr int LS = LAT ? LAT : 1;
+    int ry = 0, rx = 0;
+    if (LAT) { const int rr = t % (LS * LS); t /= (LS * LS); ry = rr / LS; rx = rr - ry * LS; }
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
     const int n0 = ob * NB;                                      // first cout of this workgroup
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         int off = -1;
         if (pix < nslots) {
             const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = gy0 + iy, gx = gx0 + ix;
+            const int gy = ry + (gy0 + iy) * LS, gx = rx + (gx0 + ix) * LS;      // (< 0 exactly when the lattice index is)
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) off = (n * a.H + gy) * a.W + gx;
         }
         x_off[i] = off;
@@ -392,20 +404,23 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             for (int r = 0; r < 4; ++r) {
                 float v = acc[m][q][r] + b;
                 v = v > 0.f ? v : v * a.slope;
-                const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W) && co < ctot;
+                const bool ok = (ry + (oy0 + m) * LS < a.H) && (rx + (ox0 + r) * LS < a.W) && co < ctot;
                 v = ok ? v : 0.f;
                 lsum[q] += v;
                 acc[m][q][r] = v;
             }
     }
     AMX_TICK(12);
-    if (a.stats && oy0 < a.H) {
+    // sub-image extent of this workgroup's residue class (the image itself outside lattice mode)
+    const int Hs = LAT ? (a.H - ry + LS - 1) / LS : a.H, Ws = LAT ? (a.W - rx + LS - 1) / LS : a.W;
+    if (a.stats && oy0 < (LAT ? (a.H + LS - 1) / LS : a.H)) {
         // one statistics row per wave: (sum, M2 about the wave's own mean) over its MTW x 16 pixel strip; the host
         // sees MTW as the "tile height" (amx_conv2d_tile_h) and the merge kernels weight rows by their pixel counts
-        const int vy = min(MTW, a.H - oy0), vx = min(TILE, a.W - tx * TILE);
-        const float inv_cnt = 1.0f / (float)(vy * vx);
-        const int sub_y = ty * 4 + wave, subs_y = amx_ceil_div(a.H, MTW);
-        const size_t row = ((size_t)n * subs_y + sub_y) * a.tiles_x + tx;
+        // (lattice mode: rows [n][ry][rx][strip][tx], strips of residue classes with a shorter sub-image may be empty)
+        const int vy = max(0, min(MTW, Hs - oy0)), vx = max(0, min(TILE, Ws - tx * TILE));
+        const float inv_cnt = vy * vx > 0 ? 1.0f / (float)(vy * vx) : 0.f;
+        const int sub_y = ty * 4 + wave, subs_y = amx_ceil_div(LAT ? (a.H + LS - 1) / LS : a.H, MTW);
+        const size_t row = ((size_t)((n * LS + ry) * LS + rx) * subs_y + sub_y) * a.tiles_x + tx;
         #pragma unroll
         for (int q = 0; q < NT; ++q) {
             float sm = lsum[q];
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             for (int m = 0; m < MTW; ++m)
                 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool ok = (oy0 + m < a.H) && (ox0 + r < a.W);
+                    const bool ok = (oy0 + m < Hs) && (ox0 + r < Ws);
                     const float d = acc[m][q][r] - mu;
                     s2 += ok ? d * d : 0.f;
                 }
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             const int e = it * 64 + lane;
             const int pix = e / CG, cgp = e - pix * CG;
             const int mm = pix / TILE, x = pix - mm * TILE;
-            const int oy = oy0 + m0 + mm, ox = tx * TILE + x;
+            const int oy = ry + (oy0 + m0 + mm) * LS, ox = rx + (tx * TILE + x) * LS;
             const int co = n0 + cgp * 4;
             if (oy < a.H && ox < a.W && co < ctot) {
                 float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
@@ -463,9 +478,9 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     AMX_TICK(13);
 }
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false, int LAT = 0>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
-    const int halo = (TAPS == 9) ? a.dil : 0;
+    const int halo = (TAPS == 9) ? (LAT ? 1 : a.dil) : 0;
     const int I = TILE + 2 * halo;
     const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
     size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
@@ -480,17 +495,17 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
         const int k = atoi(e);
         if (k >= 1 && k <= 8) { const size_t want = (size_t)(160 * 1024 / k) / 256 * 256; if (want > lds) lds = want; }
     }
-    dim3 grid(a.tiles_x * a.tiles_y * a.N, amx_ceil_div(a.cop, NT * 16));
+    dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? LAT * LAT : 1), amx_ceil_div(a.cop, NT * 16));
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL, LAT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL, LAT>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -499,3 +514,6 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
 int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
+int amx_conv_launch_lat2(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);   // lattice mode, dilation 2 / 4 / 6
+int amx_conv_launch_lat4(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
+int amx_conv_launch_lat6(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);

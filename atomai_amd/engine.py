@@ -258,7 +258,7 @@ class ConvNode(_Node):
             L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
                    L.ptr(y), L.ptr(stats), N, H, W, self.cout, cos, self.dil, self.slope, self.rows,
                    self.rows_pix, _sp(x))
-            stat_mode = 1
+            stat_mode, lat = 1, 0
         else:
             s0 = self.srcs[0]
             s1 = self.srcs[1] if len(self.srcs) > 1 else None
@@ -270,8 +270,9 @@ class ConvNode(_Node):
             bias = b.detach() if b is not None else None
             y = _empty((N, H, W, cos), s0.t)
             th = L.load().amx_conv2d_tile_h(C0s + C1s, self.cout, self.taps, self.dil, H)
-            self.rows = L.load().amx_conv2d_num_tiles(N, H, W, th)
-            self.rows_pix = th                               # mode 0: the conv tile height
+            self.rows = L.load().amx_conv2d_stats_rows(C0s + C1s, self.cout, self.taps, self.dil, N, H, W)
+            self.rows_pix = th                               # modes 0 / 3: the rows one wave owns
+            lat = L.load().amx_conv2d_stats_lattice(self.taps, self.dil)
             stats = _empty((self.rows, 2, cop), s0.t) if training_bn else None
             ps0, ps1 = s0.post_slope, (s1.post_slope if s1 else 1.0)
             if ps0 != 1.0 or ps1 != 1.0:
@@ -286,7 +287,7 @@ class ConvNode(_Node):
                        L.ptr(s1.shift if s1 else None), C1s, L.ptr(wpk), L.ptr(bias), None,
                        L.ptr(y), cos, None, 0, L.ptr(stats), N, H, W, self.cout, self.taps, self.dil,
                        self.slope, _sp(y))
-            stat_mode = 0
+            stat_mode = 3 if lat else 0                      # 3: rows ordered by residue class (dilated layers)
         if drop:
             npix = N * H * W
             self.rows = L.load().amx_rows_for(npix)
@@ -308,11 +309,11 @@ class ConvNode(_Node):
                 self.save_mean, self.save_invstd = _empty((cos,), y), _empty((cos,), y)
                 mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
                 nrows = self.rows
-                if nrows > 512 and not drop:   # two-stage merge: coalesced chunk merge first, then per channel
-                    nch = min(1024, nrows // 32)
+                if (nrows > 512 or stat_mode == 3) and not drop:   # two-stage merge: coalesced chunk merge, then per channel
+                    nch = max(1, min(1024, nrows // 32))           # (the only consumer of the lattice row order)
                     merged = _empty((nch, 3, cop), y)
                     L.call("amx_bn_stats_merge", L.ptr(stats), nrows, cop, stat_mode, N, H, W,
-                           self.rows_pix, nch, L.ptr(merged), _sp(y))
+                           self.rows_pix, lat if stat_mode == 3 else 1, nch, L.ptr(merged), _sp(y))
                     stats, nrows, stat_mode = merged, -(-nrows // -(-nrows // nch)), 2
                 L.call("amx_bn_finalize", L.ptr(stats), nrows, cop, stat_mode, N, H, W, self.rows_pix,
                        L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),

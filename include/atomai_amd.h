@@ -32,7 +32,7 @@ int amx_clear_error(void);
  * reading torch.cat([src0, src1], 1) with each source's BN affine applied on load.
  * atomai/nets/blocks.py:61-76 (ConvBlock), :122-132 (UpsampleBlock 1x1), :300-318 (DilatedBlock);
  * atomai/nets/fcnn.py:132-138,223 (cat).  Also the data-gradient engine (weights packed with mode 1):
- * y/y1 are then the gradients w.r.t. src0/src1.  stats: [amx_conv2d_num_tiles][2][round_up(cout,16)], one row
+ * y/y1 are then the gradients w.r.t. src0/src1.  stats: [amx_conv2d_stats_rows][2][round_up(cout,16)], one row
  * (sum, M2) per 16-wide x th-high pixel strip (th = amx_conv2d_tile_h: the rows one wave owns); amx_bn_finalize /
  * amx_bn_stats_merge take th in rows_pix (mode 0).  stats and addend are mutually exclusive. */
 int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
@@ -44,6 +44,11 @@ int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, const float* a
                      int Y1s, int N, int H, int W, int taps, int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
+/* Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images x[ry::d, rx::d]; their
+ * statistics rows are ordered [n][ry][rx][strip][tx].  amx_conv2d_stats_lattice: d for such a layer, else 0;
+ * amx_conv2d_stats_rows: the number of rows amx_conv2d_fwd writes (== amx_conv2d_num_tiles(N,H,W,tile_h) when 0). */
+int amx_conv2d_stats_lattice(int taps, int dil);
+int amx_conv2d_stats_rows(int Cin_s, int cout, int taps, int dil, int N, int H, int W);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d; trainer.py:205 loss.backward()).
  * part: [amx_conv2d_wgrad_rows][taps][round_up(C0s+C1s,16)][round_up(cout,16)] partial rows. */
@@ -133,7 +138,9 @@ int amx_bn_bwd_apply(const float* dy, const float* a, const float* gx, const flo
                      const float* k3, float slope, long npix, int Cs, float* dpre, float* part,
                      void* stream);
 int amx_reduce_rows(const float* part, int rows, int stride, int C, float scale, float* out, void* stream);
-int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix,
+/* mode 0: conv rows [n][strip][tx]; 1: rows of rows_pix consecutive pixels; 3: lattice-mode conv rows
+ * [n][ry][rx][strip][tx] (lat = amx_conv2d_stats_lattice).  out: [nchunks][3][cop] (sum, M2, count) = finalize mode 2. */
+int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix, int lat,
                        int nchunks, float* out, void* stream);
 int amx_reduce_rows_chunked(const float* part, int rows, long ncols, int nchunks, float* out, void* stream);
 

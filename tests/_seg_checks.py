@@ -151,6 +151,46 @@ def check_blocks(device):
                 assert e <= max(4 * e32, 5e-5), (name, mode, k, e, e32)
 
 
+def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1)), lattice=None):
+    """Dilations 2 / 4 / 6 on image sizes that are multiples of neither the dilation nor the tile (ragged residue
+    classes: sub-images of different sizes, empty statistics strips), channel counts with a partial last chunk;
+    forward, BatchNorm statistics, data and weight gradients against the same layers in stock torch fp64."""
+    import copy
+    import torch.nn as nn
+    from atomai_amd.nets import DilatedBlock
+    for cin, cout, H, W, N, *rest in cases:
+        # a case may name its LeakyReLU slope: with ~1e6 pre-activations per layer a few land within fp32 rounding of
+        # the kink and take the other branch than the fp64 graph does (expected count ~ 0.8e-6 per element); slope 1.0
+        # keeps the large-geometry cases a pure index / layout check
+        slope = rest[0] if rest else 0.01
+        torch.manual_seed(H)
+        m = DilatedBlock(2, cin, cout, [2, 4, 6], [2, 4, 6], batch_norm=True, lrelu_a=slope)
+        ref_layers = [copy.deepcopy(l).double() for l in m.atrous_module]
+        m.to(device)
+        x = torch.randn(N, cin, H, W)
+        x1 = x.clone().to(device).requires_grad_(True)
+        x2 = x.double().clone().requires_grad_(True)
+        y = m(x1)
+        h, outs = x2, []
+        for l in ref_layers:
+            h = l(h)
+            outs.append(h)                   # the block returns the sum of EVERY sub-layer's output (blocks.py:321-329)
+        yr = sum(outs)
+        gy = torch.randn(N, cout, H, W)
+        y.backward(gy.to(device))
+        yr.backward(gy.double())
+        assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-4, (cin, cout, H, W)
+        assert float((x1.grad.cpu().double() - x2.grad).abs().max() / x2.grad.abs().max()) < 1e-4
+        ref_params = [p for l in ref_layers for p in l.parameters()]
+        for (k, p), p2 in zip(m.atrous_module.named_parameters(), ref_params):
+            assert float((p.grad.cpu().double() - p2.grad).abs().max() / p2.grad.abs().max()) < 1e-4, k
+        ref_bn = [l for l in ref_layers if isinstance(l, nn.BatchNorm2d)]
+        our_bn = [l for l in m.atrous_module if isinstance(l, nn.BatchNorm2d)]
+        for a, b in zip(our_bn, ref_bn):
+            np.testing.assert_allclose(a.running_var.cpu().numpy(), b.running_var.numpy(), rtol=1e-5)
+            np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.numpy(), rtol=1e-4, atol=1e-6)
+
+
 def check_predict(device_is_gpu):
     import atomai_amd as aoi
     from atomai_amd.utils import img_pad, torch_format_image

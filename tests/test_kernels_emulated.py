@@ -37,7 +37,7 @@ def test_two_stage_bn_statistics_equal_single_stage():
         if two_stage:
             nch = 5
             merged = torch.empty(nch, 3, cop)
-            L.call("amx_bn_stats_merge", L.ptr(stats), rows, cop, 0, N, H, W, 0, nch, L.ptr(merged), None)
+            L.call("amx_bn_stats_merge", L.ptr(stats), rows, cop, 0, N, H, W, 0, 1, nch, L.ptr(merged), None)
             st, rows, mode = merged, -(-rows // -(-rows // nch)), 2
         L.call("amx_bn_finalize", L.ptr(st), rows, cop, mode, N, H, W, 0, L.ptr(g), L.ptr(b), L.ptr(rm),
                L.ptr(rv), 0.1, 1e-5, C, cs, L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(iv), None)

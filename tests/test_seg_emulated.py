@@ -140,3 +140,13 @@ def test_trainer_options(tmp_path, opts):
         assert m.optimizer.param_groups[0]["lr"] == 1e-4
     if opts.get("swa"):      # the last 5 epochs are averaged (like the reference, SWA needs >= 5 epochs / 30 iterations)
         assert sorted(m.running_weights) == [0, 1, 2, 3, 4]
+
+
+def test_dilated_layers_on_ragged_sizes():
+    C.check_dilated_ragged("cpu")
+
+
+def test_dilated_layers_halo_class_kernels_still_agree(monkeypatch):
+    """AMX_CONV_LATTICE=0 keeps the halo-class kernels of conv_fwd_dil.hip reachable (in-process A/B switch)."""
+    monkeypatch.setenv("AMX_CONV_LATTICE", "0")
+    C.check_dilated_ragged("cpu", cases=((16, 20, 23, 41, 1),))

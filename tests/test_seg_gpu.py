@@ -33,6 +33,10 @@ def test_blocks():
     C.check_blocks("cuda")
 
 
+def test_dilated_layers_on_ragged_sizes():
+    C.check_dilated_ragged("cuda", cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1), (52, 50, 131, 70, 3, 1.0)))
+
+
 def test_predictor():
     C.check_predict(True)
 

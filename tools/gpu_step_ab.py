@@ -35,6 +35,12 @@ dn, _ = aoi.nets.init_fcnn_model("dilnet", 1)
 dn = dn.cuda().eval()
 xf = torch.from_numpy(rs.rand(8, 1, 1024, 1024).astype(np.float32)).cuda()
 res = {json.dumps(v): {"unet_ms": [], "dilnet_ms_per_frame": []} for v in variants}
+ref_out = None
+for v in variants:                      # the variants must agree on the full-size dilnet output
+    setenv(v)
+    o = predict_proba(dn, xf[:2]).float()
+    if ref_out is None: ref_out = o
+    res[json.dumps(v)]["dilnet_max_abs_diff_vs_first"] = float((o - ref_out).abs().max())
 for rep in range(3):
     for v in variants:
         setenv(v)
@@ -50,6 +56,7 @@ for rep in range(3):
         res[json.dumps(v)]["dilnet_ms_per_frame"].append((time.perf_counter() - t0) / 4 / 8 * 1e3)
 for k, v in res.items():
     print(f"{k:60s} unet step {min(v['unet_ms']):7.3f} ms ({['%.2f' % t for t in v['unet_ms']]})   "
-          f"dilnet {min(v['dilnet_ms_per_frame']):6.3f} ms/frame = {91.62e9 / min(v['dilnet_ms_per_frame']) / 1e9:5.1f} TF", flush=True)
+          f"dilnet {min(v['dilnet_ms_per_frame']):6.3f} ms/frame = {91.62e9 / min(v['dilnet_ms_per_frame']) / 1e9:5.1f} TF"
+          f"  (max |out - first variant| {v['dilnet_max_abs_diff_vs_first']:.1e})", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/r02_step_ab.json", "w"), indent=1)
