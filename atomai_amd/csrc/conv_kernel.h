@@ -80,8 +80,7 @@ struct ConvFwdArgs {
 };
 
 // TAIL: compiled-in support for a partial last chunk (compute_tail).  It is a separate instantiation because the
-// extra unrolled tap loop costs registers — 108+16 -> 128+32 VGPR/AGPR, i.e. 4 -> 3 waves per SIMD — which slowed
-// every layer by ~10 %, including the ones (all channel counts multiples of 16) that never take that path.
+// extra unrolled tap loop costs code and registers that the layers with channel counts in multiples of 16 need not pay.
 //
 // Compile-time experiment switches (tools/build_variant_lib.sh builds one library per combination for in-process A/B):
 //   AMX_CONV_SWP    1: operand fragments of tap t+1 are read into a second register set before tap t's MFMAs
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         }
     };
 
-    auto stage_to_lds = [&](int stage) {
+    auto stage_to_lds = [&](int stage, bool tchunk) {
         float* s_in = smem + (size_t)stage * stage_floats;
         float* s_w = s_in + KG * plane * 4;
         #pragma unroll
@@ -239,7 +238,18 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                         v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
                     }
                 }
-                amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
+                if (TAIL && tchunk) {
+                    // partial last chunk: stored transposed — plane e holds channel e of every k-group, this thread's
+                    // k-group in component my_kg (the weight image of that chunk is packed the same way, pack.hip)
+                    if (my_kg < a.tail_kg) {
+                        s_in[((size_t)0 * plane + pix) * 4 + my_kg] = v.x;
+                        s_in[((size_t)1 * plane + pix) * 4 + my_kg] = v.y;
+                        s_in[((size_t)2 * plane + pix) * 4 + my_kg] = v.z;
+                        s_in[((size_t)3 * plane + pix) * 4 + my_kg] = v.w;
+                    }
+                } else {
+                    amx_st4(s_in + ((size_t)my_kg * plane + pix) * 4, v);
+                }
             }
         }
 #ifdef AMX_CONV_NOWLOAD
@@ -328,8 +338,10 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
 #endif
 
     // Last chunk with fewer than KG valid k-groups (channel counts that are not multiples of 16, e.g. dilnet's
-    // 25 / 50 filters -> 28 / 52 stored channels): one MFMA per valid k-group and tap instead of four, with the
-    // k index of the MFMA running over the 4 channels of ONE k-group (scalar ds_read_b32, lane g = channel g).
+    // 25 / 50 filters -> 28 / 52 stored channels).  That chunk sits TRANSPOSED in LDS (stage_to_lds / pack.hip): the
+    // ordinary fragment read returns channel g of k-groups 0..3 in components x..w, so one MFMA per VALID k-group
+    // contracts that group's 4 channels — nkg MFMAs per tap and tile instead of four, with the fragment-read code
+    // (and its registers) of the main path.
     auto compute_tail = [&](int nkg) {
         const float* s_in = smem;
         const float* s_w = s_in + KG * plane * 4;
@@ -337,24 +349,23 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         for (int tap = 0; tap < TAPS; ++tap) {
             const int dy = (TAPS == 9) ? (tap / 3 - 1) * halo : 0;
             const int dx = (TAPS == 9) ? (tap % 3 - 1) * halo : 0;
+            float4 af[MTW], bf[NT];
             #pragma unroll
-            for (int j = 0; j < KG - 1; ++j) {
-                if (j >= nkg) break;
-                float af[MTW], bf[NT];
-                #pragma unroll
-                for (int m = 0; m < MTW; ++m) {
-                    const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
-                    af[m] = s_in[((size_t)j * plane + slot) * 4 + g];
-                }
-                #pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    bf[q] = s_w[((size_t)(tap * KG + j) * NB + q * 16 + p) * 4 + g];
-                #pragma unroll
-                for (int m = 0; m < MTW; ++m)
-                    #pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[q], acc[m][q], 0, 0, 0);
+            for (int m = 0; m < MTW; ++m) {
+                const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
+                af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
             }
+            #pragma unroll
+            for (int q = 0; q < NT; ++q)
+                bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+            #define AMX_CONV_MFMA(C)                                                                    \
+                _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
+                    _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
+            AMX_CONV_MFMA(x)
+            if (nkg > 1) { AMX_CONV_MFMA(y) }
+            if (nkg > 2) { AMX_CONV_MFMA(z) }
+            #undef AMX_CONV_MFMA
         }
     };
 
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     issue_loads(0);
     AMX_TICK(1);
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-        stage_to_lds(0);
+        stage_to_lds(0, TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG);
         if (chunk < 2) AMX_TICK(2 + 5 * chunk);
         __syncthreads();
         if (chunk < 2) AMX_TICK(3 + 5 * chunk);

@@ -7,11 +7,16 @@
 //   mode 0 (forward):  k runs over the concatenated, 4-padded input channels of (src0|src1), n = cout
 //   mode 1 (dgrad):    k runs over cout, n runs over the concatenated padded input channels, taps are
 //                      spatially flipped (tap -> taps-1-tap)  [dX = conv(dY, flip(W)^T)]
+// A PARTIAL last chunk (k space not a multiple of 16: fewer than 4 valid k-groups) is stored with the roles of k-group
+// and channel-in-group swapped: slot [kg'][n][e'] holds channel (4*e' + kg') of the chunk.  The convolution kernel
+// stages the matching input chunk the same way, so its ordinary fragment read (lane group g reads [g][..][0..3])
+// returns channel g of k-groups 0..3 in components x..w, and only the components of VALID k-groups are issued as
+// MFMAs (conv_kernel.h, TAIL).
 #include "amx_device.h"
 
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ dst,
                                     int cout, int cin, int C0, int C0s, int C1, int C1s, int taps,
-                                    int mode, int nop, int total) {
+                                    int mode, int nop, int total, int tchunk) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     int t = idx;
@@ -19,7 +24,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int n = t % nop; t /= nop;
     const int kg = t & 3; t >>= 2;
     const int tap = t % taps; const int chunk = t / taps;
-    const int k = (chunk * 4 + kg) * 4 + e;
+    // a PARTIAL last chunk is stored transposed (kgroup <-> channel-in-group), see the file header
+    const int k = chunk == tchunk ? (chunk * 4 + e) * 4 + kg : (chunk * 4 + kg) * 4 + e;
     // map an index of the concatenated padded channel space to a real input channel (or -1)
     auto cat2ci = [&](int c) -> int {
         if (c < C0s) return c < C0 ? c : -1;
@@ -45,7 +51,8 @@ extern "C" int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C
     const int nop = amx_round_up(nspace, 16);
     const int total = nchunk * taps * 4 * nop * 4;
     AMX_LAUNCH(pack_weights_kernel, dim3(amx_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-               w_oihw, dst, cout, C0 + C1, C0, C0s, C1, C1s, taps, mode, nop, total);
+               w_oihw, dst, cout, C0 + C1, C0, C0s, C1, C1s, taps, mode, nop, total,
+               (kspace & 15) ? nchunk - 1 : -1);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -53,7 +60,7 @@ extern "C" int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C
 // Every layer's image in one launch (blockIdx.y = job): the per-layer launches sat between the convolutions of the
 // forward / backward chains, 30 five-microsecond kernels per training step.
 #define PACK_BATCH 8
-struct PackJob { const float* w; float* dst; int cout, cin, C0, C0s, C1, C1s, taps, mode, nop, total; };
+struct PackJob { const float* w; float* dst; int cout, cin, C0, C0s, C1, C1s, taps, mode, nop, total, tchunk; };
 struct PackBatch { PackJob j[PACK_BATCH]; };
 
 __global__ void pack_weights_batch_kernel(PackBatch b) {
@@ -64,7 +71,7 @@ __global__ void pack_weights_batch_kernel(PackBatch b) {
         const int n = t % J.nop; t /= J.nop;
         const int kg = t & 3; t >>= 2;
         const int tap = t % J.taps; const int chunk = t / J.taps;
-        const int k = (chunk * 4 + kg) * 4 + e;
+        const int k = chunk == J.tchunk ? (chunk * 4 + e) * 4 + kg : (chunk * 4 + kg) * 4 + e;
         auto cat2ci = [&](int c) -> int {
             if (c < J.C0s) return c < J.C0 ? c : -1;
             c -= J.C0s;
@@ -99,6 +106,7 @@ extern "C" int amx_pack_weights_batch(const void* const* w, void* const* dst, co
             J.cout = cout; J.cin = C0 + C1; J.C0 = C0; J.C0s = C0s; J.C1 = C1; J.C1s = C1s; J.taps = taps; J.mode = mode;
             J.nop = amx_round_up(nspace, 16);
             J.total = amx_ceil_div(kspace, 16) * taps * 4 * J.nop * 4;
+            J.tchunk = (kspace & 15) ? amx_ceil_div(kspace, 16) - 1 : -1;
             if (J.total > maxtotal) maxtotal = J.total;
         }
         int gx = amx_ceil_div(maxtotal, 256);
