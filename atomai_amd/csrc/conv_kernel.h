@@ -108,7 +108,7 @@ struct ConvFwdArgs {
 // handful of registers above the next allocation step: the bound makes the allocator take the step.
 template <int TAPS, int NT, int MAXHALO, int MTW, bool TAIL>
 struct ConvWaves {
-    static constexpr int value = (TAPS == 9 && MAXHALO == 1 && !TAIL)
+    static constexpr int value = (TAPS == 9 && MAXHALO == 1)
                                      ? ((MTW == 2 && NT <= 2) ? 4 : ((MTW == 4 && NT == 1) ? 3 : 1))
                                      : 1;
 };
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
 
     // the bias is fetched up front: a global load at the head of the epilogue would expose a full memory round trip
     // (not for the widest tile: 4 more live registers would push it past 256 = one workgroup per CU instead of two)
-    constexpr bool PREB = !(NT == 4 && MTW == 4);
+    constexpr bool PREB = !(NT == 4 && MTW == 4) && !TAIL;      // (TAIL classes: the registers buy a 4th wave per SIMD)
     float bias_q[NT];
     #pragma unroll
     for (int q = 0; q < NT; ++q) {

@@ -4,6 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 REV=${1:-b022c40}
+NAME=${2:-ref}            # atomai_amd/lib/libatomai_amd_<NAME>.so (the revision must have the product library's ABI)
 D=/tmp/amx_ref_$REV
 rm -rf $D; mkdir -p $D/csrc $D/include $D/obj
 for f in $(git ls-tree --name-only $REV atomai_amd/csrc/); do git show $REV:$f > $D/csrc/$(basename $f); done
@@ -12,5 +13,5 @@ for s in $D/csrc/*.hip; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-pass-failed -I $D/csrc -I $D/include -c $s -o $D/obj/$(basename $s .hip).o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -o atomai_amd/lib/libatomai_amd_ref.so $D/obj/*.o
-echo built atomai_amd/lib/libatomai_amd_ref.so from $REV
+hipcc --offload-arch=gfx950 -shared -o atomai_amd/lib/libatomai_amd_$NAME.so $D/obj/*.o
+echo built atomai_amd/lib/libatomai_amd_$NAME.so from $REV
