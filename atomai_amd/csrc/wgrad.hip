@@ -27,6 +27,7 @@ struct WgradArgs {
     const float* k1; const float* k2; const float* k3; float bslope;
     float* bpart;                    // [ksplit][co_pad] per-workgroup sums of dpre (bias gradient) or nullptr
     float* part;                     // [rows][taps][ci_pad][co_pad]
+    unsigned long long* prof;        // dev builds: per-wave phase clocks (or nullptr)
     int N, H, W, dil;
     int ci_pad, co_pad;              // multiples of 16
     int WN, WK;                      // wave grid (WM is a template parameter)
@@ -34,6 +35,16 @@ struct WgradArgs {
     int co_blocks;
 };
 
+// AMX_WGRAD_PROFILE (dev builds only, tools/gpu_wgrad_phases.py): every wave accumulates the shader clocks it spends in
+// each phase of its tile loop and writes [workgroup][wave][8] 64-bit totals (stage, barrier, issue, mfma, barrier, tail,
+// tiles, lifetime) to the buffer set through amx_wgrad_set_profile_buffer.
+#ifdef AMX_WGRAD_PROFILE
+static void* amx_wgrad_profile_buffer = nullptr;
+extern "C" int amx_wgrad_set_profile_buffer(void* buf) { amx_wgrad_profile_buffer = buf; return 0; }
+#define WG_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt[i] += n_ - pl; pl = n_; } while (0)
+#else
+#define WG_TICK(i) do { } while (0)
+#endif
 #ifndef AMX_WGRAD_EXACT
 #define AMX_WGRAD_EXACT 1        // compile-time experiment switch (tools/build_variant_lib.sh): 0 = runtime halo as in round 1
 #endif
@@ -180,11 +191,20 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
 
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
     int tile = blockIdx.x;
+#ifdef AMX_WGRAD_PROFILE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pl = __builtin_amdgcn_s_memtime();
+    const unsigned long long pstart = pl;
+#endif
     if (tile < ntiles) issue(tile);
     for (; tile < ntiles; tile += a.ksplit) {
+        WG_TICK(2);
         stage();
+        WG_TICK(0);
         __syncthreads();
+        WG_TICK(1);
         if (tile + a.ksplit < ntiles) issue(tile + a.ksplit);
+        WG_TICK(2);
         for (int r = wk; r < TH; r += a.WK) {
             #pragma unroll
             for (int kx = 0; kx < TW / 4; ++kx) {
@@ -203,7 +223,12 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
                 }
             }
         }
+        WG_TICK(3);
         __syncthreads();
+        WG_TICK(4);
+#ifdef AMX_WGRAD_PROFILE
+        pt[6] += 1;
+#endif
     }
 
     if (a.bpart && cb == 0) {
@@ -234,6 +259,12 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
                     a.part[((row * TAPS + t) * a.ci_pad + ci) * a.co_pad + co] = acc[t][q][r];
             }
         }
+#ifdef AMX_WGRAD_PROFILE
+    WG_TICK(5);
+    pt[7] = pl - pstart;
+    if (a.prof && lane == 0)
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + i] = pt[i];
+#endif
 }
 
 template <int TAPS, int NT, int WM, int MAXHALO, int TH>
@@ -362,6 +393,10 @@ static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int
     a.x1 = x1; a.sc1 = sc1; a.sh1 = sh1; a.C1s = C1s;
     a.in_slope0 = in_slope0; a.in_slope1 = in_slope1;
     a.dpre = dpre; a.Dos = Dos; a.part = part;
+    a.prof = nullptr;
+#ifdef AMX_WGRAD_PROFILE
+    a.prof = (unsigned long long*)amx_wgrad_profile_buffer;
+#endif
     a.aux = aux; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.bslope = bslope; a.bpart = bpart;
     a.N = N; a.H = H; a.W = W; a.dil = dil;
     a.ci_pad = pl.ci_pad; a.co_pad = pl.co_pad;

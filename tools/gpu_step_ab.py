@@ -24,6 +24,8 @@ def setenv(v):
     if name not in _libs:
         _libs[name] = _lib._bind(ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libatomai_amd_{name}.so")))
     _lib._lib = _libs[name]
+    from atomai_amd import engine
+    engine._pack_cache.store.clear()      # weight images are library-specific (layout of a partial last K chunk)
 
 
 rs = np.random.RandomState(0)
