@@ -101,39 +101,60 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
     float4 bsum = make_float4(0, 0, 0, 0);   // bias-gradient partial of this thread's channel group (ci-block 0)
     long d_off[DLD_MAX];                     // element offsets of the dy values held in dr (or -1)
 
-    auto issue = [&](int tile) {
-        int t = tile;
-        const int tx = t % a.tiles_x; t /= a.tiles_x;
-        const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
+    // Tile-independent load descriptors.  One workgroup walks ntiles / ksplit tiles with ONE wave per SIMD, so every
+    // instruction of the loaders is exposed (tools/gpu_wgrad_phases.py: issuing 9 loads cost 2400 clocks per tile when
+    // the slot -> pixel index math was redone per tile).  Per tile remain: two bases, and per load an add and the
+    // bounds compares.
+    int x_rel[XLD], x_yx[XLD];               // element offset of the slot relative to the tile origin; (iy << 8) | ix or -1
+    #pragma unroll
+    for (int i = 0; i < XLD; ++i) {
+        const int pix = (tid + i * 256) / CG;
+        x_yx[i] = -1; x_rel[i] = 0;
+        if (pix < npix_x && xsrc) {
+            const int iy = pix / IW, ix = pix - iy * IW;
+            x_yx[i] = (iy << 8) | ix;
+            x_rel[i] = (iy * a.W + ix) * xCs + xc;
+        }
+    }
+    int d_rel[DLD_MAX], d_yx[DLD_MAX];
+    #pragma unroll
+    for (int i = 0; i < DLD_MAX; ++i) {
+        const int idx = tid + i * 256;
+        d_yx[i] = -1; d_rel[i] = 0;
+        if (idx < nd4) {
+            const int pix = idx >> dg_shift, dg = idx & (DG - 1);
+            const int iy = pix / TW, ix = pix - iy * TW;
+            const int c = co0 + dg * 4;
+            if (c < a.Dos) { d_yx[i] = (iy << 8) | ix; d_rel[i] = (iy * a.W + ix) * a.Dos + c; }
+        }
+    }
+
+    auto issue = [&](int n, int ty, int tx) {
         const int gy0 = ty * TH - halo, gx0 = tx * TW - halo;
+        const long xbase = ((long)(n * a.H + gy0) * a.W + gx0) * xCs;      // (may be negative: halo rows of image 0)
         xvalid = 0;
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
-            const int pix = (tid + i * 256) / CG;
             xr[i] = make_float4(0, 0, 0, 0);
-            if (pix < npix_x && xsrc) {
-                const int iy = pix / IW, ix = pix - iy * IW;
-                const int gy = gy0 + iy, gx = gx0 + ix;
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    xr[i] = amx_ld4(xsrc + ((size_t)(n * a.H + gy) * a.W + gx) * xCs + xc);
+            if (x_yx[i] >= 0) {
+                const int gy = gy0 + (x_yx[i] >> 8), gx = gx0 + (x_yx[i] & 255);
+                if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+                    xr[i] = amx_ld4(xsrc + (xbase + x_rel[i]));
                     xvalid |= 1u << i;
                 }
             }
         }
+        const long dbase = ((long)(n * a.H + ty * TH) * a.W + tx * TW) * a.Dos;
         #pragma unroll
         for (int i = 0; i < DLD_MAX; ++i) {
-            const int idx = tid + i * 256;
             dr[i] = make_float4(0, 0, 0, 0);
             d_off[i] = -1;
-            if (idx < nd4) {
-                const int pix = idx >> dg_shift, dg = idx & (DG - 1);
-                const int iy = pix / TW, ix = pix - iy * TW;
-                const int gy = ty * TH + iy, gx = tx * TW + ix;
-                const int c = co0 + dg * 4;
-                if (gy < a.H && gx < a.W && c < a.Dos) {
-                    const size_t o = ((size_t)(n * a.H + gy) * a.W + gx) * a.Dos + c;
+            if (d_yx[i] >= 0) {
+                const int gy = ty * TH + (d_yx[i] >> 8), gx = tx * TW + (d_yx[i] & 255);
+                if (gy < a.H && gx < a.W) {
+                    const long o = dbase + d_rel[i];
                     dr[i] = amx_ld4(a.dpre + o);
-                    d_off[i] = (long)o;
+                    d_off[i] = o;
                 }
             }
         }
@@ -191,19 +212,28 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
 
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
     int tile = blockIdx.x;
+    // (tx, ty, n) of this workgroup's current tile, advanced by the split-K stride with carries (no division per tile)
+    const int tpi = a.tiles_x * a.tiles_y;
+    int ttx = tile % a.tiles_x, tty = (tile / a.tiles_x) % a.tiles_y, ttn = tile / tpi;
+    const int stx = a.ksplit % a.tiles_x, sty = (a.ksplit / a.tiles_x) % a.tiles_y, stn = a.ksplit / tpi;
 #ifdef AMX_WGRAD_PROFILE
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pl = __builtin_amdgcn_s_memtime();
     const unsigned long long pstart = pl;
 #endif
-    if (tile < ntiles) issue(tile);
+    if (tile < ntiles) issue(ttn, tty, ttx);
     for (; tile < ntiles; tile += a.ksplit) {
         WG_TICK(2);
         stage();
         WG_TICK(0);
         __syncthreads();
         WG_TICK(1);
-        if (tile + a.ksplit < ntiles) issue(tile + a.ksplit);
+        if (tile + a.ksplit < ntiles) {
+            ttx += stx; int carry = ttx >= a.tiles_x ? 1 : 0; ttx -= carry ? a.tiles_x : 0;
+            tty += sty + carry; carry = tty >= a.tiles_y ? 1 : 0; tty -= carry ? a.tiles_y : 0;
+            ttn += stn + carry;
+            issue(ttn, tty, ttx);
+        }
         WG_TICK(2);
         for (int r = wk; r < TH; r += a.WK) {
             #pragma unroll
