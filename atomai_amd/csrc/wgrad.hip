@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
             issue(ttn, tty, ttx);
         }
         WG_TICK(2);
+        // (Rejected, round 2: rows of this sweep unrolled 1 / 2 / 4-fold with a compile-time trip count — stand-alone
+        // +3..5 % on the >= 64-channel classes, but 30-60 more registers per wave, and inside the training step, where
+        // these waves share the SIMDs with the data-gradient kernels, 19.35 -> 19.95 / 20.05 / 20.55 ms.)
         for (int r = wk; r < TH; r += a.WK) {
             #pragma unroll
             for (int kx = 0; kx < TW / 4; ++kx) {
