@@ -107,3 +107,8 @@ static inline int amx_num_cus() {
 }
 static __host__ __device__ __forceinline__ int amx_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static __host__ __device__ __forceinline__ int amx_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images (conv_kernel.h, wgrad_kernel.h);
+// AMX_CONV_LATTICE=0 selects the halo-class kernels instead (defined in conv_fwd.hip).
+bool amx_lattice_mode(int taps, int dil);
+

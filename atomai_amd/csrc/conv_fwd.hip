@@ -17,7 +17,7 @@ struct ConvPlan { int nt, th; };
 // Dilations 2 / 4 / 6 (every dilation the reference's nets use, fcnn.py:186-200) run in lattice mode: d*d plain 3x3
 // convolutions on the residue-class sub-images (conv_kernel.h).  AMX_CONV_LATTICE=0 selects the round-1 halo-class
 // kernels of conv_fwd_dil.hip instead (in-process A/B; dilations 3 and 5 always use those).
-static bool lattice_mode(int taps, int dil) {
+bool amx_lattice_mode(int taps, int dil) {
     if (taps != 9 || (dil != 2 && dil != 4 && dil != 6)) return false;
     const char* e = getenv("AMX_CONV_LATTICE");
     return !e || atoi(e) != 0;
@@ -27,7 +27,7 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
     ConvPlan pl;
     const int cop = amx_round_up(cout, 16);
     const int nchunk = amx_ceil_div(Cin_s, 4 * KG);
-    const bool small = taps == 9 && (dil == 1 || lattice_mode(taps, dil));   // 8-row tiles exist for the plain geometry
+    const bool small = taps == 9 && (dil == 1 || amx_lattice_mode(taps, dil));   // 8-row tiles exist for the plain geometry
     if (cop <= 16) { pl.nt = 1; pl.th = 16; }
     else if (cop >= 64 && (nchunk >= 8 || !small)) { pl.nt = 4; pl.th = 16; }
     else { pl.nt = 2; pl.th = small ? 8 : 16; }
@@ -78,7 +78,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.th = pl.th;
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     const bool tail = a.tail_kg < KG;                       // partial last chunk: cheaper tail path
-    if (lattice_mode(taps, dil)) {                          // tiles of the (largest) residue-class sub-image
+    if (amx_lattice_mode(taps, dil)) {                          // tiles of the (largest) residue-class sub-image
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);
         a.dil = 1;
@@ -136,9 +136,9 @@ extern "C" int amx_conv2d_num_tiles(int N, int H, int W, int th) {
 // Layout of the partial-statistics rows amx_conv2d_fwd writes for this layer: the dilation d if the rows are ordered
 // [n][ry][rx][strip][tx] over the d*d residue-class sub-images (amx_bn_stats_merge mode 3), 0 for the plain
 // [n][strip][tx] order (mode 0); and the number of rows.
-extern "C" int amx_conv2d_stats_lattice(int taps, int dil) { return lattice_mode(taps, dil) ? dil : 0; }
+extern "C" int amx_conv2d_stats_lattice(int taps, int dil) { return amx_lattice_mode(taps, dil) ? dil : 0; }
 extern "C" int amx_conv2d_stats_rows(int Cin_s, int cout, int taps, int dil, int N, int H, int W) {
     const int th = plan_conv(Cin_s, cout, taps, dil, H).th / 4;
-    if (!lattice_mode(taps, dil)) return amx_ceil_div(W, TILE) * amx_ceil_div(H, th) * N;
+    if (!amx_lattice_mode(taps, dil)) return amx_ceil_div(W, TILE) * amx_ceil_div(H, th) * N;
     return amx_ceil_div(amx_ceil_div(W, dil), TILE) * amx_ceil_div(amx_ceil_div(H, dil), th) * dil * dil * N;
 }
