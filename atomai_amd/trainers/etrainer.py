@@ -2,8 +2,13 @@
 
 Same orchestration (train_baseline / train_ensemble_from_scratch / train_ensemble_from_baseline / train_swag),
 attribute names and ``*_ensemble_metadict.tar`` format; every member trains on the HIP engine through
-``BaseTrainer``.  Only the segmentation families are in scope ('imspec' raises).  Members are independent, so on a
-multi-GPU node each rank can train its own slice of the ensemble (``member_range``) with no collective at all.
+``BaseTrainer``.  Only the segmentation families are in scope ('imspec' raises).
+
+Multi-GPU (no counterpart in the reference): members are independent training runs, so under an
+initialised process group ``distributed=True`` gives rank r the members r, r + world, ... on its own GPU — no
+collective on the training path (and no gradient all-reduce: every member sees the full batch) — and ONE
+``all_gather_object`` of the finished members' CPU state dicts at the end, so that every rank returns the complete
+ensemble; rank 0 writes the metadict.  ``member_range`` selects an explicit slice instead.
 """
 import warnings
 from copy import deepcopy as dc
@@ -11,6 +16,7 @@ from typing import Callable, Dict, Tuple, Type, Union
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from ..nets import init_fcnn_model
 from ..utils import (average_weights, check_image_dims, num_classes_from_labels, sample_weights)
@@ -26,6 +32,33 @@ class BaseEnsembleTrainer(BaseTrainer):
             self.set_model(model, nb_classes)
         self.ensemble_state_dict = {}
         self.kdict = {}
+        self._ens_rank = 0                                   # rank inside a sharded ensemble run (0 writes the file)
+
+    # ------------------------------------------------------------------ sharding over ranks
+    def _members(self, n_models: int, kwargs: dict):
+        """Member indices this process trains, and whether they were sharded over the process group."""
+        distributed = kwargs.pop("distributed", False)
+        member_range = kwargs.pop("member_range", None)
+        members = list(range(n_models) if member_range is None else member_range)
+        self._ens_rank = 0
+        if distributed and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if self.dp is not None:
+                raise AssertionError("a sharded ensemble trains independent members: do not combine it with "
+                                     "data-parallel gradient averaging (trainer.dp)")
+            self._ens_rank = dist.get_rank()
+            return members[self._ens_rank::dist.get_world_size()], True
+        return members, False
+
+    def _gather_members(self) -> None:
+        """Every rank receives every member (CPU tensors); the only collective of a sharded ensemble run."""
+        local = {i: {k: v.detach().cpu() for k, v in sd.items()} for i, sd in self.ensemble_state_dict.items()}
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, local)
+        merged = {}
+        for part in parts:
+            merged.update(part)
+        dev = self.device
+        self.ensemble_state_dict = {i: {k: v.to(dev) for k, v in merged[i].items()} for i in sorted(merged)}
 
     def compile_ensemble_trainer(self, **kwargs) -> None:
         """kwargs are forwarded to BaseTrainer.compile_trainer for every member."""
@@ -47,21 +80,26 @@ class BaseEnsembleTrainer(BaseTrainer):
     def train_ensemble_from_scratch(self, X_train, y_train, X_test=None, y_test=None, n_models: int = 10,
                                     augment_fn=None, **kwargs) -> Tuple[Type[torch.nn.Module], ensemble_type]:
         """Every member starts from a different initialisation (seed = batch_seed = member index)."""
-        member_range = kwargs.pop("member_range", None)
+        members, sharded = self._members(n_models, kwargs)
         self.update_training_parameters(kwargs)
         print("Training ensemble models (strategy = 'from_scratch')")
-        for i in (range(n_models) if member_range is None else member_range):
+        for i in members:
             print("\nEnsemble model {}".format(i + 1))
             self.kdict["batch_seed"] = i
             model_i = self.train_baseline(X_train, y_train, X_test, y_test, i, augment_fn)
             self.ensemble_state_dict[i] = dc(model_i.state_dict())
+            self.save_ensemble_metadict()
+        if sharded:
+            self._gather_members()
             self.save_ensemble_metadict()
         return self.net, self.ensemble_state_dict
 
     def train_ensemble_from_baseline(self, X_train, y_train, X_test=None, y_test=None, basemodel=None,
                                      n_models: int = 10, training_cycles_base: int = 1000,
                                      training_cycles_ensemble: int = 100, augment_fn=None, **kwargs):
-        """Members continue from a common baseline with different batch shuffling (seed i + 2)."""
+        """Members continue from a common baseline with different batch shuffling (seed i + 2).  Sharded runs train
+        the (deterministic) baseline redundantly on every rank instead of broadcasting it."""
+        members, sharded = self._members(n_models, kwargs)
         self.update_training_parameters(kwargs)
         if basemodel is None:
             self.kdict["training_cycles"] = training_cycles_base
@@ -75,9 +113,10 @@ class BaseEnsembleTrainer(BaseTrainer):
         if not self.full_epoch and "print_loss" not in self.kdict:
             self.kdict["print_loss"] = 10
         print("\nTraining ensemble models (strategy = 'from_baseline')")
-        for i in range(n_models):
+        model_i = self.net
+        for j, i in enumerate(members):
             print("\nEnsemble model {}".format(i + 1))
-            if i > 0:
+            if j > 0:
                 self.net.load_state_dict(basemodel_state_dict)
             self._reset_rng(i + 2)
             self._reset_training_history()
@@ -85,6 +124,10 @@ class BaseEnsembleTrainer(BaseTrainer):
             self.compile_trainer((X_train, y_train, X_test, y_test), batch_seed=i + 2, **self.kdict)
             model_i = self.run()
             self.ensemble_state_dict[i] = dc(model_i.state_dict())
+            self.save_ensemble_metadict()
+            model_i.load_state_dict(average_weights(self.ensemble_state_dict))
+        if sharded:
+            self._gather_members()
             self.save_ensemble_metadict()
             model_i.load_state_dict(average_weights(self.ensemble_state_dict))
         return model_i, self.ensemble_state_dict
@@ -112,7 +155,7 @@ class BaseEnsembleTrainer(BaseTrainer):
         fname = self.filename if filename is None else filename
         meta = dict(self.meta_state_dict)                    # same keys as the reference's file (incl. 'optimizer')
         meta["weights"] = self.ensemble_state_dict
-        if self.dp is None or self.dp.rank == 0:
+        if (self.dp is None or self.dp.rank == 0) and self._ens_rank == 0:
             torch.save(meta, fname + "_ensemble_metadict.tar")
 
 

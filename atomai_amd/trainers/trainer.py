@@ -195,8 +195,8 @@ class BaseTrainer:
             self.meta_state_dict["optimizer"] = self.optimizer.as_torch_adam()
         else:
             self.meta_state_dict["optimizer"] = self.meta_state_dict.get("optimizer", self.optimizer)
-        if self.dp is None or self.dp.rank == 0:
-            torch.save(self.meta_state_dict, filename + '.tar')
+        if (self.dp is None or self.dp.rank == 0) and getattr(self, "_ens_rank", 0) == 0:
+            torch.save(self.meta_state_dict, filename + '.tar')    # (sharded ensemble runs: rank 0's members only)
 
     def print_statistics(self, e: int, **kwargs) -> None:
         if self.dp is not None and self.dp.rank != 0:

@@ -84,7 +84,7 @@ def reset_bnorm(module) -> None:
 
 def average_weights(ensemble: Dict[int, Dict[str, torch.Tensor]]) -> Dict[str, torch.Tensor]:
     """Averages every non-BN-statistic tensor over an ensemble of state dicts (utils/nn.py:59-81)."""
-    out = copy.deepcopy(ensemble[0])
+    out = copy.deepcopy(next(iter(ensemble.values())))       # (ensemble[0] in the reference; a rank's shard may lack it)
     for name in out:
         if name.split('_')[-1] in ("mean", "var", "tracked"):
             continue
