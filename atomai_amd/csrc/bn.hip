@@ -325,12 +325,18 @@ extern "C" int amx_reduce_rows(const float* part, int rows, int stride, int C, f
 // formula in fp64, so that amx_bn_finalize (mode 2) only has to walk RB rows per channel.
 // mode 3: rows of a lattice-mode convolution, [n][ry][rx][strip][tx] over the lat*lat residue-class sub-images
 // (conv_kernel.h); strips of residue classes with a shorter sub-image hold no pixel and are skipped.
-__global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ stats, int rows,
-                                                            int cop, int mode, int N, int H, int W,
-                                                            int rows_pix, int lat, int chunk,
-                                                            float* __restrict__ out) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= cop) return;
+// Block = 16 channels x 16 row lanes: row lane j merges rows r0 + j, r0 + j + 16, ... of the chunk (64-byte row
+// segments, 16 independent chains per channel), then the 16 partials are merged in lane order through LDS — fixed
+// order, fp64, no atomics.  (One thread per channel walking the whole chunk, as in round 1, left 3/4 of the lanes
+// idle on 16-channel layers and serialised ~128 dependent loads: 27 us per launch, 0.35 ms per training step.)
+#define MRG_RL 16
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ stats, int rows,
+                                                             int cop, int mode, int N, int H, int W,
+                                                             int rows_pix, int lat, int chunk,
+                                                             float* __restrict__ out) {
+    __shared__ double sm[3][MRG_RL][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;                       // cop is a multiple of 16
     const int th = ((mode == 0 || mode == 3) && rows_pix > 0) ? rows_pix : 16;
     const int d = mode == 3 ? lat : 1;
     const int tiles_x = ((W + d - 1) / d + 15) / 16, tiles_y = ((H + d - 1) / d + th - 1) / th;
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
     const int r0 = blockIdx.y * chunk;
     const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int r = r0; r < r1; ++r) {
+    for (int r = r0 + rl; r < r1; r += MRG_RL) {
         double nr;
         if (mode == 0) {
             const int tx = r % tiles_x, ty = (r / tiles_x) % tiles_y;
@@ -357,22 +363,34 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
         }
         const double mr = (double)stats[((size_t)r * 2) * cop + c] / nr;
         const double m2r = (double)stats[((size_t)r * 2 + 1) * cop + c];
-        const double nt = n + nr, d = mr - mean;
-        mean += d * (nr / nt);
-        m2 += m2r + d * d * (n * nr / nt);
+        const double nt = n + nr, dl = mr - mean;
+        mean += dl * (nr / nt);
+        m2 += m2r + dl * dl * (n * nr / nt);
         n = nt;
     }
-    out[((size_t)blockIdx.y * 3 + 0) * cop + c] = (float)(mean * n);
-    out[((size_t)blockIdx.y * 3 + 1) * cop + c] = (float)m2;
-    out[((size_t)blockIdx.y * 3 + 2) * cop + c] = (float)n;
+    sm[0][rl][cl] = n; sm[1][rl][cl] = mean; sm[2][rl][cl] = m2;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < MRG_RL; ++j) {
+            const double nr = sm[0][j][cl];
+            if (nr <= 0.0) continue;
+            const double nt = n + nr, dl = sm[1][j][cl] - mean;
+            mean += dl * (nr / nt);
+            m2 += sm[2][j][cl] + dl * dl * (n * nr / nt);
+            n = nt;
+        }
+        out[((size_t)blockIdx.y * 3 + 0) * cop + c] = (float)(mean * n);
+        out[((size_t)blockIdx.y * 3 + 1) * cop + c] = (float)m2;
+        out[((size_t)blockIdx.y * 3 + 2) * cop + c] = (float)n;
+    }
 }
 
 extern "C" int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W,
                                   int rows_pix, int lat, int nchunks, float* out, void* stream) {
-    if (!stats || !out || rows <= 0 || cop <= 0 || nchunks <= 0 || (mode != 0 && mode != 1 && mode != 3)) AMX_BADARG(1);
+    if (!stats || !out || rows <= 0 || cop <= 0 || (cop & 15) || nchunks <= 0 || (mode != 0 && mode != 1 && mode != 3)) AMX_BADARG(1);
     if (mode == 3 && (lat < 1 || rows_pix <= 0)) AMX_BADARG(2);
     const int chunk = amx_ceil_div(rows, nchunks);
-    AMX_LAUNCH(bn_stats_merge_kernel, dim3(amx_ceil_div(cop, 64), amx_ceil_div(rows, chunk)), dim3(64), 0,
+    AMX_LAUNCH(bn_stats_merge_kernel, dim3(cop / 16, amx_ceil_div(rows, chunk)), dim3(256), 0,
                (hipStream_t)stream, stats, rows, cop, mode, N, H, W, rows_pix, lat, chunk, out);
     AMX_CHECK_LAUNCH();
     return 0;

@@ -21,7 +21,10 @@ __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a
     // one thread per pixel: the Cs floats of a pixel are contiguous (a wave reads one contiguous 64*Cs*4 B
     // span), and every class plane is written with unit stride across the wave
     const int G = Cs >> 2;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long n = ((long)blockIdx.x * 256 + threadIdx.x) / HW, hw = ((long)blockIdx.x * 256 + threadIdx.x) - n * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride, hw += stride) {
+        while (hw >= HW) { hw -= HW; ++n; }                  // (image, pixel) of p without a division per pixel
         float acc[MAXCLS];
         #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) acc[k] = k < K ? b[k] : 0.f;
@@ -44,7 +47,6 @@ __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a
             }
         }
         if (mode == 0) {
-            const long n = p / HW, hw = p - n * HW;
             #pragma unroll
             for (int k = 0; k < MAXCLS; ++k) if (k < K) out[((size_t)n * K + k) * HW + hw] = acc[k];
         } else if (K == 1) {
@@ -112,8 +114,11 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
     if (active) {
         float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
         if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
-        for (long p = p0 + pl; p < p1; p += PL) {
-            const long n = p / HW, hw = p - n * HW;
+        // (image, pixel-in-image) of p, advanced with a carry: a 64-bit division per pixel was a third of this
+        // kernel's instructions
+        long n = (p0 + pl) / HW, hw = (p0 + pl) - n * HW;
+        for (long p = p0 + pl; p < p1; p += PL, hw += PL) {
+            while (hw >= HW) { hw -= HW; ++n; }
             float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
             const float4 raw = v;
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
@@ -198,8 +203,10 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     __shared__ float red[256];
     const int tid = threadIdx.x;
     float lsum = 0.f;
-    for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
-        const long n = p / HW, hw = p - n * HW;
+    const long stride = (long)gridDim.x * 256;
+    long n = ((long)blockIdx.x * 256 + tid) / HW, hw = ((long)blockIdx.x * 256 + tid) - n * HW;
+    for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += stride, hw += stride) {
+        while (hw >= HW) { hw -= HW; ++n; }                  // (no 64-bit division per pixel)
         const float* xp = x + (size_t)n * K * HW + hw;
         float v[MAXCLS];
         float mx = -3.4e38f;
