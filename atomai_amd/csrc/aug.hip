@@ -133,6 +133,8 @@ struct AugArgs {
     const float* f_gauss;              // optional injected fields [N][H][W]: standard normals,
     const float* f_pois;               //   poisson draws (already sampled for lam = v * vals),
     const float* f_sp1; const float* f_sp2;   //   uniforms deciding "flipped" / "salted"
+    const int* jitter;                 // [N][H] row shifts z: out[y][x] = noisy[y][(x - z) mod W] (np.roll per row,
+                                       // applied AFTER the gaussian noise: imaug.py:123-135, 332-335), or nullptr
     int N, H, W;
     unsigned seed0, seed1;
 };
@@ -157,15 +159,19 @@ __global__ __launch_bounds__(256) void aug_point_kernel(AugArgs a) {
         const int r = (int)(i - (long)n * hw);
         const int oy = r / a.W, ox = r - oy * a.W;
         const float* P = a.params + (size_t)n * AUG_NP;
+        // jitter rolls the rows of the rotated, noise-carrying image: this output pixel shows the pixel `jx` of its row
+        int jx = ox;
+        if (a.jitter) { jx = (ox - a.jitter[(long)n * a.H + oy]) % a.W; if (jx < 0) jx += a.W; }
+        const int rj = oy * a.W + jx;
         int sy, sx;
-        src_of((int)P[0], a.H, a.W, oy, ox, sy, sx);
+        src_of((int)P[0], a.H, a.W, oy, jx, sy, sx);
         float v = a.x[(long)n * hw + (long)sy * a.W + sx];
         if (a.mnmx) v = (v - mn) / inv;
         if (P[1] > 0.f) {                                   // skimage random_noise(mode='gaussian', clip=True)
             float z;
-            if (a.f_gauss) z = a.f_gauss[i];
+            if (a.f_gauss) z = a.f_gauss[(long)n * hw + rj];
             else {
-                const Philox q = philox(a.seed0, a.seed1, (unsigned)r, (unsigned)n, 1u, 0u);
+                const Philox q = philox(a.seed0, a.seed1, (unsigned)rj, (unsigned)n, 1u, 0u);
                 z = sqrtf(-2.f * logf(u01(q.c[0]))) * cosf(6.28318530718f * u01(q.c[1]));
             }
             v = fminf(fmaxf(v + P[1] * z, 0.f), 1.f);
@@ -192,14 +198,14 @@ __global__ __launch_bounds__(256) void aug_point_kernel(AugArgs a) {
 }
 
 extern "C" int amx_aug_point(const float* x, float* y, const float* params, const float* mnmx, const float* f_gauss,
-                             const float* f_pois, const float* f_sp1, const float* f_sp2, int N, int H, int W,
-                             long seed, void* stream) {
+                             const float* f_pois, const float* f_sp1, const float* f_sp2, const int* jitter,
+                             int N, int H, int W, long seed, void* stream) {
     if (!x || !y || !params || x == y) AMX_BADARG(1);
     if (N <= 0 || H <= 0 || W <= 0) AMX_BADARG(2);
     if ((f_sp1 == nullptr) != (f_sp2 == nullptr)) AMX_BADARG(3);
     AugArgs a;
     a.x = x; a.y = y; a.params = params; a.mnmx = mnmx; a.f_gauss = f_gauss; a.f_pois = f_pois; a.f_sp1 = f_sp1;
-    a.f_sp2 = f_sp2; a.N = N; a.H = H; a.W = W;
+    a.f_sp2 = f_sp2; a.jitter = jitter; a.N = N; a.H = H; a.W = W;
     a.seed0 = (unsigned)(seed & 0xffffffffL); a.seed1 = (unsigned)((unsigned long long)seed >> 32) ^ 0x5bd1e995u;
     long nb = ((long)N * H * W + 255) / 256;
     if (nb > 8192) nb = 8192;

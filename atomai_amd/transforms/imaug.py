@@ -4,7 +4,8 @@ The reference runs numpy / skimage / scipy / cv2 in float64 on the CPU for every
 (hook: atomai/trainers/trainer.py:339-341); at > 1 k images/s that would starve the GPU.  Here the batch stays in HBM
 and the steps are HIP kernels (csrc/aug.hip).  Same step order and parameter ranges as ``datatransform.run``:
 
-    (x - min) / ptp -> rotation -> gauss_noise -> poisson_noise -> salt_and_pepper -> blur -> contrast -> background
+    (x - min) / ptp -> rotation -> gauss_noise -> jitter -> poisson_noise -> salt_and_pepper -> blur -> contrast
+    -> background
     -> [drop image-label pairs that lost a class] -> (x - min) / ptp
 
 * The per-image scalar parameters (flip type, noise level, gamma, background centre / widths / amplitude) are drawn on
@@ -14,8 +15,11 @@ and the steps are HIP kernels (csrc/aug.hip).  Same step order and parameter ran
 * Per-pixel randomness comes from a counter-based Philox generator in the kernel (skimage draws its own from an unseeded
   ``default_rng``, so the reference is not reproducible there either); ``fields=`` injects explicit noise fields so that
   the arithmetic can be compared with the reference element by element (tests/golden/augment.npz).
+* ``jitter`` (rows rolled by Poisson-distributed shifts, imaug.py:123-135): the N x H shifts are drawn on the host from
+  the same stream (``scipy.stats.poisson.rvs`` draws from numpy's global state, i.e. they are the reference's shifts
+  for the same seed) and applied as an index map inside the point pass.
 * Not available (their arithmetic lives in cv2, which is absent here and cannot be pinned): ``zoom``, ``resize``;
-  also ``jitter`` and ``custom_transform`` (arbitrary host code).  Passing one raises.
+  also ``custom_transform`` (arbitrary host code).  Passing one raises.
 """
 from typing import Callable, Optional, Tuple
 
@@ -25,7 +29,7 @@ import torch
 from .. import _lib as L
 
 _NP = 12
-_UNSUPPORTED = ("zoom", "resize", "jitter", "custom_transform")
+_UNSUPPORTED = ("zoom", "resize", "custom_transform")
 
 
 def _minmax(x: torch.Tensor) -> torch.Tensor:
@@ -56,6 +60,7 @@ class datatransform:
         self.rotation = kwargs.get("rotation")
         self.background = kwargs.get("background")
         self.gauss = rng("gauss_noise", [0, 50])
+        self.jitter = rng("jitter", [0, 50])
         self.poisson = rng("poisson_noise", [30, 40])
         self.salt_and_pepper = rng("salt_and_pepper", [0, 50])
         self.blur = rng("blur", [1, 50])
@@ -81,6 +86,9 @@ class datatransform:
         if self._is_range(self.gauss):
             for i in range(n):
                 P[i, 1] = np.sqrt(1e-4 * rs.randint(self.gauss[0], self.gauss[1]))
+        if self._is_range(self.jitter):                       # one level per image, then H poisson shifts (imaug.py:132-133)
+            extra["jitter"] = np.stack([rs.poisson(rs.randint(self.jitter[0], self.jitter[1]) / 10, size=h)
+                                        for _ in range(n)]).astype(np.int32)
         if self._is_range(self.poisson):
             extra["poisson_l"] = np.array([rs.randint(self.poisson[0], self.poisson[1]) for _ in range(n)])
         if self._is_range(self.salt_and_pepper):
@@ -102,7 +110,7 @@ class datatransform:
         return P, extra
 
     # ------------------------------------------------------------------ device
-    def _point(self, x, P, mnmx=None, fields=None):
+    def _point(self, x, P, mnmx=None, fields=None, jitter=None):
         fields = fields or {}
         N, H, W = x.shape
         dev = x.device
@@ -110,13 +118,14 @@ class datatransform:
         Pd = torch.from_numpy(np.ascontiguousarray(P, dtype=np.float32)).to(dev)
         f = lambda k: None if fields.get(k) is None else fields[k].to(dev).float().contiguous()   # noqa: E731
         keep = [f("gauss"), f("poisson"), f("sp_flip"), f("sp_salt")]
+        jd = None if jitter is None else torch.from_numpy(np.ascontiguousarray(jitter, dtype=np.int32)).to(dev)
         L.call("amx_aug_point", L.ptr(x), L.ptr(y), L.ptr(Pd), L.ptr(mnmx), L.ptr(keep[0]), L.ptr(keep[1]),
-               L.ptr(keep[2]), L.ptr(keep[3]), N, H, W, self.seed, L.stream_ptr(x))
+               L.ptr(keep[2]), L.ptr(keep[3]), L.ptr(jd), N, H, W, self.seed, L.stream_ptr(x))
         return y
 
     def run(self, images: torch.Tensor, targets: torch.Tensor, fields: dict = None) -> Tuple[torch.Tensor]:
         """images (N, H, W) or (N, 1, H, W) fp32 on the device; targets (N, H, W) int64 class maps or (N, 1, H, W)
-        fp32 binary masks.  ``fields`` (tests): {'gauss','poisson','sp_flip','sp_salt'} -> (N, H, W) tensors."""
+        fp32 binary masks.  ``fields`` (tests): {'gauss','poisson','sp_flip','sp_salt'} -> (N, H, W) tensors, 'jitter' -> (N, H) ints."""
         x = images[:, 0] if images.ndim == 4 else images
         x = x.float().contiguous()
         N, H, W = x.shape
@@ -131,10 +140,13 @@ class datatransform:
         rest = P.copy()
         rest[:, 0] = 4
         rest[:, 1] = 0
-        need_split = "poisson_l" in extra or "blur_sigma" in extra
+        # (jitter moves pixels BETWEEN the gaussian step and the later per-pixel steps: those run in their own pass)
+        need_split = "poisson_l" in extra or "blur_sigma" in extra or "jitter" in extra
         if not need_split:
             PA = P                                            # everything in ONE pass
-        x = self._point(x, PA, _minmax(x), fields)
+        if "jitter" in fields:                                # tests: explicit shifts
+            extra["jitter"] = np.asarray(fields["jitter"], dtype=np.int32)
+        x = self._point(x, PA, _minmax(x), fields, extra.get("jitter"))
         if need_split:
             # ---- pass B: poisson (its scale needs the number of distinct values of the image so far), salt & pepper
             PB = zero.copy()

@@ -186,14 +186,15 @@ int amx_dropout_bwd(float* dpre, const float* mask, long n, void* stream);
  *   2-D gaussian background in one pass; params [N][12] per image = (flip code -1|0|1|2 ccw|3 cw|4 none, gauss sigma,
  *   poisson scale, s&p amount, gamma, bg x0, y0, a, b, fwhm, bg amplitude, 0); 0 switches a step off.  Per-pixel
  *   randomness: Philox4x32-10 keyed by (seed, image, pixel, step), or the caller's fields f_* ([N][H][W]; NULL = use
- *   the generator): standard normals, poisson draws, and the two uniforms of salt & pepper.
+ *   the generator): standard normals, poisson draws, and the two uniforms of salt & pepper.  jitter ([N][H] ints or
+ *   NULL): row y of image n is rolled by jitter[n][y] pixels after the gaussian-noise step (apply_jitter, np.roll).
  * amx_aug_blur: one axis (0 rows, 1 columns) of scipy.ndimage.gaussian_filter(sigma[n], mode='reflect', truncate=4).
  * amx_aug_labels: the same flip / rotation on int64 class maps; present[n] |= 1 << class (caller zeroes it). */
 int amx_aug_minmax_blocks(long n);
 int amx_aug_minmax(const float* x, long n, float* work, float* out, void* stream);
 int amx_aug_point(const float* x, float* y, const float* params, const float* mnmx, const float* f_gauss,
-                  const float* f_pois, const float* f_sp1, const float* f_sp2, int N, int H, int W, long seed,
-                  void* stream);
+                  const float* f_pois, const float* f_sp1, const float* f_sp2, const int* jitter, int N, int H, int W,
+                  long seed, void* stream);
 int amx_aug_renorm(float* x, long n, const float* mnmx, void* stream);
 int amx_aug_blur(const float* x, float* y, const float* sigma, int N, int H, int W, int axis, void* stream);
 int amx_aug_labels(const long long* t, long long* out, const float* params, int* present, int N, int H, int W,

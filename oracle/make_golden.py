@@ -365,8 +365,26 @@ def make_augment(aoi):
     finally:
         np.random.poisson = orig
     out["po|X"], out["po|out"], out["po|draws"], out["po|seed"] = X1, Xp, rec[0].astype(np.float64)[None], np.array(11)
+    # (3) jitter (+ background): rows rolled by scipy.stats.poisson.rvs shifts, which draw from numpy's global stream
+    # and are therefore reproducible from the seed; recorded as well
+    from scipy import stats
+    Xj = rs.rand(3, 20, 28)
+    shifts = []
+    orig_rvs = stats.poisson.rvs
+
+    def rvs(*a, **k):
+        r = orig_rvs(*a, **k)
+        shifts.append(np.array(r))
+        return r
+    stats.poisson.rvs = rvs
+    try:
+        dt = datatransform(1, "channel_last", "channel_first", False, 13, jitter=[20, 50], background=True)
+        Xjo, _ = dt.run(Xj.copy(), y.copy())
+    finally:
+        del stats.poisson.rvs
+    out["ji|X"], out["ji|out"], out["ji|shifts"], out["ji|seed"] = Xj, Xjo, np.stack(shifts).astype(np.int64), np.array(13)
     np.savez_compressed(os.path.join(GOLD, "augment.npz"), **out)
-    print("augment ok", Xa.shape, Xp.shape)
+    print("augment ok", Xa.shape, Xp.shape, Xjo.shape, np.stack(shifts).max())
 
 
 def make_vae_conv(aoi):

@@ -24,6 +24,13 @@ def check_oracle_vs_reference_golden():
     vals = (50 / extra["poisson_l"]) ** np.ceil(np.log2([len(np.unique(xn[0]))]))
     ref = ao.run(X1, P, fields={"poisson": g["po|draws"]}, poisson_vals=vals)
     np.testing.assert_allclose(ref[:, None], g["po|out"], rtol=0, atol=1e-12)
+    # jitter: the host draws ARE the reference's shifts (scipy's poisson.rvs draws from numpy's global stream)
+    Xj = g["ji|X"]
+    dt = datatransform(1, int(g["ji|seed"]), jitter=[20, 50], background=True)
+    P, extra = dt.draw(*Xj.shape)
+    assert np.array_equal(extra["jitter"], g["ji|shifts"]) and extra["jitter"].max() > 0
+    ref = ao.run(Xj, P, jitter=extra["jitter"])
+    np.testing.assert_allclose(ref[:, None], g["ji|out"], rtol=0, atol=1e-12)
 
 
 def check_kernels_vs_reference_golden(device):
@@ -40,6 +47,9 @@ def check_kernels_vs_reference_golden(device):
     out, _ = dt.run(X1, torch.zeros(1, 1, 24, 24, device=device),
                     fields={"poisson": torch.from_numpy(g["po|draws"])})
     assert np.abs(out.cpu().numpy() - g["po|out"]).max() < 2e-5
+    Xj = torch.from_numpy(g["ji|X"]).float().to(device)
+    out, _ = datatransform(1, int(g["ji|seed"]), jitter=[20, 50], background=True).run(Xj, y)
+    assert np.abs(out.cpu().numpy() - g["ji|out"]).max() < 2e-5
 
 
 def check_kernels_vs_oracle_all_steps(device, N=5, H=24, W=24):
@@ -50,13 +60,16 @@ def check_kernels_vs_oracle_all_steps(device, N=5, H=24, W=24):
     X = rs.rand(N, H, W)
     lab = rs.randint(0, 3, (N, H, W))
     fields = {"gauss": rs.randn(N, H, W), "sp_flip": rs.rand(N, H, W), "sp_salt": rs.rand(N, H, W)}
-    dt = datatransform(3, 5, rotation=True, gauss_noise=True, salt_and_pepper=[20, 50], contrast=True, background=True)
+    dt = datatransform(3, 5, rotation=True, gauss_noise=True, jitter=[10, 60], salt_and_pepper=[20, 50], contrast=True,
+                       background=True)
     out, tl = dt.run(torch.from_numpy(X).float().to(device), torch.from_numpy(lab).to(device),
                      fields={k: torch.from_numpy(v) for k, v in fields.items()})
     P = dt.params
+    jit = dt.extra["jitter"]
+    assert jit.shape == (N, H) and jit.max() > 0
     assert set(P[:, 0]) <= {-1, 0, 1, 2} and (P[:, 1] > 0).any() and (P[:, 4] > 0).all()
     # rotated noise fields: the kernel indexes its fields by OUTPUT pixel, as the reference applies noise after rotating
-    ref = ao.run(X, P, fields=fields)
+    ref = ao.run(X, P, fields=fields, jitter=jit)             # (labels are not jittered: imaug.py:135)
     assert out.shape == (N, 1, H, W)
     assert np.abs(out[:, 0].cpu().numpy() - ref).max() < 3e-5
     for i in range(N):
@@ -74,7 +87,7 @@ def check_generator_statistics(device, N=4, H=64, W=64):
     def point(P_, seed):
         y = torch.empty_like(x)
         Pd = torch.from_numpy(P_).to(device)
-        L.call("amx_aug_point", L.ptr(x), L.ptr(y), L.ptr(Pd), None, None, None, None, None, N, H, W, seed,
+        L.call("amx_aug_point", L.ptr(x), L.ptr(y), L.ptr(Pd), None, None, None, None, None, None, N, H, W, seed,
                L.stream_ptr(x))
         return y.cpu().numpy()
     Pg = P.copy(); Pg[:, 1] = 0.05
