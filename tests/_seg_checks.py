@@ -151,9 +151,11 @@ def check_blocks(device):
                 assert e <= max(4 * e32, 5e-5), (name, mode, k, e, e32)
 
 
-def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1)), lattice=None):
+def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1), (8, 8, 4, 6, 1), (4, 20, 3, 2, 2)),
+                          lattice=None):
     """Dilations 2 / 4 / 6 on image sizes that are multiples of neither the dilation nor the tile (ragged residue
-    classes: sub-images of different sizes, empty statistics strips), channel counts with a partial last chunk;
+    classes: sub-images of different sizes, empty statistics strips; images SMALLER than the dilation, where some
+    residue classes hold no pixel at all), channel counts with a partial last chunk;
     forward, BatchNorm statistics, data and weight gradients against the same layers in stock torch fp64."""
     import copy
     import torch.nn as nn
