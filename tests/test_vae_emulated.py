@@ -1,4 +1,9 @@
-"""`not gpu` tier for the VAE / rVAE path: kernel sources on the CPU SIMT emulator vs the reference goldens."""
+"""`not gpu` tier for the VAE / rVAE path: kernel sources on the CPU SIMT emulator vs the reference goldens.
+
+Not executed here (device-only instruction paths; the `gpu` tier runs the same checks on them): the hardware
+exp / reciprocal form of tanh in csrc/rdecoder.hip (`rd_tanh`: the emulator build compiles the library tanhf) and the
+`v_exp_f32` form of the RBF kernel in csrc/kernel_matrix.hip (emulator: expf).  Index / layout / reduction logic is
+identical in both builds."""
 import os
 import sys
 
