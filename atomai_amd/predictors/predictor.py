@@ -9,6 +9,8 @@ not depend on how the stack is chunked (``num_batches`` keeps its meaning for th
 import time
 from typing import List, Tuple, Type, Union
 
+import os
+
 import numpy as np
 import torch
 
@@ -62,6 +64,33 @@ class BasePredictor:
         return self.batch_predict(self.preprocess(data), out_shape, num_batches)
 
 
+# How the host learns that a chunk's download finished (experiment switch, see batch_predict): "default" = event
+# without timing + synchronize, "timing" = event with its own timestamp marker, "poll" = query() in a sleep loop.
+_EV_MODE = os.environ.get("AMX_PREDICT_EVENT", "default")
+
+
+class _host_threads:
+    """Caps torch's intra-op (OpenMP) thread count while the chunk pipeline runs.  On the 128-core MI355X host the
+    default pool puts 128 threads into every 64 MB staging copy; after each parallel region they spin, and the ROCm
+    runtime's signal-handler thread is scheduled tens of milliseconds late: the host then learns about finished
+    downloads only in bursts and the GPU idles one chunk time in three (369 -> 513 frames/s on 256 frames of 1024^2 with
+    the cap, tools/gpu_predict_timeline.py).  8 threads move 64 MB in < 1 ms."""
+
+    def __init__(self, n: int = 8):
+        self.n = int(os.environ.get("AMX_PREDICT_HOST_THREADS", n))
+
+    def __enter__(self):
+        self.old = torch.get_num_threads()
+        if 0 < self.n < self.old:
+            torch.set_num_threads(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.old:
+            torch.set_num_threads(self.old)
+        return False
+
+
 def _min_max(a: np.ndarray):
     """(min, max) of a stack in ONE multi-threaded pass (torch.aminmax): ``a.min()`` + ``np.ptp(a)`` are three
     single-threaded passes — 0.25 s per GB, as long as the MI355X needs to decode the 256 frames of that GB."""
@@ -99,7 +128,7 @@ class SegPredictor(BasePredictor):
         self.thresh = kwargs.get("thresh", .5)
         self.use_gpu = use_gpu
         self.verbose = kwargs.get("verbose", True)
-        self.chunk_bytes = int(kwargs.get("chunk_bytes", 64 << 20))
+        self.chunk_bytes = int(kwargs.get("chunk_bytes", int(os.environ.get("AMX_PREDICT_CHUNK_MB", "64")) << 20))
         self._norm = None
 
     def preprocess(self, image_data: np.ndarray, norm: bool = True, device_norm: bool = True) -> torch.Tensor:
@@ -161,12 +190,12 @@ class SegPredictor(BasePredictor):
         from ..engine import aux_stream
         copy_in, copy_out = aux_stream(dev, 1), aux_stream(dev, 2)
         main = torch.cuda.current_stream(dev)
-        NS = 3                                      # chunks in flight (host runs up to NS chunks ahead of the GPU)
+        NS = int(os.environ.get("AMX_PREDICT_NS", "3"))   # chunks in flight (host runs up to NS chunks ahead of the GPU)
         # pinned staging buffers are kept on the predictor: allocating 6 x 64 MB of page-locked memory costs more
         # than decoding a hundred frames
         key = (tuple(data.shape[1:]), tuple(out_shape[1:]))
         pinned = getattr(self, "_pinned", None)
-        if pinned is None or pinned[0] != key or len(pinned[1][0]) < chunk:
+        if pinned is None or pinned[0] != key or len(pinned[1][0]) < chunk or len(pinned[1]) != NS:
             self._pinned = (key,
                             [torch.empty((chunk,) + tuple(data.shape[1:]), pin_memory=True) for _ in range(NS)],
                             [torch.empty((chunk,) + tuple(out_shape[1:]), pin_memory=True) for _ in range(NS)])
@@ -191,31 +220,46 @@ class SegPredictor(BasePredictor):
             copy_out.wait_event(st["done"])
             L.call("amx_copy16", L.ptr(prob), ctypes.c_void_p(pin_out[k % NS].data_ptr()), prob.numel() * 4, 128,
                    ctypes.c_void_p(copy_out.cuda_stream))
-            st["ev_out"] = torch.cuda.Event()
+            st["ev_out"] = torch.cuda.Event(enable_timing=_EV_MODE == "timing")
             st["ev_out"].record(copy_out)
 
         def collect(k):                             # chunk k downloaded -> user-visible output; its staging
             st = stage.pop(k)                       # buffers and device tensors are free again after this
-            st["ev_out"].synchronize()
+            if _EV_MODE == "poll":
+                while not st["ev_out"].query():
+                    time.sleep(1e-4)
+            else:
+                st["ev_out"].synchronize()
             out[st["s"]:st["s"] + st["m"]] = pin_out[k % NS][:st["m"]]
 
         nchunks = 0
+        trace = [] if os.environ.get("AMX_PREDICT_TRACE") else None      # dev aid: host time per phase and chunk
+        import time as _time
         for k, s in enumerate(range(0, n, chunk)):
             slot, m = k % NS, min(chunk, n - s)
+            t0 = _time.perf_counter()
             if k >= NS:
                 collect(k - NS)
+            t1 = _time.perf_counter()
             pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of the chunks in flight
+            t2 = _time.perf_counter()
             with torch.cuda.stream(copy_in):        # upload: hipMemcpyAsync with no dependency (see above)
                 d = pin_in[slot][:m].to(dev, non_blocking=True)
             ev_in = torch.cuda.Event()
             ev_in.record(copy_in)
             main.wait_event(ev_in)
+            t3 = _time.perf_counter()
             prob = self.forward_(d)
             done = torch.cuda.Event()
             done.record(main)
             stage[k] = {"d": d, "prob": prob, "done": done, "s": s, "m": m}
             finish(k)
             nchunks = k + 1
+            if trace is not None:
+                trace.append((k, t1 - t0, t2 - t1, t3 - t2, _time.perf_counter() - t3))
+        if trace:
+            for k, a, b, c, d_ in trace:
+                print(f"chunk {k:3d}: collect {1e3*a:7.2f}  copy-in {1e3*b:7.2f}  upload {1e3*c:7.2f}  launches {1e3*d_:7.2f} ms")
         for k in range(max(0, nchunks - NS), nchunks):
             collect(k)
         return out
@@ -308,13 +352,14 @@ class SegPredictor(BasePredictor):
                 raise NotImplementedError("return_image is not available with distributed=True")
             return self.predict_distributed(image_data, **kwargs)
         kwargs.pop("gather", None)
-        image_data = self.preprocess(image_data, kwargs.get("norm", True), device_norm=not return_image)
-        n, _, w, h = image_data.shape
-        num_batches = kwargs.get("num_batches")
-        if num_batches is None:
-            num_batches = len(image_data) if (w >= 256 or h >= 256) else 10
-        segmented = self.batch_predict(image_data, (n, w, h, self.nb_classes), num_batches,
-                                       kwargs.get("_on_chunk"))
+        with _host_threads():
+            image_data = self.preprocess(image_data, kwargs.get("norm", True), device_norm=not return_image)
+            n, _, w, h = image_data.shape
+            num_batches = kwargs.get("num_batches")
+            if num_batches is None:
+                num_batches = len(image_data) if (w >= 256 or h >= 256) else 10
+            segmented = self.batch_predict(image_data, (n, w, h, self.nb_classes), num_batches,
+                                           kwargs.get("_on_chunk"))
         if return_image:
             return image_data.permute(0, 2, 3, 1).numpy(), segmented.numpy()
         return segmented.numpy()
