@@ -37,8 +37,10 @@ struct PixCursor {
 // The 3x3 neighbourhood of pixel (yy, xx) of a single-channel image, zero padded.  Interior pixels (all but the
 // image border: > 99 % at 512^2) take the branch without the four bounds compares and the address arithmetic per tap:
 // three row pointers and, for dilation 1, immediate offsets.
+// in_sub / in_div: the predictor's stack normalisation (x - min) / ptp (utils/preproc.py:822-823) applied to in-bounds
+// values while loading (the padding stays zero); (0, 1) is the exact identity.
 static __device__ __forceinline__ void load_3x3(const float* __restrict__ img, int yy, int xx, int H, int W, int dil,
-                                                float v[9]) {
+                                                float v[9], float in_sub = 0.f, float in_div = 1.f) {
     if (yy >= dil && yy < H - dil && xx >= dil && xx < W - dil) {
         const float* r1 = img + (size_t)yy * W + xx;
         const float* r0 = r1 - (size_t)dil * W;
@@ -52,12 +54,16 @@ static __device__ __forceinline__ void load_3x3(const float* __restrict__ img, i
             v[3] = r1[-dil]; v[4] = r1[0]; v[5] = r1[dil];
             v[6] = r2[-dil]; v[7] = r2[0]; v[8] = r2[dil];
         }
+        #pragma unroll
+        for (int t = 0; t < 9; ++t) { const float d = v[t] - in_sub; v[t] = d / in_div; }
         return;
     }
     #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
-        v[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(size_t)iy * W + ix] : 0.f;
+        float u = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) { const float d = img[(size_t)iy * W + ix] - in_sub; u = d / in_div; }
+        v[t] = u;
     }
 }
 
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, float* __restrict__ stats,
                                                         int N, int H, int W, int Cout, int Cs, int dil,
-                                                        float slope, int ppb, int cop) {
+                                                        float slope, int ppb, int cop, float in_sub, float in_div) {
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             const float* img = x + (size_t)cur.nimg * H * W;
             float4 acc = b4;
             float xv[9];
-            load_3x3(img, yy, xx, H, W, dil, xv);
+            load_3x3(img, yy, xx, H, W, dil, xv, in_sub, in_div);
             #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float v = xv[t];
@@ -146,14 +152,15 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 
 extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
                              int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows,
-                             int rows_pix, void* stream) {
+                             int rows_pix, float in_sub, float in_div, void* stream) {
     if (!x || !w || !y || Cout <= 0 || Cs < Cout || (Cs & 3) || Cs > 256 || dil < 1) AMX_BADARG(1);
+    if (!(in_div != 0.f)) AMX_BADARG(3);
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
     const int PL = 256 / (Cs / 4);
     AMX_LAUNCH(conv1_fwd_kernel, dim3(rows), dim3(256), (size_t)PL * 3 * Cs * sizeof(float),
                (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
-               amx_round_up(Cout, 16));
+               amx_round_up(Cout, 16), in_sub, in_div);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -255,9 +255,11 @@ class ConvNode(_Node):
             self.rows = L.load().amx_rows_for(npix)
             self.rows_pix = L.load().amx_rows_pix(npix)
             stats = _empty((self.rows, 2, cop), x) if training_bn else None
+            norm = tape.input_norm if tape.input_norm is not None else (0.0, 1.0)
+            tape.input_norm_used = tape.input_norm is not None
             L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
                    L.ptr(y), L.ptr(stats), N, H, W, self.cout, cos, self.dil, self.slope, self.rows,
-                   self.rows_pix, _sp(x))
+                   self.rows_pix, float(norm[0]), float(norm[1]), _sp(x))
             stat_mode, lat = 1, 0
         else:
             s0 = self.srcs[0]
@@ -841,6 +843,9 @@ class Tape:
         self.side_stream = None
         self.keepalive: list = []
         self.bn_counters: list = []
+        # predictor: (min, ptp) of the stack; the first-layer kernel reads its input as (x - min) / ptp
+        self.input_norm = None
+        self.input_norm_used = False
 
     def side(self, like: torch.Tensor, keep=()):
         return _SideCtx(self, like, keep)

@@ -253,12 +253,32 @@ def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwarg
     return net, meta_state_dict
 
 
-def predict_proba(net: _HipNet, x: torch.Tensor) -> torch.Tensor:
+def predict_proba(net: _HipNet, x: torch.Tensor, input_norm=None) -> torch.Tensor:
     """Eval-mode forward returning class probabilities in NHWC — sigmoid (1 class) / softmax fused into
     the px kernel together with the NCHW->NHWC permute of SegPredictor.forward_
-    (atomai/predictors/predictor.py:219-229)."""
+    (atomai/predictors/predictor.py:219-229).  ``input_norm`` = (min, ptp): the net sees (x - min) / ptp, applied by
+    the first-layer kernel while it loads (nets whose first layer is not the single-channel 3x3 kernel get a separate
+    normalisation pass)."""
     from ..engine import Tape
+    from .. import _lib as L
     assert not net.training
     with torch.no_grad():
         tape = Tape(False, False)
-        return net._build(tape, x, px_mode=1)[1].value
+        tape.input_norm = None if input_norm is None else (float(input_norm[0]), float(input_norm[1]))
+        if input_norm is not None and not _fuses_input_norm(net, x):
+            raw = x.contiguous()
+            x = torch.empty_like(raw)
+            L.call("amx_sub_div", L.ptr(raw), L.ptr(x), raw.numel(), tape.input_norm[0], tape.input_norm[1],
+                   L.stream_ptr(raw))
+            tape.input_norm = None
+        out = net._build(tape, x, px_mode=1)[1].value
+        assert tape.input_norm is None or tape.input_norm_used
+        return out
+
+
+def _fuses_input_norm(net, x) -> bool:
+    """True if the net's first layer runs on the single-channel first-layer kernel (ConvBlock._emit_input)."""
+    c1 = getattr(net, "c1", None)
+    conv0 = c1.block[0] if isinstance(c1, ConvBlock) else None
+    return (isinstance(net, (Unet, dilnet)) and conv0 is not None and x.shape[1] == 1 and conv0.in_channels == 1
+            and tuple(conv0.kernel_size) == (3, 3))

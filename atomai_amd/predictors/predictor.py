@@ -162,14 +162,15 @@ class SegPredictor(BasePredictor):
     def forward_(self, images: torch.Tensor) -> torch.Tensor:
         """Probabilities (N,H,W,C) for a batch already on / moved to the model's device."""
         images = images.to(self.device)
-        if getattr(self, "_norm", None) is not None:
-            raw = images.contiguous()
-            images = torch.empty_like(raw)
-            L.call("amx_sub_div", L.ptr(raw), L.ptr(images), raw.numel(), float(self._norm[0]),
-                   float(self._norm[1]), L.stream_ptr(raw))
+        norm = getattr(self, "_norm", None)
         self.model.eval()
         if isinstance(self.model, _HipNet) and self.logits:
-            return predict_proba(self.model, images)
+            return predict_proba(self.model, images, input_norm=norm)   # normalisation inside the first-layer kernel
+        if norm is not None:
+            raw = images.contiguous()
+            images = torch.empty_like(raw)
+            L.call("amx_sub_div", L.ptr(raw), L.ptr(images), raw.numel(), float(norm[0]),
+                   float(norm[1]), L.stream_ptr(raw))
         with torch.no_grad():
             prob = self.model(images)
         if self.logits:

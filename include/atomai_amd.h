@@ -92,10 +92,12 @@ int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, 
 int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,
                      int C1, int Cout, float* dw, void* stream);
 
-/* first layer, Cin == 1 (Conv2d(1, F, 3) of c1: fcnn.py:66-69,186-189) and its weight gradient */
+/* first layer, Cin == 1 (Conv2d(1, F, 3) of c1: fcnn.py:66-69,186-189) and its weight gradient.
+ * in_sub / in_div: the input is read as (x - in_sub) / in_div — the predictor's stack normalisation
+ * (utils/preproc.py:822-823) without a separate pass; (0, 1) = as is. */
 int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
                   int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows, int rows_pix,
-                  void* stream);
+                  float in_sub, float in_div, void* stream);
 int amx_conv1_wgrad(const float* x, const float* dpre, float* part, int N, int H, int W, int Cs,
                     int dil, int rows, int rows_pix, void* stream);
 int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, const float* k1, const float* k2,

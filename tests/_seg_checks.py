@@ -193,6 +193,26 @@ def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1)
             np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.numpy(), rtol=1e-4, atol=1e-6)
 
 
+def check_input_norm_fusion(device):
+    """The predictor's stack normalisation applied inside the first-layer kernel (Unet / dilnet) or by the separate
+    pass (nets with another first layer) gives bit-identical probabilities to normalising first."""
+    import atomai_amd as aoi
+    from atomai_amd.nets.fcnn import predict_proba, _fuses_input_norm
+    rs = np.random.RandomState(2)
+    x = torch.from_numpy((rs.rand(3, 1, 24, 40) * 37 - 5).astype(np.float32)).to(device)
+    mn, ptp = np.float32(x.min().item()), np.float32((x.max() - x.min()).item())
+    xn = ((x - float(mn)) / float(ptp)).contiguous()
+    for name, ncls, kw, fused in (("Unet", 3, dict(nb_filters=4), True), ("dilnet", 1, dict(nb_filters=5), True),
+                                  ("SegResNet", 2, dict(nb_filters=4), False)):
+        torch.manual_seed(5)
+        net, _ = aoi.nets.init_fcnn_model(name, ncls, **kw)
+        net = net.to(device).eval()
+        assert _fuses_input_norm(net, x) == fused, name
+        a = predict_proba(net, x, input_norm=(mn, ptp))
+        b = predict_proba(net, xn)
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
 def check_predict(device_is_gpu):
     import atomai_amd as aoi
     from atomai_amd.utils import img_pad, torch_format_image

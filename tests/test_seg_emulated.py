@@ -150,3 +150,7 @@ def test_dilated_layers_halo_class_kernels_still_agree(monkeypatch):
     """AMX_CONV_LATTICE=0 keeps the halo-class kernels of conv_fwd_dil.hip reachable (in-process A/B switch)."""
     monkeypatch.setenv("AMX_CONV_LATTICE", "0")
     C.check_dilated_ragged("cpu", cases=((16, 20, 23, 41, 1),))
+
+
+def test_input_normalisation_inside_the_first_layer_kernel():
+    C.check_input_norm_fusion("cpu")

@@ -224,3 +224,7 @@ def test_convblock_training_dropout(bn):
     import _dropout_checks as D
     D.check_convblock_dropout("cuda", batch_norm=bn)
     D.check_convblock_dropout("cuda", N=3, Cin=16, Cout=40, H=70, W=50, p=0.5, batch_norm=bn)
+
+
+def test_input_normalisation_inside_the_first_layer_kernel():
+    C.check_input_norm_fusion("cuda")
