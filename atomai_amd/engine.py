@@ -782,16 +782,11 @@ _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
 def aux_stream(dev, which: int = 0) -> "torch.cuda.Stream":
     """Persistent auxiliary stream number `which` of a device (0: weight gradients, 1 / 2: the predictor's
-    upload / download copies).  Persistent so that its hardware queue never changes between calls.
-    The predictor's copy streams are HIGH priority: at default priority the download kernel of chunk k was not
-    dispatched while the compute stream still had convolution workgroups pending — it ran only when the compute stream
-    drained, the host (blocked on that download) could not queue the next chunks, and the GPU idled one chunk time in
-    every three (rocprofv3 timeline, tools/gpu_predict_timeline.py)."""
+    upload / download copies).  Persistent so that its hardware queue never changes between calls."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get((idx, which))
     if st is None:
-        prio = int(_os.environ.get("AMX_COPY_STREAM_PRIORITY", "-1")) if which in (1, 2) else 0
-        st = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(dev, priority=prio)
+        st = _SIDE_STREAMS[(idx, which)] = torch.cuda.Stream(dev)
     return st
 
 

@@ -64,11 +64,6 @@ class BasePredictor:
         return self.batch_predict(self.preprocess(data), out_shape, num_batches)
 
 
-# How the host learns that a chunk's download finished (experiment switch, see batch_predict): "default" = event
-# without timing + synchronize, "timing" = event with its own timestamp marker, "poll" = query() in a sleep loop.
-_EV_MODE = os.environ.get("AMX_PREDICT_EVENT", "default")
-
-
 class _host_threads:
     """Caps torch's intra-op (OpenMP) thread count while the chunk pipeline runs.  On the 128-core MI355X host the
     default pool puts 128 threads into every 64 MB staging copy; after each parallel region they spin, and the ROCm
@@ -221,16 +216,12 @@ class SegPredictor(BasePredictor):
             copy_out.wait_event(st["done"])
             L.call("amx_copy16", L.ptr(prob), ctypes.c_void_p(pin_out[k % NS].data_ptr()), prob.numel() * 4, 128,
                    ctypes.c_void_p(copy_out.cuda_stream))
-            st["ev_out"] = torch.cuda.Event(enable_timing=_EV_MODE == "timing")
+            st["ev_out"] = torch.cuda.Event()
             st["ev_out"].record(copy_out)
 
         def collect(k):                             # chunk k downloaded -> user-visible output; its staging
             st = stage.pop(k)                       # buffers and device tensors are free again after this
-            if _EV_MODE == "poll":
-                while not st["ev_out"].query():
-                    time.sleep(1e-4)
-            else:
-                st["ev_out"].synchronize()
+            st["ev_out"].synchronize()
             out[st["s"]:st["s"] + st["m"]] = pin_out[k % NS][:st["m"]]
 
         nchunks = 0
