@@ -38,14 +38,27 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
     return pl;
 }
 
+// The classification head can be fused into a plain 3x3 layer whose plan is one of the two thin classes with ONE cout
+// block: 16 couts x 16-row tiles (U-Net's last layer) or <= 32 couts x 8-row tiles (dilnet's).
+static bool head_supported(int Cin_s, int cout, int taps, int dil, int H) {
+    if (taps != 9 || dil != 1) return false;
+    const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H);
+    const int cop = amx_round_up(cout, 16);
+    return (pl.nt == 1 && pl.th == 16 && cop == 16) || (pl.nt == 2 && pl.th == 8 && cop == 32);
+}
+extern "C" int amx_conv2d_head_supported(int Cin_s, int cout, int taps, int dil, int H) {
+    return head_supported(Cin_s, cout, taps, dil, H) ? 1 : 0;
+}
+
 // C ABI — see include/atomai_amd.h for the contract.
 static int conv2d_common(const float* x0, const float* sc0, const float* sh0, int C0s,
                          const float* x1, const float* sc1, const float* sh1, int C1s,
                          const float* wpk, const float* bias, const float* addend,
                          float* y, int Y0s, float* y1, int Y1s, float* stats,
                          int N, int H, int W, int cout, int taps, int dil, float slope, void* stream,
-                         float in_slope0 = 1.f, float in_slope1 = 1.f) {
-    if (!x0 || !wpk || !y) AMX_BADARG(1);
+                         float in_slope0 = 1.f, float in_slope1 = 1.f, const float* hw = nullptr,
+                         const float* hb = nullptr, float* hout = nullptr, int hK = 0, int hmode = 0) {
+    if (!x0 || !wpk || (!y && !hout)) AMX_BADARG(1);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
     if ((C0s & 3) || (C1s & 3) || (Y0s & 3) || (Y1s & 3) || C0s <= 0) AMX_BADARG(3);
     if (taps != 1 && taps != 9) AMX_BADARG(4);
@@ -60,10 +73,10 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.in_slope0 = in_slope0; a.in_slope1 = in_slope1;
     a.wpk = wpk; a.bias = bias; a.addend = addend;
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
-    a.aux0 = nullptr; a.k1 = a.k2 = a.k3 = nullptr; a.bslope = 1.f;      // loader / epilogue fusions of the backward
-    a.ea0 = a.ea1 = nullptr; a.bstats = nullptr;                         // experiment (round 1): not instantiated
+    a.hw = hw; a.hb = hb; a.hout = hout; a.hK = hK; a.hmode = hmode;     // fused classification head (eval) or nullptr
+    a.prof = nullptr;
 #ifdef AMX_CONV_PROFILE
-    a.bstats = (float*)amx_conv_profile_buffer;                          // dev build: per-wave phase timestamps
+    a.prof = (unsigned long long*)amx_conv_profile_buffer;               // dev build: per-wave phase timestamps
 #endif
     a.xcd = 0;
     a.N = N; a.H = H; a.W = W;
@@ -85,6 +98,11 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
         if (dil == 2) return amx_conv_launch_lat2(a, pl.nt, pl.th, tail, s);
         if (dil == 4) return amx_conv_launch_lat4(a, pl.nt, pl.th, tail, s);
         return amx_conv_launch_lat6(a, pl.nt, pl.th, tail, s);
+    }
+    if (hout) {                                             // fused head: plain 3x3, one cout block, the two thin classes
+        if (!head_supported(C0s + C1s, cout, taps, dil, H) || !hw || !hb || hK < 1 || hK > 3 || hmode < 0 || hmode > 1
+            || stats || addend || y1) AMX_BADARG(12);
+        return amx_conv_launch_3x3_head(a, pl.nt, tail, s);
     }
     if (taps == 1) return amx_conv_launch_1x1(a, pl.nt, tail, s);
     if (dil == 1) return amx_conv_launch_3x3(a, pl.nt, pl.th, tail, s);
@@ -111,6 +129,21 @@ extern "C" int amx_conv2d_fwd_act(const float* x0, const float* sc0, const float
     if (!(in_slope0 > 0.f) || !(in_slope1 > 0.f)) AMX_BADARG(11);
     return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, addend, y, Y0s, y1, Y1s, stats, N, H, W,
                          cout, taps, dil, slope, stream, in_slope0, in_slope1);
+}
+
+// amx_conv2d_fwd in eval mode with the network's classification head fused into the epilogue: the layer's activation
+// a = lrelu(conv + bias) is NOT stored; out = head(a) where hw / hb hold the final 1x1 convolution with the layer's own
+// eval-mode BatchNorm affine folded in (hw[k][c] = Wpx[k][c] * scale[c], hb[k] = bpx[k] + sum_c Wpx[k][c] * shift[c]).
+// mode 0: logits NCHW [N][K][H][W]; mode 1: probabilities NHWC [N][H][W][K] (sigmoid if K == 1, else softmax).
+// Replaces conv -> (BatchNorm eval) -> px -> sigmoid/softmax -> permute of SegPredictor.forward_ for the last layer
+// (atomai/nets/fcnn.py:139-142, 224-226; atomai/predictors/predictor.py:219-229).
+extern "C" int amx_conv2d_fwd_head(const float* x0, const float* sc0, const float* sh0, int C0s,
+                                   const float* x1, const float* sc1, const float* sh1, int C1s,
+                                   const float* wpk, const float* bias, const float* hw, const float* hb, float* out,
+                                   int K, int mode, int N, int H, int W, int cout, float slope, void* stream) {
+    if (!out) AMX_BADARG(12);
+    return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, nullptr, nullptr, amx_round_up(cout, 4),
+                         nullptr, 0, nullptr, N, H, W, cout, 9, 1, slope, stream, 1.f, 1.f, hw, hb, out, K, mode);
 }
 
 // Data gradient: forward convolution of dpre (Cs stored channels) with the flipped / transposed weight image

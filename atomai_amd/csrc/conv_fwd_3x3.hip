@@ -16,3 +16,13 @@ int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s
     GO(4, 4);
 #undef GO
 }
+
+// HEAD instantiations (classification head fused into the epilogue, eval mode): the two thin single-block classes
+int amx_conv_launch_3x3_head(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
+#define GO(N_, M_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, true, true>(a, s) \
+                               : launch_conv_fwd<9, N_, 1, true, M_, true, false>(a, s)
+    if (nt == 1) GO(1, 4);
+    GO(2, 2);
+#undef GO
+}
+

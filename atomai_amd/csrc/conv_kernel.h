@@ -59,14 +59,13 @@ struct ConvFwdArgs {
     float* y;  int Y0s;  // first  output: stored channels Y0s, receives couts [0, Y0s)
     float* y1; int Y1s;  // second output (dgrad of a concat) receives couts [Y0s, Y0s+Y1s), or nullptr
     float* stats;        // [tiles][2][cop] (sum, M2) or nullptr
-    // ---- backward fusions (dgrad use of this kernel)
-    const float* aux0;   // activation a of the layer whose gradient src0 (= dy) is: the loader forms
-                         // dpre = lrelu'(a) * (k1*dy + k2*a + k3) on the fly (BatchNorm + LeakyReLU backward)
-    const float* k1; const float* k2; const float* k3;   // [C0s] or nullptr (== 1, 0, 0)
-    float bslope;        // LeakyReLU slope of that layer
-    const float* ea0;    // activation aligned with output y  (or nullptr): epilogue emits per-tile
-    const float* ea1;    // activation aligned with output y1 (or nullptr): (sum dy, sum dy*a) -> bstats
-    float* bstats;       // [tiles][2][cop] or nullptr
+    // ---- fused classification head (HEAD instantiations, eval mode): the layer's own eval-mode BatchNorm affine and
+    // the final 1x1 convolution to K classes are folded into hw / hb on the host; the activation itself is not stored
+    const float* hw;     // [hK][cop]: Wpx[k][c] * scale[c]  (0 beyond cout)
+    const float* hb;     // [hK]:     bpx[k] + sum_c Wpx[k][c] * shift[c]
+    float* hout;         // hmode 0: logits NCHW [N][K][H][W]; 1: probabilities NHWC [N][H][W][K] (sigmoid / softmax)
+    int hK, hmode;
+    unsigned long long* prof;   // AMX_CONV_PROFILE builds: per-wave phase clocks (or nullptr)
     int N, H, W;
     int cout;            // real number of output channels
     int cop;             // cout rounded up to 16
@@ -92,12 +91,12 @@ struct ConvFwdArgs {
 #define AMX_CONV_EXACT 1
 #endif
 // AMX_CONV_PROFILE (dev builds only, tools/gpu_conv_phases.py): every wave records the shader clock at its phase
-// boundaries into the buffer passed through a.bstats: [workgroup][wave][16] 64-bit ticks.
+// boundaries into a.prof: [workgroup][wave][16] 64-bit ticks.
 #ifdef AMX_CONV_PROFILE
 #define AMX_TICK(slot)                                                                                          \
     do {                                                                                                        \
-        if (a.bstats && lane == 0)                                                                              \
-            reinterpret_cast<unsigned long long*>(a.bstats)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (slot)] = \
+        if (a.prof && lane == 0)                                                                                \
+            a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (slot)] = \
                 __builtin_amdgcn_s_memtime();                                                                   \
     } while (0)
 #else
@@ -113,7 +112,7 @@ struct ConvWaves {
                                      : 1;
 };
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false, int LAT = 0>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool HEAD, bool TAIL = false, int LAT = 0>
 __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
     static_assert(LAT == 0 || (TAPS == 9 && MAXHALO == 1 && EXACT), "lattice mode runs the plain 3x3 geometry");
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
@@ -173,9 +172,8 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
 
     float4 xr[XLD];
     float4 wr[WLD];
-    float4 r_sc, r_sh, r_k3;
+    float4 r_sc, r_sh;
     float r_islope = 1.f;                                        // post-affine LeakyReLU slope of this thread's source
-    int r_ch = -1;                                               // FUSED: channel of this thread's group in src0
 
     auto issue_loads = [&](int chunk) {
         const int ch = (chunk * KG + my_kg) * 4;                 // channel in the concatenated space
@@ -185,13 +183,8 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         else if (ch - a.C0s < a.C1s) { src = a.x1; sc = a.sc1; sh = a.sh1; Cs = a.C1s; c = ch - a.C0s; }
         r_sc = make_float4(1.f, 1.f, 1.f, 1.f);
         r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        r_k3 = r_sh;
         if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
         r_islope = src == a.x1 ? a.in_slope1 : a.in_slope0;
-        if (FUSED) {
-            r_ch = src == a.x0 ? c : -1;
-            if (r_ch >= 0 && a.k1) { r_sc = amx_ld4(a.k1 + c); r_sh = amx_ld4(a.k2 + c); r_k3 = amx_ld4(a.k3 + c); }
-        }
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
             xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -220,17 +213,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             const int pix = (tid + i * 256) >> 2;
             if (pix < nslots) {
                 float4 v = xr[i];
-                if (FUSED && a.aux0) {                           // dpre = lrelu'(a) * (k1*dy + k2*a + k3)
-                    // the saved activation is fetched here (not prefetched): keeps the register footprint, and
-                    // with it the number of co-resident workgroups, equal to the plain kernel's
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (x_off[i] >= 0 && r_ch >= 0) t = amx_ld4(a.aux0 + (size_t)x_off[i] * a.C0s + r_ch);
-                    v.x = (t.x > 0.f ? 1.f : a.bslope) * fmaf(r_sc.x, v.x, fmaf(r_sh.x, t.x, r_k3.x));
-                    v.y = (t.y > 0.f ? 1.f : a.bslope) * fmaf(r_sc.y, v.y, fmaf(r_sh.y, t.y, r_k3.y));
-                    v.z = (t.z > 0.f ? 1.f : a.bslope) * fmaf(r_sc.z, v.z, fmaf(r_sh.z, t.z, r_k3.z));
-                    v.w = (t.w > 0.f ? 1.f : a.bslope) * fmaf(r_sc.w, v.w, fmaf(r_sh.w, t.w, r_k3.w));
-                    if (x_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                } else if (x_off[i] >= 0) {                      // padding stays exactly zero
+                if (x_off[i] >= 0) {                             // padding stays exactly zero
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
                     v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
                     if (r_islope != 1.f) {
@@ -458,6 +441,14 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     constexpr int MH = MTW < 2 ? MTW : 2;
     constexpr int CG = NB / 4;                                   // float4 groups per pixel
     float* s_epi = smem + (size_t)wave * (MH * TILE * NB);
+    // HEAD: this lane's slice (4 couts) of the folded head weights; lane % CG is the lane's float4 group of a pixel in
+    // every iteration of the loops below (64 and MH * TILE * CG are multiples of CG)
+    float4 hwq[HEAD ? 3 : 1];
+    if (HEAD) {
+        #pragma unroll
+        for (int k = 0; k < 3; ++k)
+            hwq[k] = k < a.hK ? amx_ld4(a.hw + (size_t)k * a.cop + (lane % CG) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     #pragma unroll
     for (int m0 = 0; m0 < MTW; m0 += MH) {
         #pragma unroll
@@ -475,6 +466,35 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             const int mm = pix / TILE, x = pix - mm * TILE;
             const int oy = ry + (oy0 + m0 + mm) * LS, ox = rx + (tx * TILE + x) * LS;
             const int co = n0 + cgp * 4;
+            if (HEAD) {
+                // the final 1x1 convolution (own BatchNorm affine folded in) on the transposed tile: each of the CG
+                // lanes of a pixel contracts its 4 couts, a butterfly over those lanes sums them; the activation is
+                // not written at all
+                const float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
+                float lg[3];
+                #pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float d = v.x * hwq[k].x + v.y * hwq[k].y + v.z * hwq[k].z + v.w * hwq[k].w;
+                    #pragma unroll
+                    for (int o = 1; o < CG; o <<= 1) d += __shfl_xor(d, o);
+                    lg[k] = d + (k < a.hK ? a.hb[k] : 0.f);
+                }
+                if (cgp == 0 && oy < a.H && ox < a.W) {
+                    const size_t pq = (size_t)(n * a.H + oy) * a.W + ox;
+                    if (a.hmode == 0) {
+                        for (int k = 0; k < a.hK; ++k) a.hout[((size_t)n * a.hK + k) * a.H * a.W + (size_t)oy * a.W + ox] = lg[k];
+                    } else if (a.hK == 1) {
+                        a.hout[pq] = 1.f / (1.f + expf(-lg[0]));
+                    } else {
+                        float mx = lg[0];
+                        for (int k = 1; k < a.hK; ++k) mx = fmaxf(mx, lg[k]);
+                        float sme = 0.f;
+                        for (int k = 0; k < a.hK; ++k) { lg[k] = expf(lg[k] - mx); sme += lg[k]; }
+                        for (int k = 0; k < a.hK; ++k) a.hout[pq * a.hK + k] = lg[k] / sme;
+                    }
+                }
+                continue;
+            }
             if (oy < a.H && ox < a.W && co < ctot) {
                 float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
                 float* dst; int Cd, cd;
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     AMX_TICK(13);
 }
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool FUSED, bool TAIL = false, int LAT = 0>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool HEAD, bool TAIL = false, int LAT = 0>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? (LAT ? 1 : a.dil) : 0;
     const int I = TILE + 2 * halo;
@@ -510,13 +530,13 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL, LAT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, HEAD, TAIL, LAT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, FUSED, TAIL, LAT>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, HEAD, TAIL, LAT>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -524,6 +544,7 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 // dispatchers of the three instantiation units (nt in {1,2,4}; th in {8,16})
 int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
+int amx_conv_launch_3x3_head(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_lat2(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);   // lattice mode, dilation 2 / 4 / 6
 int amx_conv_launch_lat4(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);

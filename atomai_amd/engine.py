@@ -732,6 +732,61 @@ class OutputNode(_Node):
         tape.accumulate(s, g)
 
 
+FUSE_HEAD = _os.environ.get("AMX_FUSE_HEAD", "1") != "0"      # experiment switch: classification head in the conv epilogue
+
+
+def head_fusable(tape, srcs: Sequence[Act], conv, px) -> bool:
+    """Can `px` (the net's final 1x1 convolution) be evaluated in the epilogue of `conv` (its last 3x3 layer)?  Eval
+    mode only (in training the layer's BatchNorm statistics do not exist before the layer has been computed)."""
+    if not FUSE_HEAD or tape.training or tape.need_grad or px.weight.shape[0] > 3:
+        return False
+    if tuple(conv.kernel_size) != (3, 3) or tuple(conv.dilation) != (1, 1) or tuple(px.kernel_size) != (1, 1):
+        return False
+    if any(s.post_slope != 1.0 for s in srcs):
+        return False
+    cin_s = sum(s.Cs for s in srcs)
+    return bool(L.load().amx_conv2d_head_supported(cin_s, conv.weight.shape[0], 9, 1, srcs[0].H))
+
+
+class HeadNode(_Node):
+    """Last 3x3 layer of a net in eval mode with the classification head fused into its epilogue
+    (amx_conv2d_fwd_head): value = logits NCHW (mode 0) or probabilities NHWC (mode 1); the layer's activation never
+    reaches HBM."""
+
+    def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, px, mode: int):
+        s0 = srcs[0]
+        s1 = srcs[1] if len(srcs) > 1 else None
+        N, H, W = s0.N, s0.H, s0.W
+        C0, C0s = s0.C, s0.Cs
+        C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
+        w, b = conv.weight, conv.bias
+        cout, K = w.shape[0], px.weight.shape[0]
+        cos, cop = r4(cout), r16(cout)
+        assert w.shape[1] == C0 + C1 and px.weight.shape[1] == cout
+        wpk = pack_weights(w, C0, C0s, C1, C1s, 9, 0)
+        Wp = px.weight.detach().reshape(K, cout)
+        hw = torch.zeros((K, cop), dtype=torch.float32, device=s0.t.device)
+        if bn is not None:                                   # fold the layer's own eval-mode affine into the head
+            scale, shift = _empty((cos,), s0.t), _empty((cos,), s0.t)
+            L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
+                   L.ptr(bn.running_var), bn.eps, cout, cos, L.ptr(scale), L.ptr(shift), _sp(s0.t))
+            hw[:, :cout] = Wp * scale[:cout]
+            hb = (px.bias.detach() + (Wp * shift[:cout]).sum(1)).contiguous()
+        else:
+            hw[:, :cout] = Wp
+            hb = px.bias.detach().contiguous()
+        shape = (N, K, H, W) if mode == 0 else (N, H, W, K)
+        self.value = _empty(shape, s0.t)
+        L.call("amx_conv2d_fwd_head", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
+               L.ptr(s1.t if s1 else None), L.ptr(s1.scale if s1 else None), L.ptr(s1.shift if s1 else None), C1s,
+               L.ptr(wpk), L.ptr(b.detach() if b is not None else None), L.ptr(hw), L.ptr(hb), L.ptr(self.value),
+               K, mode, N, H, W, cout, float(slope), _sp(s0.t))
+        self.grad_out = None
+
+    def backward(self, tape) -> None:
+        raise AssertionError("the fused head exists in eval mode only")
+
+
 class PxNode(_Node):
     """Final 1x1 conv to nb_classes; logits NCHW (mode 0) or probabilities NHWC (mode 1)."""
 
@@ -888,6 +943,9 @@ class Tape:
 
     def px(self, src: Act, conv, mode: int = 0) -> PxNode:
         return self._push(PxNode(self, src, conv, mode))
+
+    def conv_head(self, srcs, conv, bn, slope: float, px, mode: int = 0) -> HeadNode:
+        return HeadNode(self, srcs, conv, bn, slope, px, mode)
 
     # ---- backward helpers
     def accumulate(self, act: Act, g: torch.Tensor) -> None:

@@ -91,8 +91,14 @@ class ConvBlock(_HipBlock):
                 block.append(nn.BatchNorm2d(output_channels))
         self.block = nn.Sequential(*block)
 
-    def _emit(self, tape, srcs):
-        for conv, slope, bn, drop in _layers(self.block):
+    def _emit(self, tape, srcs, head=None):
+        """head = (px conv, mode): the net's classification head, evaluated in the epilogue of this block's last layer
+        when that is possible (eval mode; engine.head_fusable) — then the fused node is returned instead of an Act."""
+        from ..engine import head_fusable
+        layers = _layers(self.block)
+        for i, (conv, slope, bn, drop) in enumerate(layers):
+            if head is not None and i == len(layers) - 1 and head_fusable(tape, srcs, conv, head[0]):
+                return tape.conv_head(srcs, conv, bn, slope, head[0], head[1])
             srcs = [tape.conv(srcs, conv, bn, slope, drop_p=_drop_p(drop))]
         return srcs[0]
 

@@ -70,8 +70,8 @@ class Unet(_HipNet):
         u2 = self.upsample_block2._emit(tape, [u3])
         u2 = self.c5._emit(tape, [c2, u2])
         u1 = self.upsample_block3._emit(tape, [u2])
-        u1 = self.c6._emit(tape, [c1, u1])
-        return node, tape.px(u1, self.px, px_mode)
+        u1 = self.c6._emit(tape, [c1, u1], head=(self.px, px_mode))
+        return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
 
     def _modular(self, x):
         import torch.nn.functional as F   # only glue between separately-emitted HIP blocks
@@ -119,8 +119,8 @@ class dilnet(_HipNet):
         at1 = self.at1._emit(tape, [d1])
         at2 = self.at2._emit(tape, [at1])
         u1 = self.up1._emit(tape, [at2])
-        u1 = self.c2._emit(tape, [c1, u1])
-        return node, tape.px(u1, self.px, px_mode)
+        u1 = self.c2._emit(tape, [c1, u1], head=(self.px, px_mode))
+        return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
 
     def _modular(self, x):
         import torch.nn.functional as F

@@ -40,6 +40,17 @@ int amx_conv2d_fwd(const float* x0, const float* sc0, const float* sh0, int C0s,
                    const float* wpk, const float* bias, const float* addend,
                    float* y, int Y0s, float* y1, int Y1s, float* stats,
                    int N, int H, int W, int cout, int taps, int dil, float slope, void* stream);
+/* Eval-mode last layer with the classification head fused into its epilogue (atomai/nets/fcnn.py:139-142, 224-226 +
+ * the sigmoid / softmax / permute of atomai/predictors/predictor.py:219-229): out = head(lrelu(conv + bias)), the
+ * activation itself is not stored.  hw [K][round_up(cout,16)] / hb [K]: the final 1x1 convolution with the layer's own
+ * eval-mode BatchNorm affine folded in (hw[k][c] = Wpx[k][c] * scale[c], hb[k] = bpx[k] + sum_c Wpx[k][c] * shift[c]).
+ * mode 0: logits NCHW; 1: probabilities NHWC.  K <= 3.  Only for layers amx_conv2d_head_supported returns 1 for
+ * (plain 3x3, one cout block, <= 32 couts). */
+int amx_conv2d_head_supported(int Cin_s, int cout, int taps, int dil, int H);
+int amx_conv2d_fwd_head(const float* x0, const float* sc0, const float* sh0, int C0s,
+                        const float* x1, const float* sc1, const float* sh1, int C1s,
+                        const float* wpk, const float* bias, const float* hw, const float* hb, float* out,
+                        int K, int mode, int N, int H, int W, int cout, float slope, void* stream);
 int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
                      int Y1s, int N, int H, int W, int taps, int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);

@@ -193,6 +193,47 @@ def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1)
             np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.numpy(), rtol=1e-4, atol=1e-6)
 
 
+def check_head_fusion(device):
+    """Eval mode: the final 1x1 convolution (+ sigmoid / softmax) evaluated in the epilogue of the last 3x3 layer must
+    agree with the separate head kernel (different summation order: 1e-6), for probabilities and for raw logits."""
+    import atomai_amd as aoi
+    from atomai_amd import engine
+    from atomai_amd.nets.fcnn import predict_proba
+    rs = np.random.RandomState(4)
+    made = []
+    orig = engine.HeadNode.__init__
+
+    def counting(self, *a, **k):
+        made.append(1)
+        return orig(self, *a, **k)
+    engine.HeadNode.__init__ = counting
+    try:
+        for name, ncls, kw, hw in (("Unet", 3, dict(nb_filters=4), (24, 40)), ("dilnet", 1, dict(nb_filters=5), (22, 38)),
+                                   ("Unet", 1, dict(nb_filters=16, batch_norm=False), (16, 16)),
+                                   ("dilnet", 2, dict(nb_filters=25), (12, 20))):
+            torch.manual_seed(6)
+            net, _ = aoi.nets.init_fcnn_model(name, ncls, **kw)
+            net = net.to(device)
+            net.train()
+            with torch.no_grad():                            # non-trivial running statistics
+                net(torch.from_numpy(rs.rand(2, 1, *hw).astype(np.float32)).to(device))
+            net.eval()
+            x = torch.from_numpy(rs.rand(3, 1, *hw).astype(np.float32)).to(device)
+            res = {}
+            for fuse in (True, False):
+                engine.FUSE_HEAD = fuse
+                n0 = len(made)
+                with torch.no_grad():
+                    res[fuse] = (predict_proba(net, x), net(x))
+                assert (len(made) - n0 == 2) == fuse, (name, fuse)
+            for a, b in zip(res[True], res[False]):
+                assert a.shape == b.shape
+                assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max())), name
+    finally:
+        engine.HeadNode.__init__ = orig
+        engine.FUSE_HEAD = True
+
+
 def check_input_norm_fusion(device):
     """The predictor's stack normalisation applied inside the first-layer kernel (Unet / dilnet) or by the separate
     pass (nets with another first layer) gives bit-identical probabilities to normalising first."""

@@ -154,3 +154,7 @@ def test_dilated_layers_halo_class_kernels_still_agree(monkeypatch):
 
 def test_input_normalisation_inside_the_first_layer_kernel():
     C.check_input_norm_fusion("cpu")
+
+
+def test_classification_head_in_the_last_conv_epilogue():
+    C.check_head_fusion("cpu")

@@ -228,3 +228,7 @@ def test_convblock_training_dropout(bn):
 
 def test_input_normalisation_inside_the_first_layer_kernel():
     C.check_input_norm_fusion("cuda")
+
+
+def test_classification_head_in_the_last_conv_epilogue():
+    C.check_head_fusion("cuda")

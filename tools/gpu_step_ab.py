@@ -26,6 +26,7 @@ def setenv(v):
     _lib._lib = _libs[name]
     from atomai_amd import engine
     engine._pack_cache.store.clear()      # weight images are library-specific (layout of a partial last K chunk)
+    engine.FUSE_HEAD = os.environ.get("AMX_FUSE_HEAD", "1") != "0"     # (python-level switch)
 
 
 rs = np.random.RandomState(0)
