@@ -242,7 +242,9 @@ def check_input_norm_fusion(device):
     rs = np.random.RandomState(2)
     x = torch.from_numpy((rs.rand(3, 1, 24, 40) * 37 - 5).astype(np.float32)).to(device)
     mn, ptp = np.float32(x.min().item()), np.float32((x.max() - x.min()).item())
-    xn = ((x - float(mn)) / float(ptp)).contiguous()
+    from atomai_amd import _lib as L
+    xn = torch.empty_like(x)                                 # the predictor's separate normalisation pass
+    L.call("amx_sub_div", L.ptr(x), L.ptr(xn), x.numel(), float(mn), float(ptp), L.stream_ptr(x))
     for name, ncls, kw, fused in (("Unet", 3, dict(nb_filters=4), True), ("dilnet", 1, dict(nb_filters=5), True),
                                   ("SegResNet", 2, dict(nb_filters=4), False)):
         torch.manual_seed(5)
