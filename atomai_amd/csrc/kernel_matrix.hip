@@ -15,7 +15,9 @@
 #include <cstdlib>
 
 #define KM_MAXD 16
-#define KM_ROWS 32            // rows of K per workgroup
+// rows of K per workgroup of the builder: measured (tools/gpu_km_ab.py, 16384^2): fp32 32 rows 5.6 TB/s / 64 rows 5.0;
+// fp64 32 rows 4.1 / 64 rows 4.7
+template <typename T> struct KmRows { static constexpr int value = sizeof(T) == 4 ? 32 : 64; };
 
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { static constexpr int N = 4; };
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
                                                             int getenv_nt) {
     constexpr int V = Vec16<T>::N;
     constexpr int COLS = 64 * V;                         // columns per workgroup
+    constexpr int KM_ROWS = KmRows<T>::value;
     __shared__ T s_x1[KM_ROWS * KM_MAXD];
     __shared__ T s_x2[KM_MAXD * COLS];                   // [d][col]
     const int tid = threadIdx.x;
@@ -76,6 +79,15 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
     }
     __syncthreads();
     const int cg = tid & 63, rg = tid >> 6;              // 64 column groups x 4 row groups
+    // a thread's V columns are the same for every row it writes: for the usual small embedding (D <= 4; dklGPR's
+    // default is 2) their scaled coordinates live in registers and the row loop only reads the row's coordinates
+    // (one broadcast LDS read per dimension) — the [d][col] reads were 8-way bank-conflicted (stride-V lanes)
+    constexpr int DR = 4;
+    T x2r[V][DR];
+    #pragma unroll
+    for (int v = 0; v < V; ++v)
+        #pragma unroll
+        for (int d = 0; d < DR; ++d) x2r[v][d] = d < D ? s_x2[d * COLS + cg * V + v] : T(0);
     #pragma unroll 2
     for (int rr = 0; rr < KM_ROWS / 4; ++rr) {
         const int r = rg * (KM_ROWS / 4) + rr;
@@ -86,9 +98,18 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
         for (int v = 0; v < V; ++v) {
             const int c = cg * V + v;
             T r2 = T(0);
-            for (int d = 0; d < D; ++d) {
-                const T df = s_x1[r * D + d] - s_x2[d * COLS + c];
-                r2 += df * df;
+            if (D <= DR) {
+                #pragma unroll
+                for (int d = 0; d < DR; ++d) {
+                    if (d >= D) break;
+                    const T df = s_x1[r * D + d] - x2r[v][d];
+                    r2 += df * df;
+                }
+            } else {
+                for (int d = 0; d < D; ++d) {
+                    const T df = s_x1[r * D + d] - s_x2[d * COLS + c];
+                    r2 += df * df;
+                }
             }
             T w;
             T k;
@@ -116,7 +137,7 @@ template <typename T>
 static int launch_km(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, double noise,
                      int N, int M, int D, void* K, hipStream_t st) {
     constexpr int COLS = 64 * Vec16<T>::N;
-    dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KM_ROWS));
+    dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KmRows<T>::value));
     AMX_LAUNCH(kernel_matrix_kernel<T>, grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
                (T)s2, kind, (T)noise, N, M, D, (T*)K, getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 3);   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp
     AMX_CHECK_LAUNCH();
