@@ -12,5 +12,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d /root/repo/gpurun_out/r02_pmc_$c -o pmc --output-format csv -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra --sustain-seconds 0 > /root/repo/gpurun_out/r02_pmc_$c.log 2>&1
 done
 cd /root/repo
+( timeout 900 python tools/bench_extra.py predict rvae dkl locate segfamily ) > gpurun_out/r02_bench_extra.log 2>&1
 echo $HEAD > gpurun_out/r02_head.txt
 echo "== pytest"; tail -3 gpurun_out/r02_pytest_gpu.log; echo "== smoke"; tail -2 gpurun_out/r02_smoke.log; echo "== bench"; tail -5 gpurun_out/r02_bench_n1.log | cut -c1-1500; echo "== rocprof"; ls gpurun_out/r02_prof_serial gpurun_out/r02_prof gpurun_out/r02_pmc_FETCH_SIZE 2>&1 | head -12
