@@ -90,6 +90,23 @@ struct ConvFwdArgs {
 #ifndef AMX_CONV_EXACT
 #define AMX_CONV_EXACT 1
 #endif
+// AMX_CONV_GLDS 1: the weight image of a chunk goes global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of
+// through WLD float4 registers per thread (-20 VGPRs on the 32-cout classes, no ds_write pass); the DMA of chunk c+1 can
+// only be issued after the barrier that ends chunk c (the weight image is single-buffered), so its latency is exposed.
+// Measured (gpurun_out/r02y_probe.log, r02y_step_ab.log): at 4 waves/SIMD +1..5 % on the <= 32-channel layers, -1.5 % on
+// the 128-channel ones, 19.28 -> 19.35 ms in the step; asking for 5 waves/SIMD (AMX_CONV_GLDS_WAVES) spills 15 registers
+// on the 32-cout class and is 3-10 % slower, and the 16-cout class, which fits 5 waves without spilling, gains nothing.
+// Off by default.
+#ifndef AMX_CONV_GLDS
+#define AMX_CONV_GLDS 0
+#endif
+#ifndef AMX_CONV_GLDS_WAVES
+#define AMX_CONV_GLDS_WAVES 5       // waves per SIMD requested for the 8-row thin classes when the weights go by LDS-DMA
+#endif
+#if defined(AMX_EMU)
+#undef AMX_CONV_GLDS
+#define AMX_CONV_GLDS 0
+#endif
 // AMX_CONV_PROFILE (dev builds only, tools/gpu_conv_phases.py): every wave records the shader clock at its phase
 // boundaries into a.prof: [workgroup][wave][16] 64-bit ticks.
 #ifdef AMX_CONV_PROFILE
@@ -108,7 +125,7 @@ struct ConvFwdArgs {
 template <int TAPS, int NT, int MAXHALO, int MTW, bool TAIL>
 struct ConvWaves {
     static constexpr int value = (TAPS == 9 && MAXHALO == 1)
-                                     ? ((MTW == 2 && NT <= 2) ? 4 : ((MTW == 4 && NT == 1) ? 3 : 1))
+                                     ? ((MTW == 2 && NT <= 2) ? (AMX_CONV_GLDS ? AMX_CONV_GLDS_WAVES : 4) : ((MTW == 4 && NT == 1) ? 3 : 1))
                                      : 1;
 };
 
@@ -190,6 +207,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
         }
+#if !AMX_CONV_GLDS
         const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
 #ifdef AMX_CONV_NOWLOAD      // TIMING EXPERIMENT ONLY (wrong results): what would a resident weight image save?
         if (chunk > 0 || blockIdx.x > 4096) return;
@@ -203,7 +221,27 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 if (n0 + col < a.cop) wr[i] = amx_ld4(wsrc + ((size_t)row * a.cop + n0 + col) * 4);
             }
         }
+#endif
     };
+#if AMX_CONV_GLDS
+    // weight image of a chunk by LDS-DMA: one wave instruction moves 1 KiB = 64 / NB rows of the [TAPS*KG][NB][4] image
+    // (LDS destination = wave-uniform base + lane * 16 B, the global source is per lane)
+    auto dma_weights = [&](int chunk) {
+        const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
+        float* s_w = smem + KG * plane * 4;
+        constexpr int NI = (TAPS * KG * NB + 63) / 64;           // wave instructions per chunk
+        #pragma unroll
+        for (int i = 0; i < (NI + 3) / 4; ++i) {
+            const int ii = wave + 4 * i;
+            if (ii < NI) {
+                const int idx = ii * 64 + lane;
+                const int row = idx / NB, col = idx - row * NB;
+                if (idx < TAPS * KG * NB && n0 + col < a.cop)
+                    __builtin_amdgcn_global_load_lds(wsrc + ((size_t)row * a.cop + n0 + col) * 4, s_w + (size_t)ii * 256, 16, 0, 0);
+            }
+        }
+    };
+#endif
 
     auto stage_to_lds = [&](int stage, bool tchunk) {
         float* s_in = smem + (size_t)stage * stage_floats;
@@ -238,11 +276,13 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
 #ifdef AMX_CONV_NOWLOAD
         if (blockIdx.x > 4096) return;
 #endif
+#if !AMX_CONV_GLDS
         #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int idx = tid + i * 256;
             if (idx < TAPS * KG * NB) amx_st4(s_w + (size_t)idx * 4, wr[i]);
         }
+#endif
     };
 
     f32x4 acc[MTW][NT];
@@ -362,6 +402,9 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         bias_q[q] = (PREB && a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
     issue_loads(0);
+#if AMX_CONV_GLDS
+    dma_weights(0);
+#endif
     AMX_TICK(1);
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         stage_to_lds(0, TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG);
@@ -374,6 +417,9 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         else compute_taps(0, 0, TAPS);
         if (chunk < 2) AMX_TICK(5 + 5 * chunk);
         __syncthreads();
+#if AMX_CONV_GLDS
+        if (chunk + 1 < a.nchunk) dma_weights(chunk + 1);        // (after the barrier: every wave is done with chunk's image)
+#endif
         if (chunk < 2) AMX_TICK(6 + 5 * chunk);
     }
 
