@@ -54,22 +54,6 @@ static __device__ __forceinline__ void amx_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
 }
-// A value the programmer knows to be wave-uniform (e.g. threadIdx.x >> 6), moved to a scalar register so that everything
-// derived from it runs on the scalar unit instead of occupying vector issue slots next to the MFMAs.
-static __device__ __forceinline__ int amx_uniform(int v) {
-#ifdef AMX_EMU
-    return v;
-#else
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
-// Scheduling fence: nothing is moved across it by the instruction scheduler (used to keep operand prefetches ahead
-// of the MFMA burst they are meant to overlap with).  No code is emitted.
-static __device__ __forceinline__ void amx_sched_fence() {
-#ifndef AMX_EMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 static __device__ __forceinline__ float4 amx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 static __device__ __forceinline__ void amx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // XCD-aware block index: the dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup

@@ -32,7 +32,7 @@
 //     unit of a global access is one pixel's 64-byte channel group either way.
 //   * Measured and rejected in round 2 (profiles/r02_conv_persistent_ab.md): persistent workgroups walking several
 //     tiles with cross-tile register prefetch, weight images kept resident in LDS for <= 2-chunk layers, and operand
-//     fragments software-pipelined across taps (AMX_CONV_SWP) — no gain over one workgroup per tile (the hardware
+//     fragments software-pipelined across taps — no gain over one workgroup per tile (the hardware
 //     dispatcher hides workgroup turnover), slower where the extra state costs a co-resident workgroup.
 //   * global->register prefetch of chunk c+1 is issued before the MFMA phase of chunk c; the BN affine and the zero
 //     padding are applied when registers are written to LDS (padding must stay zero AFTER the affine, so it cannot
@@ -82,11 +82,7 @@ struct ConvFwdArgs {
 // extra unrolled tap loop costs code and registers that the layers with channel counts in multiples of 16 need not pay.
 //
 // Compile-time experiment switches (tools/build_variant_lib.sh builds one library per combination for in-process A/B):
-//   AMX_CONV_SWP    1: operand fragments of tap t+1 are read into a second register set before tap t's MFMAs
 //   AMX_CONV_EXACT  0: instantiations marked EXACT still read the dilation from the arguments (round-1 behaviour)
-#ifndef AMX_CONV_SWP
-#define AMX_CONV_SWP 0
-#endif
 #ifndef AMX_CONV_EXACT
 #define AMX_CONV_EXACT 1
 #endif
@@ -209,9 +205,6 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         }
 #if !AMX_CONV_GLDS
         const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
-#ifdef AMX_CONV_NOWLOAD      // TIMING EXPERIMENT ONLY (wrong results): what would a resident weight image save?
-        if (chunk > 0 || blockIdx.x > 4096) return;
-#endif
         #pragma unroll
         for (int i = 0; i < WLD; ++i) {
             const int idx = tid + i * 256;                       // over [TAPS*KG][NB]
@@ -273,9 +266,6 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 }
             }
         }
-#ifdef AMX_CONV_NOWLOAD
-        if (blockIdx.x > 4096) return;
-#endif
 #if !AMX_CONV_GLDS
         #pragma unroll
         for (int i = 0; i < WLD; ++i) {
@@ -291,46 +281,6 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         #pragma unroll
         for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#if AMX_CONV_SWP
-    // software-pipelined operand fragments (experiment): tap t+1's ds_read_b128s are issued into a second register
-    // set before tap t's MFMAs
-    auto compute_taps = [&](int stage, int tap0, int tap1) {
-        const float* s_in = smem + (size_t)stage * stage_floats;
-        const float* s_w = s_in + KG * plane * 4;
-        auto load_frag = [&](int tap, float4* af, float4* bf) {
-            const int dy = (TAPS == 9) ? (tap / 3 - 1) * halo : 0;
-            const int dx = (TAPS == 9) ? (tap % 3 - 1) * halo : 0;
-            #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int slot = (wave * MTW + m + halo + dy) * IW + (p + halo + dx);
-                af[m] = amx_ld4(s_in + ((size_t)g * plane + slot) * 4);
-            }
-            #pragma unroll
-            for (int q = 0; q < NT; ++q)
-                bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
-        };
-        #define AMX_CONV_MFMA(A_, B_, C)                                                            \
-            _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
-                _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m].C, B_[q].C, acc[m][q], 0, 0, 0);
-        #define AMX_CONV_TAP(A_, B_) AMX_CONV_MFMA(A_, B_, x) AMX_CONV_MFMA(A_, B_, y) AMX_CONV_MFMA(A_, B_, z) AMX_CONV_MFMA(A_, B_, w)
-        float4 af0[MTW], bf0[NT], af1[MTW], bf1[NT];
-        load_frag(0, af0, bf0);
-        #pragma unroll
-        for (int tap = 0; tap < TAPS; tap += 2) {
-            if (tap + 1 < TAPS) load_frag(tap + 1, af1, bf1);
-            amx_sched_fence();                                   // the reads of tap+1 stay ahead of this tap's MFMAs
-            AMX_CONV_TAP(af0, bf0)
-            if (tap + 1 < TAPS) {
-                if (tap + 2 < TAPS) load_frag(tap + 2, af0, bf0);
-                amx_sched_fence();
-                AMX_CONV_TAP(af1, bf1)
-            }
-        }
-        #undef AMX_CONV_TAP
-        #undef AMX_CONV_MFMA
-    };
-#else
     auto compute_taps = [&](int stage, int tap0, int tap1) {
         const float* s_in = smem + (size_t)stage * stage_floats;
         const float* s_w = s_in + KG * plane * 4;
@@ -358,7 +308,6 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             #undef AMX_CONV_MFMA
         }
     };
-#endif
 
     // Last chunk with fewer than KG valid k-groups (channel counts that are not multiples of 16, e.g. dilnet's
     // 25 / 50 filters -> 28 / 52 stored channels).  That chunk sits TRANSPOSED in LDS (stage_to_lds / pack.hip): the
