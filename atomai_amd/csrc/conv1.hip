@@ -215,15 +215,16 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     }
     #pragma unroll
     for (int t = 0; t < 10; ++t) {
-        if (t >= nrow) break;
-        if (active) amx_st4(s + ((size_t)pl * Cs + cg * 4), acc[t]);
-        __syncthreads();
-        for (int c = tid; c < Cs; c += 256) {
-            float a = 0.f;
-            for (int q = 0; q < PL; ++q) a += s[(size_t)q * Cs + c];
-            part[((size_t)blockIdx.x * nrow + t) * Cs + c] = a;
+        if (t < nrow) {                              // (uniform; no `break`, so that the loop unrolls and acc stays in registers)
+            if (active) amx_st4(s + ((size_t)pl * Cs + cg * 4), acc[t]);
+            __syncthreads();
+            for (int c = tid; c < Cs; c += 256) {
+                float a = 0.f;
+                for (int q = 0; q < PL; ++q) a += s[(size_t)q * Cs + c];
+                part[((size_t)blockIdx.x * nrow + t) * Cs + c] = a;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
