@@ -5,6 +5,11 @@
 //   select_loss('ce'): CrossEntropyLoss (nb_classes > 2) / BCEWithLogitsLoss (== 1)   atomai/losses_metrics/losses.py:152-155
 //   SegPredictor.forward_: softmax(dim=1) / sigmoid, permute to NHWC     atomai/predictors/predictor.py:219-229
 #include "amx_device.h"
+#ifndef AMX_HEAD_DIV
+#define AMX_HEAD_DIV 1          // (image, pixel) of a linear index: 1 = 64-bit division per pixel, 0 = carry-advanced.
+                                // Measured in isolation (tools/gpu_small_kernels_ab.py): px_bwd 317 vs 390 us, px_fwd 141
+                                // vs 149 us -> the division stays
+#endif
 
 #define MAXCLS 8
 
@@ -24,7 +29,11 @@ __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a
     const long stride = (long)gridDim.x * 256;
     long n = ((long)blockIdx.x * 256 + threadIdx.x) / HW, hw = ((long)blockIdx.x * 256 + threadIdx.x) - n * HW;
     for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride, hw += stride) {
+#if AMX_HEAD_DIV
+        n = p / HW; hw = p - n * HW;
+#else
         while (hw >= HW) { hw -= HW; ++n; }                  // (image, pixel) of p without a division per pixel
+#endif
         float acc[MAXCLS];
         #pragma unroll
         for (int k = 0; k < MAXCLS; ++k) acc[k] = k < K ? b[k] : 0.f;
@@ -118,7 +127,11 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
         // kernel's instructions
         long n = (p0 + pl) / HW, hw = (p0 + pl) - n * HW;
         for (long p = p0 + pl; p < p1; p += PL, hw += PL) {
+#if AMX_HEAD_DIV
+            n = p / HW; hw = p - n * HW;
+#else
             while (hw >= HW) { hw -= HW; ++n; }
+#endif
             float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
             const float4 raw = v;
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
@@ -206,7 +219,11 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     const long stride = (long)gridDim.x * 256;
     long n = ((long)blockIdx.x * 256 + tid) / HW, hw = ((long)blockIdx.x * 256 + tid) - n * HW;
     for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += stride, hw += stride) {
+#if AMX_HEAD_DIV
+        n = p / HW; hw = p - n * HW;
+#else
         while (hw >= HW) { hw -= HW; ++n; }                  // (no 64-bit division per pixel)
+#endif
         const float* xp = x + (size_t)n * K * HW + hw;
         float v[MAXCLS];
         float mx = -3.4e38f;
