@@ -50,14 +50,35 @@ extern "C" int amx_conv2d_head_supported(int Cin_s, int cout, int taps, int dil,
     return head_supported(Cin_s, cout, taps, dil, H) ? 1 : 0;
 }
 
+// The sum of a DilatedBlock can be fused into its last layer when that layer runs in lattice mode on the 8-row,
+// 32-couts-per-block class (dilnet's 25 / 50-filter blocks).
+static bool dsum_supported(int Cin_s, int cout, int taps, int dil, int H) {
+    if (!amx_lattice_mode(taps, dil)) return false;
+    const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H);
+    return pl.nt == 2 && pl.th == 8;
+}
+extern "C" int amx_conv2d_dsum_supported(int Cin_s, int cout, int taps, int dil, int H) {
+    return dsum_supported(Cin_s, cout, taps, dil, H) ? 1 : 0;
+}
+
+// epilogue extras of the eval-mode fusions (classification head / DilatedBlock sum)
+struct ConvEpi {
+    const float* hw = nullptr; const float* hb = nullptr; float* hout = nullptr; int hK = 0, hmode = 0;
+    const float* ds_a[3] = {nullptr, nullptr, nullptr};
+    const float* ds_sc[4] = {nullptr, nullptr, nullptr, nullptr}; const float* ds_sh[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nds = 0; float ds_inv_slope = 1.f;
+};
+
 // C ABI — see include/atomai_amd.h for the contract.
 static int conv2d_common(const float* x0, const float* sc0, const float* sh0, int C0s,
                          const float* x1, const float* sc1, const float* sh1, int C1s,
                          const float* wpk, const float* bias, const float* addend,
                          float* y, int Y0s, float* y1, int Y1s, float* stats,
                          int N, int H, int W, int cout, int taps, int dil, float slope, void* stream,
-                         float in_slope0 = 1.f, float in_slope1 = 1.f, const float* hw = nullptr,
-                         const float* hb = nullptr, float* hout = nullptr, int hK = 0, int hmode = 0) {
+                         float in_slope0 = 1.f, float in_slope1 = 1.f, const ConvEpi* epi = nullptr) {
+    const float* hw = epi ? epi->hw : nullptr; const float* hb = epi ? epi->hb : nullptr;
+    float* hout = epi ? epi->hout : nullptr; const int hK = epi ? epi->hK : 0, hmode = epi ? epi->hmode : 0;
+    const int nds = epi ? epi->nds : 0;
     if (!x0 || !wpk || (!y && !hout)) AMX_BADARG(1);
     if (N <= 0 || H <= 0 || W <= 0 || cout <= 0) AMX_BADARG(2);
     if ((C0s & 3) || (C1s & 3) || (Y0s & 3) || (Y1s & 3) || C0s <= 0) AMX_BADARG(3);
@@ -74,6 +95,9 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.wpk = wpk; a.bias = bias; a.addend = addend;
     a.y = y; a.Y0s = Y0s; a.y1 = y1; a.Y1s = Y1s; a.stats = stats;
     a.hw = hw; a.hb = hb; a.hout = hout; a.hK = hK; a.hmode = hmode;     // fused classification head (eval) or nullptr
+    a.nds = nds; a.ds_inv_slope = epi ? epi->ds_inv_slope : 1.f;         // fused DilatedBlock sum (eval) or 0
+    for (int l = 0; l < 3; ++l) a.ds_a[l] = (epi && l < nds) ? epi->ds_a[l] : nullptr;
+    for (int l = 0; l < 4; ++l) { a.ds_sc[l] = (epi && l <= nds) ? epi->ds_sc[l] : nullptr; a.ds_sh[l] = (epi && l <= nds) ? epi->ds_sh[l] : nullptr; }
     a.prof = nullptr;
 #ifdef AMX_CONV_PROFILE
     a.prof = (unsigned long long*)amx_conv_profile_buffer;               // dev build: per-wave phase timestamps
@@ -95,10 +119,19 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);
         a.dil = 1;
+        if (nds) {                                          // fused DilatedBlock sum: the 32-couts-per-block 8-row class only
+            if (!dsum_supported(C0s + C1s, cout, taps, dil, H) || nds > 3 || stats || addend || y1 || hout) AMX_BADARG(13);
+            for (int l = 0; l < nds; ++l) if (!a.ds_a[l]) AMX_BADARG(13);
+            for (int l = 0; l <= nds; ++l) if (!a.ds_sc[l] || !a.ds_sh[l]) AMX_BADARG(13);
+            if (dil == 2) return amx_conv_launch_lat2_dsum(a, tail, s);
+            if (dil == 4) return amx_conv_launch_lat4_dsum(a, tail, s);
+            return amx_conv_launch_lat6_dsum(a, tail, s);
+        }
         if (dil == 2) return amx_conv_launch_lat2(a, pl.nt, pl.th, tail, s);
         if (dil == 4) return amx_conv_launch_lat4(a, pl.nt, pl.th, tail, s);
         return amx_conv_launch_lat6(a, pl.nt, pl.th, tail, s);
     }
+    if (nds) AMX_BADARG(13);                                // (the fused sum exists for the lattice classes only)
     if (hout) {                                             // fused head: plain 3x3, one cout block, the two thin classes
         if (!head_supported(C0s + C1s, cout, taps, dil, H) || !hw || !hb || hK < 1 || hK > 3 || hmode < 0 || hmode > 1
             || stats || addend || y1) AMX_BADARG(12);
@@ -142,8 +175,26 @@ extern "C" int amx_conv2d_fwd_head(const float* x0, const float* sc0, const floa
                                    const float* wpk, const float* bias, const float* hw, const float* hb, float* out,
                                    int K, int mode, int N, int H, int W, int cout, float slope, void* stream) {
     if (!out) AMX_BADARG(12);
+    ConvEpi e; e.hw = hw; e.hb = hb; e.hout = out; e.hK = K; e.hmode = mode;
     return conv2d_common(x0, sc0, sh0, C0s, x1, sc1, sh1, C1s, wpk, bias, nullptr, nullptr, amx_round_up(cout, 4),
-                         nullptr, 0, nullptr, N, H, W, cout, 9, 1, slope, stream, 1.f, 1.f, hw, hb, out, K, mode);
+                         nullptr, 0, nullptr, N, H, W, cout, 9, 1, slope, stream, 1.f, 1.f, &e);
+}
+
+// amx_conv2d_fwd in eval mode for the LAST layer of a DilatedBlock with the block's sum fused into the epilogue
+// (atomai/nets/blocks.py:321-329: the block returns the sum of EVERY sub-layer output = per layer the convolution, its
+// LeakyReLU and its BatchNorm): y = sum over layers l of [pre_l + a_l + (a_l * sc_l + sh_l)], pre_l = inverse LeakyReLU
+// of a_l; prev: the n earlier layers' activations (device pointers, same shape as y); sc / sh: n + 1 eval-mode BatchNorm
+// affines (this layer's last; zero vectors when the block has no BatchNorm).  This layer's own activation is not stored.
+extern "C" int amx_conv2d_fwd_dsum(const float* x0, const float* sc0, const float* sh0, int C0s, const float* wpk,
+                                   const float* bias, const float* const* prev, const float* const* sc,
+                                   const float* const* sh, int n, float* y, int N, int H, int W, int cout, int dil,
+                                   float slope, void* stream) {
+    if (!prev || !sc || !sh || n < 1 || n > 3 || slope == 0.f) AMX_BADARG(13);
+    ConvEpi e; e.nds = n; e.ds_inv_slope = 1.0f / slope;
+    for (int l = 0; l < n; ++l) e.ds_a[l] = prev[l];
+    for (int l = 0; l <= n; ++l) { e.ds_sc[l] = sc[l]; e.ds_sh[l] = sh[l]; }
+    return conv2d_common(x0, sc0, sh0, C0s, nullptr, nullptr, nullptr, 0, wpk, bias, nullptr, y, amx_round_up(cout, 4),
+                         nullptr, 0, nullptr, N, H, W, cout, 9, dil, slope, stream, 1.f, 1.f, &e);
 }
 
 // Data gradient: forward convolution of dpre (Cs stored channels) with the flipped / transposed weight image

@@ -3,8 +3,8 @@
 #include "conv_kernel.h"
 
 int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
-#define GO(N_) return tail ? launch_conv_fwd<1, N_, 0, true, 4, false, true>(a, s) \
-                           : launch_conv_fwd<1, N_, 0, true, 4, false, false>(a, s)
+#define GO(N_) return tail ? launch_conv_fwd<1, N_, 0, true, 4, 0, true>(a, s) \
+                           : launch_conv_fwd<1, N_, 0, true, 4, 0, false>(a, s)
     if (nt == 1) GO(1);
     if (nt == 2) GO(2);
     GO(4);

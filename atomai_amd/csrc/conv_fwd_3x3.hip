@@ -4,8 +4,8 @@
 #include "conv_kernel.h"
 
 int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s) {
-#define GO(N_, M_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, false, true>(a, s) \
-                               : launch_conv_fwd<9, N_, 1, true, M_, false, false>(a, s)
+#define GO(N_, M_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, 0, true>(a, s) \
+                               : launch_conv_fwd<9, N_, 1, true, M_, 0, false>(a, s)
     if (th == 8) {
         if (nt == 1) GO(1, 2);
         if (nt == 2) GO(2, 2);
@@ -19,8 +19,8 @@ int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s
 
 // HEAD instantiations (classification head fused into the epilogue, eval mode): the two thin single-block classes
 int amx_conv_launch_3x3_head(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
-#define GO(N_, M_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, true, true>(a, s) \
-                               : launch_conv_fwd<9, N_, 1, true, M_, true, false>(a, s)
+#define GO(N_, M_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, 1, true>(a, s) \
+                               : launch_conv_fwd<9, N_, 1, true, M_, 1, false>(a, s)
     if (nt == 1) GO(1, 4);
     GO(2, 2);
 #undef GO

@@ -5,8 +5,8 @@
 #include "conv_kernel.h"
 
 int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
-#define GO(N_, H_, E_, M_) return tail ? launch_conv_fwd<9, N_, H_, E_, M_, false, true>(a, s) \
-                                       : launch_conv_fwd<9, N_, H_, E_, M_, false, false>(a, s)
+#define GO(N_, H_, E_, M_) return tail ? launch_conv_fwd<9, N_, H_, E_, M_, 0, true>(a, s) \
+                                       : launch_conv_fwd<9, N_, H_, E_, M_, 0, false>(a, s)
 #define CLASS(H_, E_)                                                                     \
     do {                                                                                  \
         if (a.th == 8) GO(4, H_, E_, 2);   /* experiment AMX_CONV_DIL_TH=8 (64-cout variant only) */ \

@@ -65,6 +65,13 @@ struct ConvFwdArgs {
     const float* hb;     // [hK]:     bpx[k] + sum_c Wpx[k][c] * shift[c]
     float* hout;         // hmode 0: logits NCHW [N][K][H][W]; 1: probabilities NHWC [N][H][W][K] (sigmoid / softmax)
     int hK, hmode;
+    // ---- fused DilatedBlock sum (EPI == 2, eval mode; atomai/nets/blocks.py:321-329): this layer is the block's last
+    // one; y receives sum over the block's layers l of [pre_l + a_l + bn_l(a_l)] (pre_l = inverse LeakyReLU of a_l)
+    // instead of this layer's activation; ds_a: the earlier layers' activations (same shape as y), ds_sc / ds_sh:
+    // eval-mode BatchNorm affines of ALL layers, this layer's last ([nds + 1] vectors of Y0s floats, zeros = no BN)
+    const float* ds_a[3];
+    const float* ds_sc[4]; const float* ds_sh[4];
+    int nds; float ds_inv_slope;
     unsigned long long* prof;   // AMX_CONV_PROFILE builds: per-wave phase clocks (or nullptr)
     int N, H, W;
     int cout;            // real number of output channels
@@ -125,9 +132,11 @@ struct ConvWaves {
                                      : 1;
 };
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool HEAD, bool TAIL = false, int LAT = 0>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0>
 __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
     static_assert(LAT == 0 || (TAPS == 9 && MAXHALO == 1 && EXACT), "lattice mode runs the plain 3x3 geometry");
+    // EPI: 0 = store the activation; 1 = classification head fused in (eval); 2 = sum of a DilatedBlock fused in (eval)
+    constexpr bool HEAD = EPI == 1, DSUM = EPI == 2;
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16;
     constexpr int MAXI = TILE + 2 * MAXHALO;
@@ -490,6 +499,29 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 }
                 continue;
             }
+            if (DSUM) {
+                if (oy < a.H && ox < a.W && co < a.Y0s) {
+                    const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.Y0s + co;
+                    auto term = [&](float4 t, const float* scp, const float* shp) {
+                        const float4 sc = amx_ld4(scp + co), sh = amx_ld4(shp + co);
+                        float4 r;
+                        r.x = (t.x > 0.f ? t.x : t.x * a.ds_inv_slope) + t.x + fmaf(t.x, sc.x, sh.x);
+                        r.y = (t.y > 0.f ? t.y : t.y * a.ds_inv_slope) + t.y + fmaf(t.y, sc.y, sh.y);
+                        r.z = (t.z > 0.f ? t.z : t.z * a.ds_inv_slope) + t.z + fmaf(t.z, sc.z, sh.z);
+                        r.w = (t.w > 0.f ? t.w : t.w * a.ds_inv_slope) + t.w + fmaf(t.w, sc.w, sh.w);
+                        return r;
+                    };
+                    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int l = 0; l < a.nds; ++l) {                    // same order as amx_dilated_sum: layers ascending
+                        const float4 r = term(amx_ld4(a.ds_a[l] + o), a.ds_sc[l], a.ds_sh[l]);
+                        acc4.x += r.x; acc4.y += r.y; acc4.z += r.z; acc4.w += r.w;
+                    }
+                    const float4 r = term(amx_ld4(s_epi + (size_t)pix * NB + cgp * 4), a.ds_sc[a.nds], a.ds_sh[a.nds]);
+                    acc4.x += r.x; acc4.y += r.y; acc4.z += r.z; acc4.w += r.w;
+                    amx_st4(a.y + o, acc4);
+                }
+                continue;
+            }
             if (oy < a.H && ox < a.W && co < ctot) {
                 float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
                 float* dst; int Cd, cd;
@@ -504,7 +536,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     AMX_TICK(13);
 }
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, bool HEAD, bool TAIL = false, int LAT = 0>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     const int halo = (TAPS == 9) ? (LAT ? 1 : a.dil) : 0;
     const int I = TILE + 2 * halo;
@@ -525,13 +557,13 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, HEAD, TAIL, LAT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, HEAD, TAIL, LAT>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -544,3 +576,6 @@ int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_lat2(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);   // lattice mode, dilation 2 / 4 / 6
 int amx_conv_launch_lat4(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
 int amx_conv_launch_lat6(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
+int amx_conv_launch_lat2_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);           // + fused DilatedBlock sum (eval)
+int amx_conv_launch_lat4_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);
+int amx_conv_launch_lat6_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);

@@ -14,5 +14,10 @@
         if (nt == 2) AMX_LAT_GO(2, 4, D_);                                                                   \
         AMX_LAT_GO(4, 4, D_);                                                                                \
     }
-#define AMX_LAT_GO(N_, M_, D_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, false, true, D_>(a, s)      \
-                                           : launch_conv_fwd<9, N_, 1, true, M_, false, false, D_>(a, s)
+#define AMX_LAT_UNIT_DSUM(D_)                                                                                \
+    int amx_conv_launch_lat##D_##_dsum(ConvFwdArgs& a, bool tail, hipStream_t s) {                           \
+        return tail ? launch_conv_fwd<9, 2, 1, true, 2, 2, true, D_>(a, s)                                   \
+                    : launch_conv_fwd<9, 2, 1, true, 2, 2, false, D_>(a, s);                                 \
+    }
+#define AMX_LAT_GO(N_, M_, D_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, 0, true, D_>(a, s)      \
+                                           : launch_conv_fwd<9, N_, 1, true, M_, 0, false, D_>(a, s)

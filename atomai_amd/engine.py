@@ -787,6 +787,49 @@ class HeadNode(_Node):
         raise AssertionError("the fused head exists in eval mode only")
 
 
+def dsum_fusable(tape, srcs: Sequence[Act], conv, acts: Sequence[Act]) -> bool:
+    """Can the sum of a DilatedBlock be evaluated in the epilogue of `conv`, the block's last layer?  Eval mode only (in
+    training the last layer's activation is needed by its own backward and must be stored anyway)."""
+    if not FUSE_HEAD or tape.training or tape.need_grad or not (1 <= len(acts) <= 3) or len(srcs) != 1:
+        return False
+    if tuple(conv.kernel_size) != (3, 3) or srcs[0].post_slope != 1.0:
+        return False
+    return bool(L.load().amx_conv2d_dsum_supported(srcs[0].Cs, conv.weight.shape[0], 9, int(conv.dilation[0]), srcs[0].H))
+
+
+class DsumConvNode(_Node):
+    """Last layer of a DilatedBlock in eval mode with the block's output (the sum of every sub-layer output,
+    blocks.py:321-329) fused into its epilogue (amx_conv2d_fwd_dsum); the layer's own activation is not stored."""
+
+    def __init__(self, tape, src: Act, conv, bn, slope: float, acts: Sequence[Act]):
+        N, H, W = src.N, src.H, src.W
+        w, b = conv.weight, conv.bias
+        cout = w.shape[0]
+        cos = r4(cout)
+        wpk = pack_weights(w, src.C, src.Cs, 0, 0, 9, 0)
+        zero = torch.zeros((cos,), dtype=torch.float32, device=src.t.device)
+        if bn is not None:
+            scale, shift = _empty((cos,), src.t), _empty((cos,), src.t)
+            L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
+                   L.ptr(bn.running_var), bn.eps, cout, cos, L.ptr(scale), L.ptr(shift), _sp(src.t))
+        else:
+            scale = shift = zero
+        scs = [(a.scale if a.scale is not None else zero) for a in acts] + [scale]
+        shs = [(a.shift if a.shift is not None else zero) for a in acts] + [shift]
+        n = len(acts)
+        PA, PS = ctypes.c_void_p * n, ctypes.c_void_p * (n + 1)
+        y = _empty((N, H, W, cos), src.t)
+        self.keep = (scs, shs, zero)
+        L.call("amx_conv2d_fwd_dsum", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), src.Cs, L.ptr(wpk),
+               L.ptr(b.detach() if b is not None else None), PA(*[a.t.data_ptr() for a in acts]),
+               PS(*[t.data_ptr() for t in scs]), PS(*[t.data_ptr() for t in shs]), n, L.ptr(y), N, H, W, cout,
+               int(conv.dilation[0]), float(slope), _sp(src.t))
+        self.out = Act(y, cout)
+
+    def backward(self, tape) -> None:
+        raise AssertionError("the fused DilatedBlock sum exists in eval mode only")
+
+
 class PxNode(_Node):
     """Final 1x1 conv to nb_classes; logits NCHW (mode 0) or probabilities NHWC (mode 1)."""
 
@@ -943,6 +986,9 @@ class Tape:
 
     def px(self, src: Act, conv, mode: int = 0) -> PxNode:
         return self._push(PxNode(self, src, conv, mode))
+
+    def conv_dsum(self, src: Act, conv, bn, slope: float, acts) -> Act:
+        return DsumConvNode(self, src, conv, bn, slope, acts).out
 
     def conv_head(self, srcs, conv, bn, slope: float, px, mode: int = 0) -> HeadNode:
         return HeadNode(self, srcs, conv, bn, slope, px, mode)

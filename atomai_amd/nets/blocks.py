@@ -165,9 +165,13 @@ class DilatedBlock(_HipBlock):
         self.atrous_module = nn.Sequential(*atrous_module)
 
     def _emit(self, tape, srcs):
+        from ..engine import dsum_fusable
         acts, slope = [], 0.01
-        for conv, slope, bn, drop in _layers(self.atrous_module):
+        layers = _layers(self.atrous_module)
+        for i, (conv, slope, bn, drop) in enumerate(layers):
             _check_dropout(drop, tape.training)
+            if i == len(layers) - 1 and dsum_fusable(tape, srcs, conv, acts):
+                return tape.conv_dsum(srcs[0], conv, bn, slope, acts)      # eval: the block's sum in this layer's epilogue
             a = tape.conv(srcs, conv, bn, slope)
             acts.append(a)
             srcs = [a]

@@ -51,6 +51,15 @@ int amx_conv2d_fwd_head(const float* x0, const float* sc0, const float* sh0, int
                         const float* x1, const float* sc1, const float* sh1, int C1s,
                         const float* wpk, const float* bias, const float* hw, const float* hb, float* out,
                         int K, int mode, int N, int H, int W, int cout, float slope, void* stream);
+/* Eval-mode LAST layer of a DilatedBlock with the block's output fused into its epilogue (atomai/nets/blocks.py:321-329:
+ * the block returns the sum of every sub-layer output): y = sum over the block's layers l of
+ * [pre_l + a_l + (a_l * sc_l + sh_l)], pre_l = inverse LeakyReLU of a_l.  prev: n (1..3) device pointers to the earlier
+ * layers' activations (shape of y); sc / sh: n + 1 eval-mode BatchNorm affines (round_up(cout,4) floats each, this layer's
+ * last; zero vectors without BatchNorm).  Only for layers amx_conv2d_dsum_supported returns 1 for. */
+int amx_conv2d_dsum_supported(int Cin_s, int cout, int taps, int dil, int H);
+int amx_conv2d_fwd_dsum(const float* x0, const float* sc0, const float* sh0, int C0s, const float* wpk,
+                        const float* bias, const float* const* prev, const float* const* sc, const float* const* sh,
+                        int n, float* y, int N, int H, int W, int cout, int dil, float slope, void* stream);
 int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
                      int Y1s, int N, int H, int W, int taps, int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);

@@ -234,6 +234,42 @@ def check_head_fusion(device):
         engine.FUSE_HEAD = True
 
 
+def check_dsum_fusion(device):
+    """Eval mode: the sum of a DilatedBlock evaluated in the epilogue of its last layer is BIT-IDENTICAL to the separate
+    sum kernel (same terms in the same order), with and without BatchNorm, for 2- and 3-layer blocks."""
+    from atomai_amd import engine
+    from atomai_amd.nets import DilatedBlock
+    rs = np.random.RandomState(8)
+    made = []
+    orig = engine.DsumConvNode.__init__
+
+    def counting(self, *a, **k):
+        made.append(1)
+        return orig(self, *a, **k)
+    engine.DsumConvNode.__init__ = counting
+    try:
+        for cin, cout, dils, bn, hw in ((25, 50, [2, 4, 6], True, (22, 38)), (50, 50, [2, 4], True, (16, 24)),
+                                        (20, 28, [2, 4, 6], False, (13, 21))):
+            torch.manual_seed(9)
+            m = DilatedBlock(2, cin, cout, dils, dils, batch_norm=bn).to(device)
+            m.train()
+            with torch.no_grad():
+                m(torch.from_numpy(rs.randn(2, cin, *hw).astype(np.float32)).to(device))
+            m.eval()
+            x = torch.from_numpy(rs.randn(3, cin, *hw).astype(np.float32)).to(device)
+            res = {}
+            for fuse in (True, False):
+                engine.FUSE_HEAD = fuse
+                n0 = len(made)
+                with torch.no_grad():
+                    res[fuse] = m(x)
+                assert (len(made) - n0 == 1) == fuse, (cin, cout, fuse)
+            assert torch.equal(res[True], res[False]), (cin, cout, float((res[True] - res[False]).abs().max()))
+    finally:
+        engine.DsumConvNode.__init__ = orig
+        engine.FUSE_HEAD = True
+
+
 def check_input_norm_fusion(device):
     """The predictor's stack normalisation applied inside the first-layer kernel (Unet / dilnet) or by the separate
     pass (nets with another first layer) gives bit-identical probabilities to normalising first."""

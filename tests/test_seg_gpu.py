@@ -232,3 +232,7 @@ def test_input_normalisation_inside_the_first_layer_kernel():
 
 def test_classification_head_in_the_last_conv_epilogue():
     C.check_head_fusion("cuda")
+
+
+def test_dilated_block_sum_in_the_last_conv_epilogue():
+    C.check_dsum_fusion("cuda")
