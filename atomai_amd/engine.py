@@ -732,7 +732,8 @@ class OutputNode(_Node):
         tape.accumulate(s, g)
 
 
-FUSE_HEAD = _os.environ.get("AMX_FUSE_HEAD", "1") != "0"      # experiment switch: classification head in the conv epilogue
+# experiment switch for the eval-mode epilogue fusions (classification head, DilatedBlock sum); 0 = separate kernels
+FUSE_HEAD = _os.environ.get("AMX_FUSE_HEAD", "1") != "0"
 
 
 def head_fusable(tape, srcs: Sequence[Act], conv, px) -> bool:
