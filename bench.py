@@ -321,7 +321,7 @@ def main():
     marks = [t0]
     for i in range(args.steps):
         losses.append(one_step(i))
-        marks.append(time.perf_counter())                    # loss.item() already synchronised this step
+        marks.append(time.perf_counter())                    # host time at which the step's loss value arrived
     barrier()
     elapsed = time.perf_counter() - t0
     per_step = np.diff(marks) * 1e3
@@ -403,6 +403,9 @@ def main():
         "step_ms_median_max": [round(float(np.median(per_step)), 3), round(float(per_step.max()), 3)],
         "allocator": alloc_info,
         "step_ms_all": [round(float(v), 1) for v in list(np.diff(wmarks) * 1e3) + list(per_step)],
+        "step_ms_note": "host-side intervals between loss values: the loss of step t reaches the host after its forward "
+                        "pass (trainer._EarlyScalar), its backward + Adam overlap the host work of step t+1; the timed "
+                        "region is closed by a device synchronisation, ms_per_step = region / steps",
         "step_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
         "step_frac_of_mfma_f32_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_F32, 4),
     }
