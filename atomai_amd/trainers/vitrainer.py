@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from ..optim import FusedAdam
+from .trainer import _EarlyScalar
 from ..utils import get_array_memsize, set_train_rng
 
 
@@ -123,12 +124,13 @@ class viBaseTrainer:
             x, y = self._unpack(batch)
             b = x.size(0)
             elbo = self.forward_compute_elbo(x) if y is None else self.forward_compute_elbo(x, y)
+            early = _EarlyScalar(elbo)             # the value travels to the host while backward + Adam still run
             (-elbo).backward()
             if self.dp is not None:
                 self.dp.allreduce_grads()
             self.optim.step()
             self.optim.zero_grad()
-            elbo = elbo.item()
+            elbo = early.item()
             c += b
             elbo_epoch += b * (elbo - elbo_epoch) / c
         return elbo_epoch

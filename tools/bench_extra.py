@@ -35,12 +35,15 @@ def bench_rvae(steps=10, warmup=3, B=512, emit=True):
     xs = [torch.from_numpy(X[i * B:(i + 1) * B]).cuda() for i in range(2)]
     recs = timed_calls({"amx_rdecoder_fwd", "amx_rdecoder_bwd"})
 
-    def step(i):
+    from atomai_amd.trainers.trainer import _EarlyScalar
+
+    def step(i):                                      # the body of viBaseTrainer.train_epoch for one mini-batch
         m.optim.zero_grad()
         elbo = m.forward_compute_elbo(xs[i % 2])
+        early = _EarlyScalar(elbo)
         (-elbo).backward()
         m.optim.step()
-        return elbo.item()
+        return early.item()
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize(); recs.clear()
