@@ -13,8 +13,10 @@ the closed forms gpytorch documents for the objects the reference instantiates
   ScaleToBounds(-1, 1)  x -> (x - min) * 0.95*(hi-lo)/(max-min) + 0.95*lo   (min/max of the training batch)
   ExactMarginalLogLikelihood = ( -1/2 r^T Khat^-1 r - 1/2 log det Khat - N/2 log 2 pi ) / N
 (The KISS-GP interpolation the reference wraps around the base kernel is NOT reproduced: the north_star asks
-for the dense tiled builder.)  Pinned instead by float64 known-answer tests (scipy cho_solve), symmetry /
-PSD / diagonal properties and finite differences in tests/test_gp_*.py.
+for the dense tiled builder.)  Pinned instead by float64 known-answer tests (scipy cho_solve), gpytorch's documented
+constants, an independent published implementation (scikit-learn's GaussianProcessRegressor with fixed
+hyper-parameters: kernels, posterior mean / variance, log marginal likelihood to 1e-9), symmetry / PSD / diagonal
+properties and finite differences in tests/test_gp_*.py.
 """
 import numpy as np
 

@@ -53,3 +53,27 @@ def test_conv_feature_extractor_vs_stock_torch():
 
 def test_dklgpr_with_conv_feature_extractor():
     G.check_dklgpr_conv_extractor("cpu", N=48, p=8, cycles=2, precision="double")
+
+
+def test_gp_oracle_against_scikit_learn():
+    """An independent published implementation as a second anchor for the (reference-unpinned) GP oracle: kernel
+    matrices (RBF-ARD, Matern-5/2, scaled), exact-GP posterior mean / variance and the log marginal likelihood of
+    scikit-learn's GaussianProcessRegressor with FIXED hyper-parameters (optimizer=None) — same closed forms as
+    gpytorch's ScaleKernel(RBFKernel | MaternKernel) + GaussianLikelihood + ExactMarginalLogLikelihood."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+    from oracle import gp_oracle as go
+    rs = np.random.RandomState(5)
+    Z, Zs = rs.uniform(-1, 1, (40, 3)), rs.uniform(-1, 1, (17, 3))
+    y = np.sin(Z.sum(1)) + 0.1 * rs.randn(40)
+    ls, s2, noise = np.array([0.7, 1.3, 0.4]), 1.7, 0.05
+    for kind, base in (("rbf", RBF(length_scale=ls)), ("matern", Matern(length_scale=ls, nu=2.5))):
+        k = ConstantKernel(s2) * base
+        np.testing.assert_allclose(go.kernel_matrix(Z, Zs, ls, s2, kind), k(Z, Zs), rtol=1e-12, atol=1e-14)
+        gpr = GaussianProcessRegressor(kernel=k, alpha=noise, optimizer=None, normalize_y=False).fit(Z, y)
+        mu, sd = gpr.predict(Zs, return_std=True)
+        mo, vo = go.posterior(Z, y, Zs, ls, s2, noise, 0.0, kind)
+        np.testing.assert_allclose(mo, mu, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(vo, sd ** 2, rtol=1e-7, atol=1e-10)
+        mll, _ = go.exact_mll(Z, y, ls, s2, noise, 0.0, kind)             # the oracle's is per datum (gpytorch's MLL)
+        np.testing.assert_allclose(mll * len(y), gpr.log_marginal_likelihood_value_, rtol=1e-10)
