@@ -11,16 +11,15 @@
 //   forward   y  = x  * W^T  (+ b, act)    A = x  [M][K] (k contiguous),  B = W^T: element (k, n) = W[n][k] (k contiguous)
 //   dgrad     dx = dpre * W                A = dpre [M][N'] (k contiguous), B = W [N'][K] (n contiguous)
 //   wgrad     dW = dpre^T * x              A = dpre^T: (m, k) = dpre[k][m] (m contiguous), B = x [M'][K] (n contiguous)
-// Mapping to CDNA4: 64 x 64 output tile per workgroup, 4 waves in a 2 x 2 grid, each wave 2 x 2 tiles of
+// Mapping to CDNA4: 64 x 64 (or, for small problems, 32 x 32) output tile per workgroup, 4 waves in a 2 x 2 grid, each wave 2 x 2 (1 x 1) tiles of
 // v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, k ascending -> deterministic, no split-K atomics); K is streamed in
 // steps of 16 through LDS images [k/4][row][4] so that every operand fragment is one conflict-free ds_read_b128 (the
 // layout of conv_kernel.h); the next step's operands are prefetched into registers under the current step's MFMAs.
 // Operands that are contiguous along k and 16-byte aligned are fetched as float4; any other stride / alignment / edge
 // goes through a scalar loader with per-element bounds (zero fill).
 #include "amx_device.h"
+#include <cstdlib>
 
-#define LBM 64
-#define LBN 64
 #define LBK 16
 
 struct GemmArgs {
@@ -33,8 +32,8 @@ struct GemmArgs {
     int vecA, vecB;                     // 1: k-contiguous, aligned float4 path is legal for this operand
 };
 
-// One operand tile (64 rows x 16 k) -> 4 registers per thread.  `rs` / `ks` are the row / k strides.
-// Thread t owns row = t >> 2, k-group kg = t & 3 (4 consecutive k): the LDS slot [kg][row][0..3].
+// One operand tile (ROWS rows x 16 k) -> 4 registers per thread.  `rs` / `ks` are the row / k strides.
+// Thread t (< 4 * ROWS) owns row = t >> 2, k-group kg = t & 3 (4 consecutive k): the LDS slot [kg][row][0..3].
 static __device__ __forceinline__ float4 gemm_load(const float* P, long rs, long ks, int row0, int nrows, int k0, int K,
                                                    int vec, int tid) {
     const int row = row0 + (tid >> 2), k = k0 + (tid & 3) * 4;
@@ -53,39 +52,50 @@ static __device__ __forceinline__ float4 gemm_load(const float* P, long rs, long
     return v;
 }
 
+// TW x TW tiles of 16 x 16 per wave, 2 x 2 waves: output tile 32 TW x 32 TW per workgroup (TW = 2: 64 x 64; TW = 1:
+// 32 x 32 for problems whose 64 x 64 grid would leave most of the 256 CUs idle, e.g. the 512 x 128 x 4096 first
+// encoder layer of the VAEs: 16 -> 64 workgroups).
+template <int TW>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[4 * LBM * 4];
-    __shared__ __attribute__((aligned(16))) float sB[4 * LBN * 4];
+    constexpr int LB = 32 * TW;                                  // rows of A / columns of B per workgroup
+    __shared__ __attribute__((aligned(16))) float sA[4 * LB * 4];
+    __shared__ __attribute__((aligned(16))) float sB[4 * LB * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;                     // 2 x 2 waves, 32 x 32 outputs each
-    const int m0 = blockIdx.y * LBM, n0 = blockIdx.x * LBN;
+    const int wm = wave >> 1, wn = wave & 1;                     // 2 x 2 waves
+    const int m0 = blockIdx.y * LB, n0 = blockIdx.x * LB;
+    const bool loader = tid < 4 * LB;                            // TW = 1: 128 threads fetch a 32-row operand tile
 
-    f32x4 acc[2][2];
+    f32x4 acc[TW][TW];
     #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
         #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float4 ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, 0, a.K, a.vecA, tid);
-    float4 rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, a.vecB, tid);
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    if (loader) {
+        ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, 0, a.K, a.vecA, tid);
+        rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, a.vecB, tid);
+    }
     for (int k0 = 0; k0 < a.K; k0 += LBK) {
-        amx_st4(sA + ((tid & 3) * LBM + (tid >> 2)) * 4, ra);
-        amx_st4(sB + ((tid & 3) * LBN + (tid >> 2)) * 4, rb);
+        if (loader) {
+            amx_st4(sA + ((tid & 3) * LB + (tid >> 2)) * 4, ra);
+            amx_st4(sB + ((tid & 3) * LB + (tid >> 2)) * 4, rb);
+        }
         __syncthreads();
-        if (k0 + LBK < a.K) {
+        if (loader && k0 + LBK < a.K) {
             ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, k0 + LBK, a.K, a.vecA, tid);
             rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, k0 + LBK, a.K, a.vecB, tid);
         }
-        float4 af[2], bf[2];
+        float4 af[TW], bf[TW];
         #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = amx_ld4(sA + (g * LBM + wm * 32 + i * 16 + p) * 4);
+        for (int i = 0; i < TW; ++i) af[i] = amx_ld4(sA + (g * LB + (wm * TW + i) * 16 + p) * 4);
         #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = amx_ld4(sB + (g * LBN + wn * 32 + j * 16 + p) * 4);
+        for (int j = 0; j < TW; ++j) bf[j] = amx_ld4(sB + (g * LB + (wn * TW + j) * 16 + p) * 4);
         // one MFMA contracts k in {t, 4+t, 8+t, 12+t}; consecutive MFMAs target different accumulators
         #define AMX_GEMM_STEP(C_)                                                                                   \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+            _Pragma("unroll") for (int i = 0; i < TW; ++i)                                                          \
+                _Pragma("unroll") for (int j = 0; j < TW; ++j)                                                      \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].C_, bf[j].C_, acc[i][j], 0, 0, 0);
         AMX_GEMM_STEP(x) AMX_GEMM_STEP(y) AMX_GEMM_STEP(z) AMX_GEMM_STEP(w)
         #undef AMX_GEMM_STEP
@@ -93,15 +103,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
     // D fragment: column n = p, rows 4 g + r
     #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 32 + j * 16 + p;
+    for (int j = 0; j < TW; ++j) {
+        const int n = n0 + (wn * TW + j) * 16 + p;
         if (n >= a.N) continue;
         const float b = a.bias ? a.bias[n] : 0.f;
         #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TW; ++i)
             #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 32 + i * 16 + 4 * g + r;
+                const int m = m0 + (wm * TW + i) * 16 + 4 * g + r;
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + b;
                 if (a.act == 1) v = tanhf(v);
@@ -124,9 +134,14 @@ extern "C" int amx_gemm_f32(const float* A, long sam, long sak, const float* B, 
     a.M = M; a.N = N; a.K = K; a.act = act;
     a.vecA = sak == 1 && (sam & 3) == 0 && aligned16(A);
     a.vecB = sbk == 1 && (sbn & 3) == 0 && aligned16(B);
-    dim3 grid(amx_ceil_div(N, LBN), amx_ceil_div(M, LBM));
+    // 64 x 64 tiles unless they would leave most of the chip idle (< 128 workgroups): then 32 x 32 (4x the workgroups)
+    const long wg64 = (long)amx_ceil_div(N, 64) * amx_ceil_div(M, 64);
+    int tile = wg64 < 128 ? 32 : 64;
+    if (const char* e = getenv("AMX_GEMM_TILE")) { const int v = atoi(e); if (v == 32 || v == 64) tile = v; }
+    dim3 grid(amx_ceil_div(N, tile), amx_ceil_div(M, tile));
     if (grid.y > 65535) AMX_BADARG(4);
-    AMX_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (tile == 32) AMX_LAUNCH(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else AMX_LAUNCH(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
