@@ -49,8 +49,22 @@ struct RDecArgs {
     float* pbc;            // [B][HID]
     float* pWz;            // [B][HID][L]
     int B, n, L, NL, skip;
+    unsigned long long* prof;   // AMX_RDEC_PROFILE builds: per-wave phase clocks [workgroup][wave][8], or nullptr
 };
 
+// AMX_RDEC_PROFILE (dev builds only, tools/gpu_rdec_phases.py): every wave of the backward kernel accumulates the shader
+// clocks it spends per phase of its tile loop: coordinate layer, hidden layers forward, output-layer backward, wgrad
+// MFMAs, dgrad MFMAs, elementwise after dgrad, coordinate-layer backward, lifetime.
+#ifdef AMX_RDEC_PROFILE
+static void* amx_rdec_profile_buffer = nullptr;
+extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer = buf; return 0; }
+#define RD_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt[i] += n_ - pl; pl = n_; } while (0)
+#else
+#define RD_TICK(i) do { } while (0)
+#endif
+#ifndef RD_PLANE_PAD
+#define RD_PLANE_PAD 4        // compile-time experiment switch: 0 = the unpadded round-1 layout
+#endif
 #define MAXL 8
 #define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
 
@@ -75,7 +89,14 @@ struct Geo {
     static constexpr int NT = 64 * NW;           // threads
     static constexpr int KG = HID / 4;           // feature groups of 4
     static constexpr int PT = MT / 16;           // pixel tiles per wave GEMM
-    static constexpr int BUF = HID * MT;         // floats per activation image
+    // Plane stride of an activation image [kg][pixel][4] in 16-byte slots: MT + 4.  With a stride of MT (a multiple of 32
+    // banks) the scalar operand reads of the in-kernel weight gradient — lane (p, g) reads feature 16w+p of pixel 4s+g,
+    // i.e. planes (16w+p)>>2 — hit each bank four times; 4 slots (16 banks) of padding bring that to the minimum of two
+    // lanes per bank.  The float4 fragment reads / writes of the other phases stay conflict free (8 consecutive lanes
+    // still cover 128 contiguous bytes).  tools/gpu_rdec_phases.py: the wgrad phase was LDS-bound (23.2 k clocks per
+    // tile for 16.4 k of MFMA time).
+    static constexpr int PS = MT + RD_PLANE_PAD;
+    static constexpr int BUF = HID * PS;         // floats per activation image (KG planes of PS slots)
     static constexpr int SPT = KG * MT / NT;     // (kg,pixel) slots per thread  (= MT/16)
     static constexpr int TPP = NT / MT;          // threads per pixel in the output stage
 };
@@ -109,7 +130,7 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
             h.w = fmaf(a.Wc[2 * f + 6], xx, fmaf(a.Wc[2 * f + 7], yy, s_zc[f + 3]));
             if (!a.skip) { h.x = rd_tanh(h.x); h.y = rd_tanh(h.y); h.z = rd_tanh(h.z); h.w = rd_tanh(h.w); }
         }
-        amx_st4(dst + (size_t)s * 4, h);
+        amx_st4(dst + ((size_t)kg * G::PS + p) * 4, h);
     }
 }
 
@@ -129,7 +150,7 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
     for (int c = 0; c < HID / 16; ++c) {
         float4 bq[G::PT];
         #pragma unroll
-        for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(src + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+        for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(src + ((size_t)(4 * c + g) * G::PS + 16 * t + p) * 4);
         // k-subgroup outermost so that consecutive MFMAs target different accumulators (40-cycle dependent
         // latency vs 32-cycle issue of v_mfma_f32_16x16x4_f32)
         #pragma unroll
@@ -148,7 +169,7 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
         float4 v;
         v.x = rd_tanh(acc[t][0] + bias.x); v.y = rd_tanh(acc[t][1] + bias.y);
         v.z = rd_tanh(acc[t][2] + bias.z); v.w = rd_tanh(acc[t][3] + bias.w);
-        const size_t o = ((size_t)(4 * wave + g) * MT + 16 * t + p) * 4;
+        const size_t o = ((size_t)(4 * wave + g) * G::PS + 16 * t + p) * 4;
         if (res) { const float4 r = amx_ld4(res + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         amx_st4(dst + o, v);
     }
@@ -163,7 +184,7 @@ __device__ __forceinline__ void output_layer(const RDecArgs& a, const float* h, 
     for (int c = 0; c < a.C; ++c) {
         float acc = 0.f;
         for (int kg = part; kg < G::KG; kg += G::TPP) {
-            const float4 v = amx_ld4(h + ((size_t)kg * MT + p) * 4);
+            const float4 v = amx_ld4(h + ((size_t)kg * G::PS + p) * 4);
             const float4 w = amx_ld4(a.Wo + (size_t)c * HID + kg * 4);
             acc = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc))));
         }
@@ -274,16 +295,23 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     #pragma unroll
     for (int c = 0; c < MAXC; ++c) { aWo[c] = 0.f; abo[c] = 0.f; }
 
+#ifdef AMX_RDEC_PROFILE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pl = __builtin_amdgcn_s_memtime();
+    const unsigned long long pstart = pl;
+#endif
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
         coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
         __syncthreads();
+        RD_TICK(0);
         #pragma unroll
         for (int l = 0; l < NL; ++l) {
             hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, H[l], H[l + 1],
                                   a.skip ? H[0] : nullptr, wave, lane);
             __syncthreads();
         }
+        RD_TICK(1);
         // ---- output layer backward: dout, dWo, dbo, ga_NL (in place over H[NL])
         for (int e = tid; e < MT * a.C; e += G::NT) {
             const int pp = e / a.C, c = e - pp * a.C;
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             if (c >= a.C) break;
             if (tid < MT) abo[c] += s_out[c * MT + tid];
             if (tid < HID) {                     // dWo[c][f] += sum_p dout[p][c] * h_NL[p][f]
-                const float* hf = H[NL] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
+                const float* hf = H[NL] + (size_t)(tid >> 2) * G::PS * 4 + (tid & 3);
                 float t = aWo[c];
                 #pragma unroll 8
                 for (int pp = 0; pp < MT; ++pp) t = fmaf(s_out[c * MT + pp], hf[pp * 4], t);
@@ -308,7 +336,8 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         for (int i = 0; i < G::SPT; ++i) {
             const int s = tid + i * G::NT;
             const int kg = s / MT, pp = s - kg * MT;
-            float4 h = amx_ld4(H[NL] + (size_t)s * 4);
+            const size_t so = ((size_t)kg * G::PS + pp) * 4;         // this slot in an activation image
+            float4 h = amx_ld4(H[NL] + so);
             float4 gh = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int c = 0; c < a.C; ++c) {
                 const float d = s_out[c * MT + pp];
@@ -316,14 +345,15 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
                 gh.x = fmaf(d, w.x, gh.x); gh.y = fmaf(d, w.y, gh.y); gh.z = fmaf(d, w.z, gh.z); gh.w = fmaf(d, w.w, gh.w);
             }
             if (a.skip) {
-                const float4 r = amx_ld4(H[0] + (size_t)s * 4);
-                amx_st4(GR + (size_t)s * 4, gh);                        // g_res = gh_NL
+                const float4 r = amx_ld4(H[0] + so);
+                amx_st4(GR + so, gh);                                   // g_res = gh_NL
                 h.x -= r.x; h.y -= r.y; h.z -= r.z; h.w -= r.w;         // t = h - residual
             }
             gh.x *= 1.f - h.x * h.x; gh.y *= 1.f - h.y * h.y; gh.z *= 1.f - h.z * h.z; gh.w *= 1.f - h.w * h.w;
-            amx_st4(H[NL] + (size_t)s * 4, gh);
+            amx_st4(H[NL] + so, gh);
         }
         __syncthreads();
+        RD_TICK(2);
         // ---- hidden layers, last to first
         #pragma unroll
         for (int l = NL - 1; l >= 0; --l) {
@@ -334,15 +364,16 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             for (int s4 = 0; s4 < MT / 4; ++s4) {
                 const int pix = 4 * s4 + g;
                 const int f = 16 * wave + p;
-                const float av = ga[((size_t)(f >> 2) * MT + pix) * 4 + (f & 3)];
+                const float av = ga[((size_t)(f >> 2) * G::PS + pix) * 4 + (f & 3)];
                 accb[l] += av;
                 #pragma unroll
                 for (int c = 0; c < HID / 16; ++c) {
                     const int k = 16 * c + p;
-                    const float bv = hin[((size_t)(k >> 2) * MT + pix) * 4 + (k & 3)];
+                    const float bv = hin[((size_t)(k >> 2) * G::PS + pix) * 4 + (k & 3)];
                     accW[l][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accW[l][c], 0, 0, 0);
                 }
             }
+            RD_TICK(3);
             // dgrad: gh[k][pix] = sum_f W[f][k] ga[pix][f]  (A = W^T fragments, B = ga image)
             float4 areg[HID / 16];
             const float* Wt = a.Wt + (size_t)l * HID * HID;
@@ -355,7 +386,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             for (int c = 0; c < HID / 16; ++c) {
                 float4 bq[G::PT];
                 #pragma unroll
-                for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(ga + ((size_t)(4 * c + g) * MT + 16 * t + p) * 4);
+                for (int t = 0; t < G::PT; ++t) bq[t] = amx_ld4(ga + ((size_t)(4 * c + g) * G::PS + 16 * t + p) * 4);
                 #pragma unroll
                 for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].x, bq[t].x, acc[t], 0, 0, 0);
                 #pragma unroll
@@ -365,12 +396,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
                 #pragma unroll
                 for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq[t].w, acc[t], 0, 0, 0);
             }
+            RD_TICK(4);
             __syncthreads();                     // every wave is done reading hin = H[l] and ga
             // turn gh_{l} (grad w.r.t. h_l, the layer's INPUT) into the pre-activation gradient of the
             // layer below and store it in place over H[l]
             #pragma unroll
             for (int t = 0; t < G::PT; ++t) {
-                const size_t o = ((size_t)(4 * wave + g) * MT + 16 * t + p) * 4;
+                const size_t o = ((size_t)(4 * wave + g) * G::PS + 16 * t + p) * 4;
                 float4 gh = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
                 float4 h = amx_ld4(H[l] + o);
                 if (a.skip) {
@@ -394,12 +426,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             __syncthreads();
         }
         // ---- coordinate layer backward from ga_0 = H[0]
+        RD_TICK(5);
         float* s_g = H[1];                       // scratch [KG][MT][2] (H[1] is free now; NL >= 1)
         #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
             const int s = tid + i * G::NT;
             const int kg = s / MT, pp = s - kg * MT;
-            const float4 ga0 = amx_ld4(H[0] + (size_t)s * 4);
+            const float4 ga0 = amx_ld4(H[0] + ((size_t)kg * G::PS + pp) * 4);
             const bool ok = pix0 + pp < a.n;
             const int f = kg * 4;
             float gx = ga0.x * a.Wc[2 * f + 0] + ga0.y * a.Wc[2 * f + 2] + ga0.z * a.Wc[2 * f + 4] + ga0.w * a.Wc[2 * f + 6];
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             s_g[((size_t)kg * MT + pp) * 2 + 1] = ok ? gy : 0.f;
         }
         if (tid < HID) {                         // dWc[f][:] += sum_p ga0[p][f] * (x', y');  dzc[f] += sum_p ga0
-            const float* gf = H[0] + (size_t)(tid >> 2) * MT * 4 + (tid & 3);
+            const float* gf = H[0] + (size_t)(tid >> 2) * G::PS * 4 + (tid & 3);
             const int np = a.n - pix0 < MT ? a.n - pix0 : MT;
             for (int pp = 0; pp < np; ++pp) {
                 const float gv = gf[pp * 4];
@@ -433,7 +466,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             }
         }
         __syncthreads();
+        RD_TICK(6);
     }
+#ifdef AMX_RDEC_PROFILE
+    pt[7] = __builtin_amdgcn_s_memtime() - pstart;
+    if (a.prof && lane == 0)
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)blockIdx.x * (HID / 16) + wave) * 8 + i] = pt[i];
+#endif
     if (th) {                                     // fixed-order sums over the 2*MT (pixel slot, component) threads
         __syncthreads();
         if (tid < 2 * MT) { s_red[2 * tid] = a_phi; s_red[2 * tid + 1] = a_tr; }
@@ -574,6 +613,9 @@ extern "C" int amx_rdecoder_bwd(const float* coords, const float* theta, const f
     a.Wo = Wo; a.bo = bo; a.dxrec = dxrec; a.dcoords = dcoords; a.dtheta = dtheta; a.dz = dz;
     a.pW = pW; a.pb = pb; a.pWo = pWo; a.pbo = pbo; a.pWc = pWc; a.pbc = pbc; a.pWz = pWz;
     a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip; a.C = C;
+#ifdef AMX_RDEC_PROFILE
+    a.prof = (unsigned long long*)amx_rdec_profile_buffer;
+#endif
     const int rc = check_common(a, hid);
     if (rc) return rc;
     if (!Wt || !dxrec || !dz || !pW || !pb || !pWo || !pbo || !pWc || !pbc || !pWz) AMX_BADARG(4);
