@@ -289,7 +289,8 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         #pragma unroll
         for (int c = 0; c < HID / 16; ++c) accW[l][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // per-feature accumulators owned by thread f = tid < HID (kept out of the MFMA waves' register budget)
+    // per-feature accumulators: thread tid owns feature fq for the qq-th quarter of every tile's pixels
+    const int fq = tid & (HID - 1), qq = tid / HID;
     float aWo[MAXC], aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
     float abo[MAXC];
     #pragma unroll
@@ -323,11 +324,12 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         for (int c = 0; c < MAXC; ++c) {
             if (c >= a.C) break;
             if (tid < MT) abo[c] += s_out[c * MT + tid];
-            if (tid < HID) {                     // dWo[c][f] += sum_p dout[p][c] * h_NL[p][f]
-                const float* hf = H[NL] + (size_t)(tid >> 2) * G::PS * 4 + (tid & 3);
+            {                                    // dWo[c][f] += sum_p dout[p][c] * h_NL[p][f]: feature fq, the qq-th
+                // quarter of the tile's pixels (all 4 * HID threads work; the quarters are summed once, after the tile loop)
+                const float* hf = H[NL] + (size_t)(fq >> 2) * G::PS * 4 + (fq & 3);
                 float t = aWo[c];
                 #pragma unroll 8
-                for (int pp = 0; pp < MT; ++pp) t = fmaf(s_out[c * MT + pp], hf[pp * 4], t);
+                for (int pp = qq * (MT / 4); pp < (qq + 1) * (MT / 4); ++pp) t = fmaf(s_out[c * MT + pp], hf[pp * 4], t);
                 aWo[c] = t;
             }
         }
@@ -440,10 +442,11 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             s_g[((size_t)kg * MT + pp) * 2 + 0] = ok ? gx : 0.f;
             s_g[((size_t)kg * MT + pp) * 2 + 1] = ok ? gy : 0.f;
         }
-        if (tid < HID) {                         // dWc[f][:] += sum_p ga0[p][f] * (x', y');  dzc[f] += sum_p ga0
-            const float* gf = H[0] + (size_t)(tid >> 2) * G::PS * 4 + (tid & 3);
+        {                                        // dWc[f][:] += sum_p ga0[p][f] * (x', y');  dzc[f] += sum_p ga0
+            const float* gf = H[0] + (size_t)(fq >> 2) * G::PS * 4 + (fq & 3);      // (feature fq, pixel quarter qq)
             const int np = a.n - pix0 < MT ? a.n - pix0 : MT;
-            for (int pp = 0; pp < np; ++pp) {
+            const int pe = (qq + 1) * (MT / 4) < np ? (qq + 1) * (MT / 4) : np;
+            for (int pp = qq * (MT / 4); pp < pe; ++pp) {
                 const float gv = gf[pp * 4];
                 aWc0 = fmaf(gv, s_xy[2 * pp], aWc0);
                 aWc1 = fmaf(gv, s_xy[2 * pp + 1], aWc1);
@@ -499,13 +502,28 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         if (g == 0) a.pb[((size_t)bidx * NL + l) * HID + 16 * wave + p] = sb;
     }
     __syncthreads();
-    if (tid < HID) {
+    {   // the four pixel quarters of every per-feature accumulator, summed in quarter order
+        float4* r4 = reinterpret_cast<float4*>(s_red);               // [NT] float4
+        r4[tid] = make_float4(aWc0, aWc1, aZc, 0.f);
+        __syncthreads();
+        if (tid < HID) {
+            float4 t = r4[tid];
+            #pragma unroll
+            for (int q = 1; q < 4; ++q) { const float4 u = r4[tid + q * HID]; t.x += u.x; t.y += u.y; t.z += u.z; }
+            a.pWc[((size_t)bidx * HID + tid) * 2 + 0] = t.x;
+            a.pWc[((size_t)bidx * HID + tid) * 2 + 1] = t.y;
+            a.pbc[(size_t)bidx * HID + tid] = t.z;
+            s_zc[tid] = t.z;                     // dzc, consumed below for dWz / dz
+        }
+        __syncthreads();
         #pragma unroll
-        for (int c = 0; c < MAXC; ++c) if (c < a.C) a.pWo[((size_t)bidx * a.C + c) * HID + tid] = aWo[c];
-        a.pWc[((size_t)bidx * HID + tid) * 2 + 0] = aWc0;
-        a.pWc[((size_t)bidx * HID + tid) * 2 + 1] = aWc1;
-        a.pbc[(size_t)bidx * HID + tid] = aZc;
-        s_zc[tid] = aZc;                         // dzc, consumed below for dWz / dz
+        for (int c = 0; c < MAXC; ++c) {
+            if (c >= a.C) break;
+            s_red[tid] = aWo[c];
+            __syncthreads();
+            if (tid < HID) a.pWo[((size_t)bidx * a.C + c) * HID + tid] = (s_red[tid] + s_red[tid + HID]) + (s_red[tid + 2 * HID] + s_red[tid + 3 * HID]);
+            __syncthreads();
+        }
     }
     // dbo
     __syncthreads();
