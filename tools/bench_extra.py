@@ -75,7 +75,7 @@ def bench_predict(frames=256, hw=1024, emit=True):
     rs = np.random.RandomState(0)
     stack = rs.rand(frames, hw, hw).astype(np.float32)
     p = aoi.predictors.SegPredictor(net, use_gpu=True, nb_classes=1, downsampling=2, verbose=False)
-    p.run(stack[:8], compute_coords=False)
+    p.run(stack[:min(frames, 16)], compute_coords=False)     # warm-up with a full chunk: the pinned staging buffers get their final size
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = p.run(stack, compute_coords=False)
