@@ -24,7 +24,10 @@ class DataParallelGrads:
         optimizer.prepare()
         optimizer.grad_scale = 1.0 / self.world
         # identical initial weights on every rank (buffers too: BN running stats)
-        dist.broadcast(optimizer._flat["p"], src=0)
+        self.broadcast_state(net)
+
+    def broadcast_state(self, net=None) -> None:
+        dist.broadcast(self.optimizer._flat["p"], src=0)
         if net is not None:
             for b in net.buffers():
                 dist.broadcast(b, src=0)
@@ -40,12 +43,36 @@ class DataParallelGrads:
         dist.all_reduce(f["g"], op=dist.ReduceOp.SUM)
 
 
-def init_distributed(backend: str = None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract); returns (rank, world, local)."""
+def shard_range(n: int, rank: int, world: int):
+    """Rank's contiguous, EQUAL-sized range of n samples (the n % world tail is dropped so that every rank runs
+    the same number of steps — each step holds one collective)."""
+    per = n // world
+    if per == 0:
+        raise ValueError(f"cannot shard {n} samples over {world} ranks")
+    return rank * per, (rank + 1) * per
+
+
+def shard_train_data(X, y, rank: int, world: int):
+    lo, hi = shard_range(len(X), rank, world)
+    return X[lo:hi], (None if y is None else y[lo:hi])
+
+
+def offset_rng_by_rank(rank: int) -> None:
+    """Every rank was seeded identically (set_train_rng) so that the nets are drawn identically; from here on the
+    random streams that feed DATA (loader shuffles, dropout seeds, the VAE's eps) must differ per rank."""
+    if rank:
+        import numpy as np
+        torch.manual_seed(torch.initial_seed() + rank)           # CPU generator + every GPU generator
+        np.random.seed((int(np.random.get_state()[1][0]) + rank) % (2 ** 32))
+
+
+def init_distributed(backend: str = None, force: bool = False):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract); returns (rank, world, local).
+    ``force`` creates the process group even for a world of one (the RCCL path on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -258,6 +258,8 @@ class BaseTrainer:
             var = torch.tensor(a / (1 + e) ** gamma)
             for k, v in self.net.state_dict().items():
                 v.copy_(v + v.new(v.shape).normal_(0, torch.sqrt(var)))
+            if self.dp is not None:                  # per-rank noise: replicas follow rank 0's draw
+                self.dp.broadcast_state(self.net)
 
     def save_running_weights(self, e: int) -> None:
         n_last = 5 if self.full_epoch else 30
@@ -285,6 +287,18 @@ class BaseTrainer:
         self.swa = swa
         self.lr_scheduler = kwargs.get("lr_scheduler")
         alloc = kwargs.get("memory_alloc", 4)
+        distributed = bool(kwargs.get("distributed", False))
+        rank, world = 0, 1
+        if distributed:
+            # one process per GPU, rank r trains on ITS contiguous shard of X_train (equal
+            # sizes: every step holds one collective), identical weights by broadcast, the reference's shuffle
+            # schedule (trainer.py:552-555) seeded with batch_seed + rank, rank 0 saves.  Test data is not sharded:
+            # every rank reports the same test loss as a single-process run.
+            from .. import parallel
+            rank, world, _ = parallel.init_distributed(force=True)
+            if train_data is not None and world > 1:
+                Xs, ys = parallel.shard_train_data(train_data[0], train_data[1], rank, world)
+                train_data = (Xs, ys) + tuple(train_data[2:])
         if not self.data_is_set or kwargs.get("overwrite_train_data", True):
             self.set_data(*train_data, memory_alloc=alloc)
         self.perturb_weights = perturb_weights
@@ -299,10 +313,16 @@ class BaseTrainer:
             self.optimizer = FusedAdam(params, lr=1e-3) if optimizer is None else optimizer(params)
         if isinstance(self.optimizer, FusedAdam):
             self.optimizer.prepare()
+        if distributed and self.dp is None:
+            if not isinstance(self.optimizer, FusedAdam):
+                raise TypeError("distributed=True needs the flat-bucket optimizer (FusedAdam)")
+            from ..parallel import DataParallelGrads, offset_rng_by_rank
+            self.dp = DataParallelGrads(self.optimizer, self.net)
+            offset_rng_by_rank(rank)
         if self.criterion is None:
             self.criterion = self.get_loss_fn(loss, self.nb_classes)
         if not self.full_epoch:
-            seed = kwargs.get("batch_seed", 1)
+            seed = kwargs.get("batch_seed", 1) + rank
             for name, data in (("batch_idx_train", self.X_train), ("batch_idx_test", self.X_test)):
                 reps = self.training_cycles // len(data) + 1
                 idx = np.arange(len(data)).repeat(reps)[:self.training_cycles]

@@ -92,6 +92,13 @@ class viBaseTrainer:
         if elbo_fn is not None:
             self.elbo_fn = elbo_fn
         alloc = kwargs.get("memory_alloc", 4)
+        distributed = bool(kwargs.get("distributed", False))
+        rank, world = 0, 1
+        if distributed:          # rank r trains on its shard, eps drawn per rank
+            from .. import parallel
+            rank, world, _ = parallel.init_distributed(force=True)
+            if world > 1:
+                train_data = parallel.shard_train_data(train_data[0], train_data[1], rank, world)
         if test_data is not None:
             self.set_data(*train_data, *test_data, memory_alloc=alloc)
         else:
@@ -103,6 +110,12 @@ class viBaseTrainer:
             self.optim = FusedAdam(params, lr=1e-4) if optimizer is None else optimizer(params)
         if isinstance(self.optim, FusedAdam):
             self.optim.prepare()
+        if distributed and self.dp is None:
+            if not isinstance(self.optim, FusedAdam):
+                raise TypeError("distributed=True needs the flat-bucket optimizer (FusedAdam)")
+            from ..parallel import DataParallelGrads, offset_rng_by_rank
+            self.dp = DataParallelGrads(self.optim)
+            offset_rng_by_rank(rank)
         self.filename = kwargs.get("filename", "./model")
 
     @classmethod

@@ -274,7 +274,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback (tests use --test-backend emu)")
     import atomai_amd as aoi
     from atomai_amd.parallel import DataParallelGrads, init_distributed
-    rank, world, local = init_distributed("gloo" if emu else None)
+    force_dp = os.environ.get("AMX_BENCH_FORCE_DP") == "1"      # N=1 through the RCCL branch (a 1-rank nccl group)
+    rank, world, local = init_distributed("gloo" if emu else None, force=force_dp)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hw, bs = args.hw, args.bs
@@ -294,7 +295,7 @@ def main():
     model = aoi.models.Segmentor("Unet", nb_classes=3, seed=1, nb_filters=args.nb_filters)
     model.compile_trainer((X, y, X[:bs], y[:bs]), loss="ce", training_cycles=args.steps + args.warmup,
                           batch_size=bs, plot_training_history=False)
-    if world > 1:
+    if world > 1 or force_dp:
         model.dp = DataParallelGrads(model.optimizer, model.net)
     timer = None if (args.no_kernel_timing or emu) else KernelTimer(
         ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
@@ -303,7 +304,7 @@ def main():
         Tape.use_side_stream = False
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dp:
             torch.distributed.barrier()
         sync()
 
@@ -330,7 +331,7 @@ def main():
                   "hipFree_calls_in_timed_region": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
                   "reserved_GB": round(ms1.get("reserved_bytes.all.current", 0) / 1e9, 2),
                   "peak_allocated_GB": round(ms1.get("allocated_bytes.all.peak", 0) / 1e9, 2)}
-    if world > 1:
+    if world > 1 or force_dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -351,7 +352,7 @@ def main():
         barrier()
         s_el = time.perf_counter() - s0
         clk.stop()
-        if world > 1:
+        if world > 1 or force_dp:
             t = torch.tensor([s_el], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             s_el = float(t.item())
@@ -395,7 +396,7 @@ def main():
                                "(BASELINE.json configs[1]); step = fwd+bwd+allreduce+Adam+loss.item()",
                    "global_batch": world * bs, "parallelism": f"dp{world}",
                    "world_size_seen": world,
-                   "collective_backend": ("gloo (test emulator)" if emu else ("nccl (RCCL)" if world > 1 else None)),
+                   "collective_backend": ("gloo (test emulator)" if emu else ("nccl (RCCL)" if (world > 1 or force_dp) else None)),
                    "launcher": "self" if os.environ.get("AMX_BENCH_SELF_LAUNCHED") else
                                ("torchrun" if "WORLD_SIZE" in os.environ else "single"),
                    "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]},
@@ -451,6 +452,8 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

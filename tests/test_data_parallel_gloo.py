@@ -196,3 +196,142 @@ def test_two_rank_rvae_step_matches_averaged_gradient_oracle():
     for k, v in list(dec.items()):
         a = torch.from_numpy(got[0][1]["dec|" + k]).double()
         assert float((a - v).abs().max()) < 2e-4 * max(1.0, float(v.abs().max())), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fit(..., distributed=True): the training ENTRY POINT of the data-parallel path
+def _fit_worker(rank, world, port, q, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    rs = np.random.RandomState(30)
+    X = rs.rand(8, 16, 16).astype(np.float32)                  # the WHOLE training set on every rank: fit() shards it
+    y = rs.randint(0, 3, (8, 16, 16))
+    Xt, yt = X[:2], y[:2]
+    m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, seed=1 + rank)   # different init, broadcast by fit
+    m.fit(X, y, Xt, yt, training_cycles=3, batch_size=2, distributed=True, plot_training_history=False,
+          filename=os.path.join(tmp, "seg"))
+    q.put((rank, list(m.loss_acc["train_loss"]), list(m.loss_acc["test_loss"]), list(m.batch_idx_train),
+           [t.numpy().copy() for t in m.X_train],
+           {k: v.detach().cpu().numpy().copy() for k, v in m.net.state_dict().items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_segmentor_fit_distributed_matches_averaged_gradient_oracle(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    from oracle import seg_oracle as so
+    from sklearn.utils import shuffle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, *rest = q.get(timeout=500)
+        got[r] = rest
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert os.path.exists(tmp_path / "seg_metadict_final.tar")          # rank 0 saved (and only rank 0 writes)
+    rs = np.random.RandomState(30)
+    X = rs.rand(8, 16, 16).astype(np.float32)
+    y = rs.randint(0, 3, (8, 16, 16))
+    # shards: rank r owns samples [4r, 4r+4) = 2 mini-batches; schedule = the reference's shuffle with batch_seed + rank
+    for r in range(2):
+        sched = shuffle(np.arange(2).repeat(3 // 2 + 1)[:3], random_state=1 + r)
+        assert got[r][2] == list(sched), (r, got[r][2])
+        for b in range(2):
+            np.testing.assert_array_equal(got[r][3][b][:, 0], X[4 * r + 2 * b:4 * r + 2 * b + 2])
+    # oracle: 2 replicas from rank 0's weights (seed 1), each on its own scheduled mini-batch, gradients averaged
+    sd = so.cast(so.init_unet(3, 4, seed=1), torch.float64)
+    bn = [OrderedDict(sd), OrderedDict(sd)]
+    opt = so.AdamState(lr=1e-3)
+    ref_losses = [[], []]
+    for step in range(3):
+        grads = []
+        for r in range(2):
+            b = got[r][2][step]
+            xb = torch.from_numpy(X[4 * r + 2 * b:4 * r + 2 * b + 2][:, None]).double()
+            yb = torch.from_numpy(y[4 * r + 2 * b:4 * r + 2 * b + 2])
+            rep = OrderedDict((k, (sd[k] if k in so.param_keys(sd) else bn[r][k].clone())) for k in sd)
+            loss, _, g = so.loss_and_grads("Unet", rep, xb, yb, 3)
+            ref_losses[r].append(float(loss))
+            for k in rep:
+                if k not in g:
+                    bn[r][k] = rep[k]
+            grads.append(g)
+        opt.step(sd, {k: 0.5 * (grads[0][k] + grads[1][k]) for k in grads[0]})
+    for r in range(2):
+        np.testing.assert_allclose(got[r][0], ref_losses[r], rtol=1e-4)
+    for k in so.param_keys(sd):
+        assert np.array_equal(got[0][4][k], got[1][4][k]), k
+        a = torch.from_numpy(got[0][4][k]).double()
+        assert float((a - sd[k]).abs().max()) < 3e-3 * max(1.0, float(sd[k].abs().max())), k
+
+
+def _rvae_fit_worker(rank, world, port, q, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    rs = np.random.RandomState(40)
+    X = rs.rand(16, 16, 16).astype(np.float32)
+    m = aoi.models.rVAE((16, 16), latent_dim=2, seed=rank, numhidden_encoder=32, numhidden_decoder=32)
+    seen = []
+    orig = m.forward_compute_elbo
+    m.forward_compute_elbo = lambda x, *a, **k: (seen.append(x.detach().cpu().numpy().copy()), orig(x, *a, **k))[1]
+    eps_seen = []
+    rp = m.reparameterize
+    m.reparameterize = lambda zm, zs: (lambda z: (eps_seen.append(((z - zm) / zs).detach().numpy().copy()), z)[1])(rp(zm, zs))
+    m.fit(X, training_cycles=2, batch_size=4, distributed=True, filename=os.path.join(tmp, "rvae"))
+    sd = {"enc|" + k: v.detach().numpy().copy() for k, v in m.encoder_net.state_dict().items()}
+    sd.update({"dec|" + k: v.detach().numpy().copy() for k, v in m.decoder_net.state_dict().items()})
+    q.put((rank, list(m.loss_history["train_loss"]), seen, eps_seen, sd))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rvae_fit_distributed_shards_and_keeps_replicas_identical(tmp_path):
+    """rVAE.fit(distributed=True): rank r sees only its shard, draws its own eps and shuffle, and the replicas stay
+    bit-identical (one all-reduce of the flat bucket per step); rank 0 writes the checkpoint."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rvae_fit_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, *rest = q.get(timeout=500)
+        got[r] = rest
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert os.path.exists(tmp_path / "rvae.tar")
+    rs = np.random.RandomState(40)
+    X = rs.rand(16, 16, 16).astype(np.float32)
+    for r in range(2):
+        shard = X[8 * r:8 * r + 8]
+        assert len(got[r][1]) == 4                                      # 2 epochs x 2 mini-batches of 4
+        for xb in got[r][1]:
+            for img in xb:
+                assert any(np.array_equal(img, s) for s in shard)      # only its own shard
+        assert np.isfinite(got[r][0]).all()
+    assert not np.allclose(got[0][2][0], got[1][2][0])                  # eps drawn per rank
+    for k in got[0][3]:
+        assert np.array_equal(got[0][3][k], got[1][3][k]), k           # replicas stay bit-identical
