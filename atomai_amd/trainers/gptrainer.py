@@ -44,6 +44,19 @@ class dklGPTrainer:
             y = self._set_data(y, device)
         return x, y
 
+    def _build_extractor(self, feature_net, input_dim: int, embedim: int):
+        """The reference makes the chosen precision the process-wide default tensor type (utils/nn.py:149-167), so
+        under precision='double' — the trainer's default — the Linear layers are DRAWN in float64 (a different
+        consumption of the generator than float32 draws cast up).  Same here, scoped to the construction and on the
+        CPU generator for any device (pinned by tests/golden/gp_extractor.npz)."""
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(self.dtype)
+        try:
+            net = feature_net(input_dim, embedim)
+        finally:
+            torch.set_default_dtype(prev)
+        return net.to(self.dtype).to(self.device)
+
     def compile_multi_model_trainer(self, *args, **kwargs):
         raise NotImplementedError("independent per-output networks / ensembles are outside this build's scope")
 
@@ -55,7 +68,7 @@ class dklGPTrainer:
         X, y = self.set_data(X, y)
         input_dim, embedim = self.dimdict["input_dim"], self.dimdict["embedim"]
         feature_net = kwargs.get("feature_extractor", fcFeatureExtractor)
-        feature_extractor = feature_net(input_dim, embedim).to(self.dtype).to(self.device)
+        feature_extractor = self._build_extractor(feature_net, input_dim, embedim)
         freeze = kwargs.get("freeze_weights", False)
         if freeze:
             for p in feature_extractor.parameters():

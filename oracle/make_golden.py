@@ -1,7 +1,7 @@
 """Generates the golden fixtures under tests/golden/ by importing the REAL reference
 (pycroscopy/atomai at /root/reference) in the dev container.  Run once here:
 
-    python oracle/make_golden.py [seg] [blocks] [config1] [predict] [vae]
+    python oracle/make_golden.py [seg] [blocks] [config1] [predict] [vae] [gp] ...
 
 The reference's Python never travels to the GPU box; only these small .npz vectors do.
 Every network fixture is emitted twice: reference in fp32 and the same module ``.double()``'d,
@@ -543,11 +543,52 @@ def make_vae_api(aoi):
     print("vae_api ok", out["encimg|z"].shape, out["recon"].shape)
 
 
+def make_gp(aoi):
+    """fcFeatureExtractor (nets/gp.py:14-26) exactly as dklGPTrainer builds it (gptrainer.py:162-177, 254-262):
+    ``set_seed_and_precision`` (utils/nn.py:149-167) seeds numpy / torch with 42 and makes the chosen precision the
+    DEFAULT tensor type, so under precision='double' (the trainer's default) the Linear layers are DRAWN in float64.
+    Pins state-dict keys, RNG-order init, forward and every gradient.  gpytorch itself is a stub here: nothing of the
+    GP layer is (or can be) pinned."""
+    from atomai.nets.gp import fcFeatureExtractor
+    from atomai.utils import set_seed_and_precision
+    out = {}
+    rs = np.random.RandomState(5)
+
+    def mom(v):                      # default widths: 5 numbers per tensor instead of 0.6 M values
+        v = torch.as_tensor(v).double().flatten()
+        return np.array([v.numel(), v.sum().item(), (v * v).sum().item(), v[0].item(), v[-1].item()])
+    try:
+        for tag, feat, emb, hid, prec, full in (("dbl", 48, 2, None, "double", False),
+                                                ("sgl", 48, 2, None, "single", False),
+                                                ("small", 20, 3, [32, 16], "double", True),
+                                                ("small_sgl", 20, 3, [32, 16], "single", True)):
+            set_seed_and_precision(seed=42, precision=prec)
+            kw = {} if hid is None else {"hidden_dim": list(hid)}
+            net = fcFeatureExtractor(feat, emb, **kw)
+            keep = (lambda v: v.detach().numpy().copy()) if full else mom
+            out[f"{tag}|keys"] = np.array(list(net.state_dict().keys()))
+            out.update({f"{tag}|init|{k}": keep(v) for k, v in net.state_dict().items()})
+            x = rs.rand(37, feat)
+            w = rs.randn(37, emb)
+            out[f"{tag}|x"], out[f"{tag}|w"] = x, w
+            out[f"{tag}|meta"] = np.array([feat, emb, int(prec == "double"), int(full)] + (hid or [1000, 500, 50]))
+            for dt, dtag in ((torch.float32, "f32"), (torch.float64, "f64")):
+                n2 = copy.deepcopy(net).to(dt)
+                y = n2(torch.from_numpy(x).to(dt))
+                (y * torch.from_numpy(w).to(dt)).sum().backward()
+                out[f"{tag}|y|{dtag}"] = y.detach().numpy()
+                out.update({f"{tag}|grad|{k}|{dtag}": keep(p.grad) for k, p in n2.named_parameters()})
+            print("gp", tag, {k: tuple(v.shape) for k, v in net.state_dict().items()}, net.linear1.weight.dtype)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(GOLD, "gp_extractor.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp}[w](aoi)
     print("done ->", GOLD)

@@ -259,3 +259,47 @@ def check_dklgpr_conv_extractor(device, N=256, p=8, cycles=2, precision="single"
     s2 = float(m.gp_model.outputscale[0])
     assert (var >= 0).all() and (var <= s2 * (1 + 1e-4)).all()
     return m
+
+
+def check_extractor_golden(device):
+    """fcFeatureExtractor vs tests/golden/gp_extractor.npz (generated by the real reference, oracle/make_golden.py gp):
+    state-dict keys, RNG-order initialisation as dklGPTrainer draws it (seed 42, in the trainer's precision), forward
+    and every gradient in fp32 (MFMA GEMM path) and fp64 (library path), each within the golden's own fp32 floor."""
+    import os
+    from atomai_amd.trainers import dklGPTrainer
+    from atomai_amd.nets.gp import fcFeatureExtractor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gp_extractor.npz"))
+
+    def mom(v):
+        v = v.detach().double().flatten().cpu()
+        return np.array([v.numel(), v.sum().item(), (v * v).sum().item(), v[0].item(), v[-1].item()])
+    for tag in ("dbl", "sgl", "small", "small_sgl"):
+        meta = g[f"{tag}|meta"]
+        feat, emb, dbl, full, hid = int(meta[0]), int(meta[1]), bool(meta[2]), bool(meta[3]), [int(v) for v in meta[4:]]
+        tr = dklGPTrainer(feat, emb, precision="double" if dbl else "single", device=device)
+        fx = (lambda i, e: fcFeatureExtractor(i, e, hidden_dim=list(hid))) if tag.startswith("small") else fcFeatureExtractor
+        net = tr._build_extractor(fx, feat, emb)
+        assert list(net.state_dict().keys()) == list(g[f"{tag}|keys"])
+        for k, v in net.state_dict().items():
+            assert v.dtype == (torch.float64 if dbl else torch.float32)
+            ref = g[f"{tag}|init|{k}"]
+            if full:
+                assert np.array_equal(v.cpu().numpy(), ref), (tag, k)          # bit-equal RNG-order init
+            else:
+                np.testing.assert_allclose(mom(v), ref, rtol=1e-12, atol=0, err_msg=f"{tag} {k}")
+        x, w = g[f"{tag}|x"], g[f"{tag}|w"]
+        for dt, dtag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            import copy
+            n2 = copy.deepcopy(net).to(dt)
+            y = n2(torch.from_numpy(x).to(dt).to(device))
+            (y * torch.from_numpy(w).to(dt).to(device)).sum().backward()
+            y64 = g[f"{tag}|y|f64"]
+            floor = np.abs(g[f"{tag}|y|f32"] - y64).max()
+            tol = 1e-10 if dt == torch.float64 else max(4 * floor, 1e-6 * np.abs(y64).max())
+            assert np.abs(y.detach().cpu().numpy() - y64).max() <= tol, (tag, dtag)
+            for k, p in n2.named_parameters():
+                r64, r32 = g[f"{tag}|grad|{k}|f64"], g[f"{tag}|grad|{k}|f32"]
+                got = p.grad.cpu().numpy() if full else mom(p.grad)
+                fl = np.abs(r32 - r64).max()
+                tol = 1e-9 * max(1.0, np.abs(r64).max()) if dt == torch.float64 else max(4 * fl, 1e-5 * np.abs(r64).max())
+                assert np.abs(got - r64).max() <= tol, (tag, dtag, k, np.abs(got - r64).max(), tol)

@@ -37,6 +37,10 @@ def test_dklgpr_api():
     G.check_dklgpr_api()
 
 
+def test_feature_extractor_vs_reference_golden():
+    G.check_extractor_golden("cpu")
+
+
 def test_gpytorch_known_answer_vectors():
     G.check_gpytorch_known_answers_oracle()
     G.check_gpytorch_known_answers_kernel("cpu")

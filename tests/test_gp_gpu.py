@@ -24,6 +24,10 @@ def test_dklgpr_api():
     G.check_dklgpr_api()
 
 
+def test_feature_extractor_vs_reference_golden():
+    G.check_extractor_golden("cuda")
+
+
 def test_config5_covariance_properties():
     """BASELINE.json configs[4] size (N = 16384 embedded points, RBF): size-independent properties of the tiled
     builder — symmetry, unit-scaled diagonal, agreement of K @ v with the matrix-free mat-vec, row checksums vs
