@@ -154,6 +154,37 @@ class _PackCache:
 
 _pack_cache = _PackCache()
 
+_bn_generation = [0]          # bumped by every training-mode amx_bn_finalize (it updates running stats through raw pointers)
+_eval_cache: Dict[tuple, tuple] = {}
+
+
+def cached_eval(owner, tensors, extra: tuple, build):
+    """Eval-mode constants derived from parameters / BatchNorm buffers only (the eval affine, the folded head weights):
+    built once per (tensor storage, tensor version, optimizer generation, BatchNorm generation) instead of on every
+    predictor chunk."""
+    ver = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (_weight_generation[0], _bn_generation[0])
+    key = (id(owner),) + extra
+    hit = _eval_cache.get(key)
+    if hit is not None and hit[0]() is owner and hit[1] == ver:
+        return hit[2]
+    val = build()
+    if len(_eval_cache) > 4096:
+        for k in [k for k, v in _eval_cache.items() if v[0]() is None]:
+            del _eval_cache[k]
+    _eval_cache[key] = (weakref.ref(owner), ver, val)
+    return val
+
+
+def bn_eval_affine(bn, cout: int, cos: int, like: torch.Tensor):
+    """(scale, shift) of an eval-mode BatchNorm, cached."""
+    def build():
+        scale, shift = _empty((cos,), like), _empty((cos,), like)
+        L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
+               L.ptr(bn.running_var), bn.eps, cout, cos, L.ptr(scale), L.ptr(shift), _sp(like))
+        return scale, shift
+    return cached_eval(bn, (bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                       ("affine", cout, cos, float(bn.eps), like.device.index), build)
+
 
 def _empty(shape, like: torch.Tensor, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
@@ -299,6 +330,8 @@ class ConvNode(_Node):
             hook = DROPOUT_MASK_HOOK[0]
             mask_in = hook(tuple(y.shape), self.drop_p).to(y.device).float().contiguous() if hook else None
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: reproducible under manual_seed
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed ^= torch.distributed.get_rank() << 48             # data-parallel ranks draw different masks
             L.call("amx_dropout_fwd", L.ptr(y), L.ptr(self.mask), L.ptr(mask_in), self.drop_p, seed, L.ptr(stats),
                    npix, cos, cop, self.rows, self.rows_pix, _sp(y))
             stat_mode = 1
@@ -306,12 +339,13 @@ class ConvNode(_Node):
         scale = shift = None
         if self.bn is not None:
             bn = self.bn
-            scale, shift = _empty((cos,), y), _empty((cos,), y)
             if tape.training:
+                scale, shift = _empty((cos,), y), _empty((cos,), y)
+                _bn_generation[0] += 1
                 self.save_mean, self.save_invstd = _empty((cos,), y), _empty((cos,), y)
                 mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
                 nrows = self.rows
-                if (nrows > 512 or stat_mode == 3) and not drop:   # two-stage merge: coalesced chunk merge, then per channel
+                if nrows > 512 or stat_mode == 3:                  # two-stage merge: coalesced chunk merge, then per channel
                     nch = max(1, min(1024, nrows // 32))           # (the only consumer of the lattice row order)
                     merged = _empty((nch, 3, cop), y)
                     L.call("amx_bn_stats_merge", L.ptr(stats), nrows, cop, stat_mode, N, H, W,
@@ -324,9 +358,7 @@ class ConvNode(_Node):
                 if bn.num_batches_tracked is not None:
                     tape.bn_counters.append(bn.num_batches_tracked)      # += 1 for all layers in ONE launch
             else:
-                L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()),
-                       L.ptr(bn.running_mean), L.ptr(bn.running_var), bn.eps, self.cout, cos,
-                       L.ptr(scale), L.ptr(shift), _sp(y))
+                scale, shift = bn_eval_affine(bn, self.cout, cos, y)
         needs = tape.need_grad
         return Act(y, self.cout, scale, shift, needs_grad=needs)
 
@@ -765,17 +797,20 @@ class HeadNode(_Node):
         cos, cop = r4(cout), r16(cout)
         assert w.shape[1] == C0 + C1 and px.weight.shape[1] == cout
         wpk = pack_weights(w, C0, C0s, C1, C1s, 9, 0)
-        Wp = px.weight.detach().reshape(K, cout)
-        hw = torch.zeros((K, cop), dtype=torch.float32, device=s0.t.device)
-        if bn is not None:                                   # fold the layer's own eval-mode affine into the head
-            scale, shift = _empty((cos,), s0.t), _empty((cos,), s0.t)
-            L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
-                   L.ptr(bn.running_var), bn.eps, cout, cos, L.ptr(scale), L.ptr(shift), _sp(s0.t))
-            hw[:, :cout] = Wp * scale[:cout]
-            hb = (px.bias.detach() + (Wp * shift[:cout]).sum(1)).contiguous()
-        else:
-            hw[:, :cout] = Wp
-            hb = px.bias.detach().contiguous()
+
+        def fold():
+            Wp = px.weight.detach().reshape(K, cout)
+            hw = torch.zeros((K, cop), dtype=torch.float32, device=s0.t.device)
+            if bn is not None:                               # fold the layer's own eval-mode affine into the head
+                scale, shift = bn_eval_affine(bn, cout, cos, s0.t)
+                hw[:, :cout] = Wp * scale[:cout]
+                hb = (px.bias.detach() + (Wp * shift[:cout]).sum(1)).contiguous()
+            else:
+                hw[:, :cout] = Wp
+                hb = px.bias.detach().contiguous()
+            return hw, hb
+        deps = (px.weight, px.bias) + ((bn.weight, bn.bias, bn.running_mean, bn.running_var) if bn is not None else ())
+        hw, hb = cached_eval(px, deps, ("head", id(bn), cop, s0.t.device.index), fold)
         shape = (N, K, H, W) if mode == 0 else (N, H, W, K)
         self.value = _empty(shape, s0.t)
         L.call("amx_conv2d_fwd_head", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), C0s,
@@ -810,9 +845,7 @@ class DsumConvNode(_Node):
         wpk = pack_weights(w, src.C, src.Cs, 0, 0, 9, 0)
         zero = torch.zeros((cos,), dtype=torch.float32, device=src.t.device)
         if bn is not None:
-            scale, shift = _empty((cos,), src.t), _empty((cos,), src.t)
-            L.call("amx_bn_eval_affine", L.ptr(bn.weight.detach()), L.ptr(bn.bias.detach()), L.ptr(bn.running_mean),
-                   L.ptr(bn.running_var), bn.eps, cout, cos, L.ptr(scale), L.ptr(shift), _sp(src.t))
+            scale, shift = bn_eval_affine(bn, cout, cos, src.t)
         else:
             scale = shift = zero
         scs = [(a.scale if a.scale is not None else zero) for a in acts] + [scale]
@@ -820,7 +853,7 @@ class DsumConvNode(_Node):
         n = len(acts)
         PA, PS = ctypes.c_void_p * n, ctypes.c_void_p * (n + 1)
         y = _empty((N, H, W, cos), src.t)
-        self.keep = (scs, shs, zero)
+        self.keep = (scs, shs, zero, [a.t for a in acts])     # raw data_ptr() arrays below: keep every tensor alive
         L.call("amx_conv2d_fwd_dsum", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), src.Cs, L.ptr(wpk),
                L.ptr(b.detach() if b is not None else None), PA(*[a.t.data_ptr() for a in acts]),
                PS(*[t.data_ptr() for t in scs]), PS(*[t.data_ptr() for t in shs]), n, L.ptr(y), N, H, W, cout,

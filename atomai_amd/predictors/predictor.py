@@ -291,7 +291,8 @@ class SegPredictor(BasePredictor):
         """``predict`` with the frames of the stack sharded over the ranks of the initialised process group (one
         process per GPU).  Every rank passes the SAME stack (or a memory-map of it) and decodes only its contiguous
         range; normalisation uses the global min / ptp (`_global_min_ptp`).  With ``gather`` rank 0 returns the whole
-        decoded stack (other ranks return their own range); without it every rank returns (lo, decoded range)."""
+        decoded stack (other ranks return their own range — possibly empty, shape (0, H, W, C)); without it every rank
+        returns (lo, decoded range)."""
         import torch.distributed as dist
         rank, world = self._dist_world()
         if image_data.ndim == 2:
@@ -310,22 +311,25 @@ class SegPredictor(BasePredictor):
             self._fixed_norm = None
         if world == 1:
             return mine if gather else (lo, mine)
+        # a rank whose range is empty (more ranks than frames) returns an EMPTY (0, H, W, C) array, never None
+        shapes = [None] * world
+        dist.all_gather_object(shapes, None if mine is None else mine.shape[1:])
+        shape = next(s_ for s_ in shapes if s_ is not None)
+        if mine is None:
+            mine = np.empty((0,) + tuple(shape), dtype=np.float32)
         if not gather:
             return lo, mine
-        # gather on rank 0: equal-sized (padded) blocks through the backend's device, a bounded number of frames at a
-        # time so that a 17 GB stack never needs a second full copy on one GPU
+        # gather on rank 0 (ONLY rank 0 returns the complete stack; the others return their own range): equal-sized
+        # (padded) blocks through the backend's device, a bounded number of frames at a time so that a 17 GB stack never
+        # needs a second full copy on one GPU
         cnt = max(self.frame_range(n, r, world)[1] - self.frame_range(n, r, world)[0] for r in range(world))
-        shape = None if mine is None else mine.shape[1:]
-        shapes = [None] * world
-        dist.all_gather_object(shapes, shape)
-        shape = next(s_ for s_ in shapes if s_ is not None)
         dev = self.device if dist.get_backend() == "nccl" else "cpu"
         out = np.empty((n,) + tuple(shape), dtype=np.float32) if rank == 0 else None
         step = max(1, (256 << 20) // (int(np.prod(shape)) * 4))
         for s in range(0, cnt, step):
             m = min(step, cnt - s)
             blk = torch.zeros((m,) + tuple(shape), dtype=torch.float32, device=dev)
-            if mine is not None and s < len(mine):
+            if s < len(mine):
                 k = min(m, len(mine) - s)
                 blk[:k] = torch.from_numpy(mine[s:s + k]).to(dev)
             bufs = [torch.empty_like(blk) for _ in range(world)] if rank == 0 else None

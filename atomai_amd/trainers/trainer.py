@@ -37,7 +37,8 @@ class _EarlyScalar:
     a 19 ms U-Net step).  The value exists as soon as the forward pass is done: it is copied to pinned host memory on a
     side stream right then, and ``item()`` waits for that copy only.  Same value, same place in the program; the next
     step's kernels simply queue up behind the current backward.  AMX_EARLY_LOSS=0 restores the plain ``.item()``."""
-    _pinned = {}
+    _pinned = {}                                   # device index -> [ring of pinned scalars, next slot]
+    _RING = 64
 
     def __init__(self, t: torch.Tensor):
         self.t, self.ev = t, None
@@ -49,9 +50,13 @@ class _EarlyScalar:
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         st.wait_event(ready)
-        buf = _EarlyScalar._pinned.get(dev.index)
-        if buf is None:
-            buf = _EarlyScalar._pinned[dev.index] = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        ring = _EarlyScalar._pinned.get(dev.index)
+        if ring is None:
+            ring = _EarlyScalar._pinned[dev.index] = [torch.empty(self._RING, dtype=torch.float32, pin_memory=True), 0]
+        # every instance owns its slot: a second trainer (or a second loss of the same step) cannot overwrite a value
+        # that has not been read yet (up to _RING values in flight per device)
+        buf = ring[0][ring[1]:ring[1] + 1]
+        ring[1] = (ring[1] + 1) % self._RING
         with torch.cuda.stream(st):
             buf.copy_(t.detach().reshape(1).float(), non_blocking=True)
         self.buf, self.ev = buf, torch.cuda.Event()

@@ -56,6 +56,9 @@ def _worker(rank, world, port, q):
     res["coords"] = (dec, coords)
     lo, part = p.predict(_stack(), distributed=True, gather=False)
     res["nogather"] = (lo, part)
+    # more ranks than frames: 1 frame over 2 ranks -> rank 0's range is EMPTY ([0,0)), rank 1 owns the frame
+    p = aoi.predictors.SegPredictor(_model(), use_gpu=False, nb_classes=1, downsampling=2, verbose=True)
+    res["one_frame"] = p.run(_stack()[:1], compute_coords=True, distributed=True, thresh=0.5)
     q.put((rank, res))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -95,6 +98,9 @@ def test_two_rank_predict_is_bit_identical_to_single_process():
     for i in c1:
         assert np.array_equal(coords[i], c1[i])
     assert got[0]["nogather"][0] == 0 and got[1]["nogather"][0] == 2
+    dec0, c0 = sp.run(_stack()[:1], compute_coords=True, thresh=0.5)
+    assert got[0]["one_frame"][0].shape == (1, 20, 24, 1) and np.array_equal(got[0]["one_frame"][0], dec0)
+    assert list(got[0]["one_frame"][1]) == [0] and np.array_equal(got[0]["one_frame"][1][0], c0[0])
     assert np.array_equal(got[1]["nogather"][1], dec1[2:5])
 
 
