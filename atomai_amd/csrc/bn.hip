@@ -245,7 +245,8 @@ extern "C" int amx_bn_bwd_finalize(const float* part, int rows, int stride, int 
 
 // ------------------------------------------------------------------ backward: apply
 // dpre = gx + lrelu'(a) * (gx + k1*dy + k2*a + k3)      (gx == 0 unless DilatedBlock, blocks.py:321-329)
-// k1/k2/k3 may be null (no BatchNorm): dpre = gx + lrelu'(a) * (gx + dy).
+// k1/k2/k3 may be null (no BatchNorm): dpre = gx + lrelu'(a) * dy — the block then sums only (pre, a), and dy, the
+// gradient of the value the consumers see (= a), already contains gx (engine.Tape.accumulate).
 // part[b][Cs] = per-block sum of dpre (conv bias gradient).
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ gx,
@@ -266,11 +267,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             const float4 v = amx_ld4(a + o);
             float4 e = make_float4(0, 0, 0, 0);
             if (gx) e = amx_ld4(gx + o);
+            const float ei = k1 ? 1.f : 0.f;      // the activation is a summed sub-layer of its own only under a BatchNorm
             float4 d;
-            d.x = e.x + (v.x > 0.f ? 1.f : slope) * (e.x + fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)));
-            d.y = e.y + (v.y > 0.f ? 1.f : slope) * (e.y + fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y)));
-            d.z = e.z + (v.z > 0.f ? 1.f : slope) * (e.z + fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)));
-            d.w = e.w + (v.w > 0.f ? 1.f : slope) * (e.w + fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w)));
+            d.x = e.x + (v.x > 0.f ? 1.f : slope) * (ei * e.x + fmaf(c1.x, g.x, fmaf(c2.x, v.x, c3.x)));
+            d.y = e.y + (v.y > 0.f ? 1.f : slope) * (ei * e.y + fmaf(c1.y, g.y, fmaf(c2.y, v.y, c3.y)));
+            d.z = e.z + (v.z > 0.f ? 1.f : slope) * (ei * e.z + fmaf(c1.z, g.z, fmaf(c2.z, v.z, c3.z)));
+            d.w = e.w + (v.w > 0.f ? 1.f : slope) * (ei * e.w + fmaf(c1.w, g.w, fmaf(c2.w, v.w, c3.w)));
             amx_st4(dpre + o, d);
             sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
         }

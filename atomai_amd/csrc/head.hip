@@ -292,3 +292,59 @@ extern "C" int amx_bce_fwd_bwd(const float* logits, const float* target, float* 
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------ IoU confusion counts (SegTrainer.accuracy_fn)
+// The reference's IoU (losses_metrics/metrics.py:16-95) moves logits and labels to the host, thresholds the softmax /
+// sigmoid probabilities at `thresh` (cv2.threshold THRESH_BINARY: p > thresh -> 1), squeezes the channels into a class
+// map (sum_c c * [p_c > thresh], values above K-1 clipped to 0) and builds a K x K confusion histogram per image with
+// torch.bincount.  Here one pass over the logits produces the same per-image integer histograms on the device (integer
+// atomics: exact and order independent); the host reads N*Kc*Kc integers and finishes the 10-flop Jaccard arithmetic.
+// logits NCHW [N][K][HW]; truth int64 [N][HW] (K > 1) or float [N][HW] (K == 1, binary masks); Kc = max(K, 2);
+// hist int32 [N][Kc][Kc] (zeroed by the caller).  Pixels whose label is outside [0, Kc) are skipped (metrics.py:73).
+__global__ __launch_bounds__(256) void iou_hist_kernel(const float* __restrict__ x, const long long* __restrict__ ti,
+                                                       const float* __restrict__ tf, int* __restrict__ hist,
+                                                       long HW, int K, int Kc, float thresh, int blocks_per_img) {
+    __shared__ int sh[MAXCLS * MAXCLS < 4 ? 4 : MAXCLS * MAXCLS];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / blocks_per_img, b = blockIdx.x - n * blocks_per_img;
+    for (int i = tid; i < Kc * Kc; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (long hw = (long)b * 256 + tid; hw < HW; hw += (long)blocks_per_img * 256) {
+        const float* xp = x + (size_t)n * K * HW + hw;
+        int pred = 0;
+        if (K == 1) {
+            const float p = 1.f / (1.f + expf(-xp[0]));
+            pred = p > thresh ? 1 : 0;
+        } else {
+            float v[MAXCLS];
+            float mx = -3.4e38f;
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = xp[(size_t)k * HW]; mx = fmaxf(mx, v[k]); }
+            float s = 0.f;
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = expf(v[k] - mx); s += v[k]; }
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; if (v[k] / s > thresh) pred += k; }
+            if (pred > K - 1) pred = 0;                          // squeeze_channels(clip=True), imaug.py:385-386
+        }
+        const long t = ti ? (long)ti[(size_t)n * HW + hw] : (long)tf[(size_t)n * HW + hw];   // .long(): truncation
+        if (t >= 0 && t < Kc) atomicAdd(&sh[(int)t * Kc + pred], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < Kc * Kc; i += 256)
+        if (sh[i]) atomicAdd(&hist[(size_t)n * Kc * Kc + i], sh[i]);
+}
+
+extern "C" int amx_iou_hist(const float* logits, const long long* truth_i64, const float* truth_f32, int N, int K,
+                            long HW, float thresh, int* hist, void* stream) {
+    if (!logits || !hist || N <= 0 || HW <= 0 || K < 1 || K > MAXCLS) AMX_BADARG(1);
+    if ((truth_i64 == nullptr) == (truth_f32 == nullptr)) AMX_BADARG(2);
+    const int Kc = K < 2 ? 2 : K;
+    long bpi = (HW + 256L * 16 - 1) / (256L * 16);               // ~16 pixels per thread
+    if (bpi < 1) bpi = 1;
+    if (bpi > 1024) bpi = 1024;
+    AMX_LAUNCH(iou_hist_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, (hipStream_t)stream, logits, truth_i64,
+               truth_f32, hist, HW, K, Kc, thresh, (int)bpi);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

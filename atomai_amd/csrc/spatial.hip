@@ -267,9 +267,12 @@ extern "C" int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int 
 // ------------------------------------------------------------------ DilatedBlock sum
 // out (+)= sum_i [ pre_i + a_i + bn_i ],  pre_i = a_i > 0 ? a_i : a_i / slope  (inverse LeakyReLU),
 // bn_i = a_i*scale_i + shift_i (omitted when the block has no BatchNorm: scale_i == nullptr).
+// amx_dilated_sum_ex: out (+)= sum_i [ wpre * pre_i + wact * a_i + bn_i ] — a Dropout layer inside the block is one
+// more sub-layer whose output is summed (eval mode: Dropout is the identity, so pre_i counts twice: wpre = 2; training:
+// the un-dropped convolution output is one extra pre term: a second call with wpre = 1, wact = 0 on the unmasked tensors).
 struct DilSumArgs {
     const float* a[4]; const float* scale[4]; const float* shift[4];
-    int n; int accumulate; float inv_slope;
+    int n; int accumulate; float inv_slope; float wpre; float wact;
 };
 
 __global__ void dilated_sum_kernel(DilSumArgs p, float* __restrict__ out, size_t n4, int G) {
@@ -284,18 +287,35 @@ __global__ void dilated_sum_kernel(DilSumArgs p, float* __restrict__ out, size_t
             const float4 v = amx_ld4(p.a[k] + i * 4);
             float4 sc = make_float4(0, 0, 0, 0), sh = sc;
             if (p.scale[k]) { sc = amx_ld4(p.scale[k] + cg * 4); sh = amx_ld4(p.shift[k] + cg * 4); }
-            acc.x += (v.x > 0.f ? v.x : v.x * p.inv_slope) + v.x + fmaf(v.x, sc.x, sh.x);
-            acc.y += (v.y > 0.f ? v.y : v.y * p.inv_slope) + v.y + fmaf(v.y, sc.y, sh.y);
-            acc.z += (v.z > 0.f ? v.z : v.z * p.inv_slope) + v.z + fmaf(v.z, sc.z, sh.z);
-            acc.w += (v.w > 0.f ? v.w : v.w * p.inv_slope) + v.w + fmaf(v.w, sc.w, sh.w);
+            if (p.wpre == 1.f && p.wact == 1.f) {            // the plain block: the original expression, bit for bit
+                acc.x += (v.x > 0.f ? v.x : v.x * p.inv_slope) + v.x + fmaf(v.x, sc.x, sh.x);
+                acc.y += (v.y > 0.f ? v.y : v.y * p.inv_slope) + v.y + fmaf(v.y, sc.y, sh.y);
+                acc.z += (v.z > 0.f ? v.z : v.z * p.inv_slope) + v.z + fmaf(v.z, sc.z, sh.z);
+                acc.w += (v.w > 0.f ? v.w : v.w * p.inv_slope) + v.w + fmaf(v.w, sc.w, sh.w);
+            } else {
+                acc.x += p.wpre * (v.x > 0.f ? v.x : v.x * p.inv_slope) + p.wact * v.x + fmaf(v.x, sc.x, sh.x);
+                acc.y += p.wpre * (v.y > 0.f ? v.y : v.y * p.inv_slope) + p.wact * v.y + fmaf(v.y, sc.y, sh.y);
+                acc.z += p.wpre * (v.z > 0.f ? v.z : v.z * p.inv_slope) + p.wact * v.z + fmaf(v.z, sc.z, sh.z);
+                acc.w += p.wpre * (v.w > 0.f ? v.w : v.w * p.inv_slope) + p.wact * v.w + fmaf(v.w, sc.w, sh.w);
+            }
         }
         amx_st4(out + i * 4, acc);
     }
 }
 
+extern "C" int amx_dilated_sum_ex(const float* const* a, const float* const* scale,
+                                  const float* const* shift, int n, float slope, int accumulate, float wpre,
+                                  float wact, float* out, long npix, int Cs, void* stream);
+
 extern "C" int amx_dilated_sum(const float* const* a, const float* const* scale,
                                const float* const* shift, int n, float slope, int accumulate,
                                float* out, long npix, int Cs, void* stream) {
+    return amx_dilated_sum_ex(a, scale, shift, n, slope, accumulate, 1.f, 1.f, out, npix, Cs, stream);
+}
+
+extern "C" int amx_dilated_sum_ex(const float* const* a, const float* const* scale,
+                                  const float* const* shift, int n, float slope, int accumulate, float wpre,
+                                  float wact, float* out, long npix, int Cs, void* stream) {
     if (!a || !out || n < 1 || n > 4 || (Cs & 3) || Cs <= 0 || slope == 0.f) AMX_BADARG(1);
     DilSumArgs p;
     for (int k = 0; k < 4; ++k) {
@@ -303,7 +323,7 @@ extern "C" int amx_dilated_sum(const float* const* a, const float* const* scale,
         p.scale[k] = (k < n && scale) ? scale[k] : nullptr;
         p.shift[k] = (k < n && shift) ? shift[k] : nullptr;
     }
-    p.n = n; p.accumulate = accumulate; p.inv_slope = 1.0f / slope;
+    p.n = n; p.accumulate = accumulate; p.inv_slope = 1.0f / slope; p.wpre = wpre; p.wact = wact;
     const size_t n4 = (size_t)npix * (Cs / 4);
     AMX_LAUNCH(dilated_sum_kernel, GRID_FOR(n4), dim3(256), 0, (hipStream_t)stream, p, out, n4, Cs / 4);
     AMX_CHECK_LAUNCH();

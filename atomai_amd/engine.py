@@ -60,7 +60,7 @@ class Act:
     """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
     per-channel affine of the producing BatchNorm (None == identity)."""
     __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad", "producer",
-                 "first_consumer", "bstats", "post_slope")
+                 "first_consumer", "bstats", "post_slope", "unmasked")
 
     def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
         self.t = t
@@ -71,6 +71,7 @@ class Act:
                                                       # (ResBlock's conv -> BN -> activation order); 1.0 = none
         self.grad: Optional[torch.Tensor] = None      # d loss / d (value the consumers see), NHWC
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
+        self.unmasked: Optional[torch.Tensor] = None  # DilatedBlock + training Dropout: lrelu(conv) BEFORE the mask
         self.needs_grad = needs_grad
         # No object references from an activation back to graph nodes: node <-> activation cycles would keep
         # gigabytes of device memory alive until the cyclic garbage collector happens to run (erratic step times).
@@ -238,8 +239,9 @@ class ConvNode(_Node):
     """conv (3x3 / dilated / 1x1) [+bias] [+LeakyReLU] [+BatchNorm statistics] over 1 or 2 sources."""
 
     def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None, post_slope: float = 1.0,
-                 drop_p: float = 0.0):
+                 drop_p: float = 0.0, keep_unmasked: bool = False):
         self.srcs = list(srcs)
+        self.keep_unmasked = keep_unmasked            # DilatedBlock sums the convolution output itself too
         self.conv, self.bn, self.slope = conv, bn, float(slope)
         # training-mode nn.Dropout between the convolution and its LeakyReLU (blocks.py:68-69): applied after the fused
         # conv + activation (dropout.hip); the mask is kept for backward
@@ -327,6 +329,7 @@ class ConvNode(_Node):
             self.rows_pix = L.load().amx_rows_pix(npix)
             stats = _empty((self.rows, 2, cop), y) if want_stats else None
             self.mask = _empty(y.shape, y)
+            unmasked = y.clone() if self.keep_unmasked else None
             hook = DROPOUT_MASK_HOOK[0]
             mask_in = hook(tuple(y.shape), self.drop_p).to(y.device).float().contiguous() if hook else None
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: reproducible under manual_seed
@@ -360,7 +363,10 @@ class ConvNode(_Node):
             else:
                 scale, shift = bn_eval_affine(bn, self.cout, cos, y)
         needs = tape.need_grad
-        return Act(y, self.cout, scale, shift, needs_grad=needs)
+        act = Act(y, self.cout, scale, shift, needs_grad=needs)
+        if drop and self.keep_unmasked:
+            act.unmasked = unmasked
+        return act
 
     # -------------------------------------------------------------------------------- backward
     def backward(self, tape) -> None:
@@ -430,6 +436,8 @@ class ConvNode(_Node):
                 # d conv = mask * lrelu'(.) * (...): the saved activation is already masked, so the sign test of
                 # bn_bwd_apply is right wherever the mask is non-zero, and the mask zeroes the rest
                 L.call("amx_dropout_bwd", L.ptr(dpre), L.ptr(self.mask), dpre.numel(), sp)
+                if out.gx is not None:        # DilatedBlock: the convolution output itself is a summed sub-layer too
+                    L.call("amx_add_inplace", L.ptr(dpre), L.ptr(out.gx), dpre.numel(), sp)
                 if has_bias:                                  # bias gradient = column sums of the masked dpre
                     nch = 128 if npix >= 1024 else 1
                     tmp = _empty((nch, cos), a)
@@ -689,9 +697,12 @@ class ResizeCatNode(_Node):
 
 
 class DilatedSumNode(_Node):
-    """out = sum_i (pre_i + a_i + bn_i) over the layers of a DilatedBlock (blocks.py:321-329)."""
+    """out = sum_i (pre_i + a_i + bn_i) over the layers of a DilatedBlock (blocks.py:321-329).  With a Dropout layer in
+    the block (blocks.py:311-312) its output is one more summed sub-layer: in eval mode it equals pre_i (wpre = 2); in
+    training pre_i / a_i / bn_i are those of the DROPPED tensor and the un-dropped convolution output is added by a
+    second pass over ``act.unmasked``."""
 
-    def __init__(self, tape, acts: Sequence[Act], slope: float):
+    def __init__(self, tape, acts: Sequence[Act], slope: float, wpre: float = 1.0):
         self.acts, self.slope = list(acts), slope
         for act in self.acts:
             act.consumed_by(self)
@@ -703,8 +714,16 @@ class DilatedSumNode(_Node):
             pa = PP(*[x.t.data_ptr() for x in grp] + [0] * (4 - len(grp)))
             ps = PP(*[(x.scale.data_ptr() if x.scale is not None else 0) for x in grp] + [0] * (4 - len(grp)))
             ph = PP(*[(x.shift.data_ptr() if x.shift is not None else 0) for x in grp] + [0] * (4 - len(grp)))
-            L.call("amx_dilated_sum", pa, ps, ph, len(grp), slope, 1 if i else 0, L.ptr(y), a0.npix,
-                   a0.Cs, _sp(y))
+            L.call("amx_dilated_sum_ex", pa, ps, ph, len(grp), slope, 1 if i else 0, float(wpre), 1.0, L.ptr(y),
+                   a0.npix, a0.Cs, _sp(y))
+        um = [x.unmasked for x in acts if x.unmasked is not None]
+        for i in range(0, len(um), 4):
+            grp = um[i:i + 4]
+            pa = PP(*[t.data_ptr() for t in grp] + [0] * (4 - len(grp)))
+            zero = PP(0, 0, 0, 0)
+            L.call("amx_dilated_sum_ex", pa, zero, zero, len(grp), slope, 1, 1.0, 0.0, L.ptr(y), a0.npix, a0.Cs, _sp(y))
+        for x in acts:
+            x.unmasked = None                            # read once; nothing in backward needs it
         self.out = Act(y, a0.C, needs_grad=a0.needs_grad)
 
     def backward(self, tape) -> None:
@@ -993,8 +1012,10 @@ class Tape:
     def input(self, x: torch.Tensor) -> InputNode:
         return self._push(InputNode(self, x))
 
-    def conv(self, srcs, conv, bn=None, slope: float = 1.0, post_slope: float = 1.0, drop_p: float = 0.0) -> Act:
-        return self._push(ConvNode(self, srcs, conv, bn, slope, post_slope=post_slope, drop_p=drop_p)).out
+    def conv(self, srcs, conv, bn=None, slope: float = 1.0, post_slope: float = 1.0, drop_p: float = 0.0,
+             keep_unmasked: bool = False) -> Act:
+        return self._push(ConvNode(self, srcs, conv, bn, slope, post_slope=post_slope, drop_p=drop_p,
+                                   keep_unmasked=keep_unmasked)).out
 
     def res_out(self, t: Act, r: Act, slope: float) -> Act:
         return self._push(ResOutNode(self, t, r, slope)).out
@@ -1012,8 +1033,8 @@ class Tape:
     def resize_cat(self, srcs, H: int, W: int, mode: str) -> Act:
         return self._push(ResizeCatNode(self, srcs, H, W, mode)).out
 
-    def dilated_sum(self, acts, slope) -> Act:
-        return self._push(DilatedSumNode(self, acts, slope)).out
+    def dilated_sum(self, acts, slope, wpre: float = 1.0) -> Act:
+        return self._push(DilatedSumNode(self, acts, slope, wpre)).out
 
     def output(self, src: Act) -> OutputNode:
         return self._push(OutputNode(self, src))

@@ -1,0 +1,50 @@
+"""Accuracy metrics on the device (reference: atomai/losses_metrics/metrics.py:16-95).
+
+``IoU(true, pred, activation=True, thresh=.5).evaluate()`` has the reference's signature and result.  The reference
+moves logits and labels to the host, thresholds every frame with ``cv2.threshold`` (THRESH_BINARY: p > thresh -> 1),
+squeezes the channels into a class map (``squeeze_channels(clip=True)``, transforms/imaug.py:361-393) and builds one
+K x K confusion histogram per frame with ``torch.bincount``; here ONE kernel pass over the logits (``amx_iou_hist``,
+csrc/head.hip) produces the same per-frame integer histograms, the host reads N*K*K integers and finishes the Jaccard
+arithmetic in float32 in the reference's order (per-frame histograms accumulated, A, B, diag, 1e-10, mean).
+"""
+import torch
+
+from .. import _lib as L
+
+
+class IoU:
+    """Mean intersection over union of (labels, thresholded predictions)."""
+
+    def __init__(self, true: torch.Tensor, pred: torch.Tensor, activation: bool = True, thresh: float = 0.5):
+        if not activation:
+            raise NotImplementedError("IoU(activation=False) (probabilities in, as `pred`) is not on the device "
+                                      "path: the trainers always pass logits (trainers/trainer.py:727-737)")
+        if pred.ndim != 4:
+            raise AssertionError("expected predictions of shape (N, K, H, W)")
+        self.thresh = thresh
+        N, K = pred.shape[0], pred.shape[1]
+        HW = pred.shape[2] * pred.shape[3]
+        self.nb_classes = max(K, 2)
+        x = pred.detach().float().contiguous()
+        true = true.detach().to(x.device)
+        if true.numel() != N * HW:
+            raise AssertionError("labels and predictions must describe the same pixels")
+        ti = tf = None
+        if true.dtype.is_floating_point:
+            tf = true.float().contiguous()
+        else:
+            ti = true.long().contiguous()
+        self.hist = torch.zeros((N, self.nb_classes, self.nb_classes), dtype=torch.int32, device=x.device)
+        L.call("amx_iou_hist", L.ptr(x), L.ptr(ti), L.ptr(tf), N, K, HW, float(thresh), L.ptr(self.hist),
+               L.stream_ptr(x))
+
+    def evaluate(self) -> float:
+        per_frame = self.hist.cpu().float()                   # the only host transfer: N*K*K integers
+        hist = torch.zeros((self.nb_classes, self.nb_classes))
+        for h in per_frame:                                   # metrics.py:86-87: hist += compute_hist(frame)
+            hist += h
+        A_inter_B = torch.diag(hist)
+        A = torch.sum(hist, dim=1)
+        B = torch.sum(hist, dim=0)
+        jcd = A_inter_B / (A + B - A_inter_B + 1e-10)
+        return torch.mean(jcd[jcd == jcd]).item()

@@ -35,13 +35,6 @@ def _layers(seq: nn.Sequential):
     return out
 
 
-def _check_dropout(drop, training):
-    """DilatedBlock only: its output sums EVERY sub-layer's output, the Dropout layer's included (blocks.py:321-329)."""
-    if drop is not None and drop.p > 0 and training:
-        raise NotImplementedError("training-mode Dropout inside DilatedBlock is not on the MI355X hot path "
-                                  "(ConvBlock's is; the reference default is dropout=False)")
-
-
 def _drop_p(drop) -> float:
     return float(drop.p) if drop is not None else 0.0
 
@@ -168,14 +161,17 @@ class DilatedBlock(_HipBlock):
         from ..engine import dsum_fusable
         acts, slope = [], 0.01
         layers = _layers(self.atrous_module)
+        # A Dropout layer is one more sub-layer whose OUTPUT is summed (blocks.py:311-312, 321-329): in eval mode it is the
+        # identity (the convolution output counts twice), in training the dropped AND the un-dropped tensor are summed.
+        has_drop = any(d is not None for _, _, _, d in layers)
+        dropping = has_drop and tape.training and any(_drop_p(d) > 0 for _, _, _, d in layers)
         for i, (conv, slope, bn, drop) in enumerate(layers):
-            _check_dropout(drop, tape.training)
-            if i == len(layers) - 1 and dsum_fusable(tape, srcs, conv, acts):
+            if i == len(layers) - 1 and not has_drop and dsum_fusable(tape, srcs, conv, acts):
                 return tape.conv_dsum(srcs[0], conv, bn, slope, acts)      # eval: the block's sum in this layer's epilogue
-            a = tape.conv(srcs, conv, bn, slope)
+            a = tape.conv(srcs, conv, bn, slope, drop_p=_drop_p(drop) if dropping else 0.0, keep_unmasked=dropping)
             acts.append(a)
             srcs = [a]
-        return tape.dilated_sum(acts, slope)
+        return tape.dilated_sum(acts, slope, wpre=2.0 if (has_drop and not dropping) else 1.0)
 
 
 class ResBlock(_HipBlock):

@@ -410,4 +410,6 @@ class SegTrainer(BaseTrainer):
                                  "of classes contained in training data")
 
     def accuracy_fn(self, y, y_prob, *args):
-        raise NotImplementedError("IoU (cv2-based, CPU) is outside the MI355X hot path of this build")
+        """Mean IoU of the mini-batch (trainer.py:727-737).  As in the reference the third positional argument of
+        ``IoU`` — ``activation`` — receives ``self.nb_classes`` (truthy): the logits go through softmax / sigmoid."""
+        return losses_metrics.IoU(y, y_prob, self.nb_classes).evaluate()

@@ -177,6 +177,12 @@ int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, in
 int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int w, int Cs, int mode, void* stream);
 int amx_dilated_sum(const float* const* a, const float* const* scale, const float* const* shift, int n,
                     float slope, int accumulate, float* out, long npix, int Cs, void* stream);
+/* the same with weights on the pre-activation / activation terms: a Dropout layer inside DilatedBlock is one more
+ * summed sub-layer (blocks.py:311-312, 321-329) — eval: wpre = 2; training: an extra (wpre 1, wact 0, no scale) call
+ * over the un-dropped convolution outputs. */
+int amx_dilated_sum_ex(const float* const* a, const float* const* scale, const float* const* shift, int n,
+                       float slope, int accumulate, float wpre, float wact, float* out, long npix, int Cs,
+                       void* stream);
 
 /* ---- head: px = Conv2d(F, nb_classes, 1) (fcnn.py:115,212); losses select_loss('ce')
  * (losses_metrics/losses.py:152-155) fused fwd+bwd; mode 1 of px = SegPredictor.forward_ probabilities
@@ -190,6 +196,13 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
                    int N, int K, long HW, void* stream);
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
+/* IoU of SegTrainer.accuracy_fn (trainers/trainer.py:727-737 -> losses_metrics/metrics.py:16-95): per-image K x K
+ * confusion counts of (label, thresholded softmax / sigmoid class map) in one pass over the NCHW logits, replacing the
+ * reference's host round trip (cv2.threshold per image + squeeze_channels + torch.bincount).  Exactly one of truth_i64
+ * ([N][HW] class maps, K > 1) / truth_f32 ([N][HW] binary masks, K == 1) is non-NULL; hist is int32
+ * [N][Kc][Kc], Kc = max(K, 2), zeroed by the caller. */
+int amx_iou_hist(const float* logits, const long long* truth_i64, const float* truth_f32, int N, int K, long HW,
+                 float thresh, int* hist, void* stream);
 
 /* ---- training-mode nn.Dropout of ConvBlock (Conv2d -> Dropout(p) -> LeakyReLU -> BatchNorm2d, atomai/nets/blocks.py:
  * 59-76): applied AFTER the fused conv + LeakyReLU (LeakyReLU is positively homogeneous, the mask multiplier is >= 0).

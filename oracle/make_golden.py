@@ -543,6 +543,74 @@ def make_vae_api(aoi):
     print("vae_api ok", out["encimg|z"].shape, out["recon"].shape)
 
 
+def make_dil_drop(aoi):
+    """DilatedBlock with Dropout layers (blocks.py:311-312): the block sums the output of EVERY sub-layer, the Dropout
+    layer's included (blocks.py:321-329).  The reference's module graph is run unchanged; only the random mask is made
+    explicit (torch.nn.functional.dropout -> multiplication by a recorded mask in training, identity in eval)."""
+    import torch.nn.functional as F
+    from atomai.nets.blocks import DilatedBlock
+    out = {}
+    rs = np.random.RandomState(21)
+    orig = F.dropout
+    try:
+        for tag, bn, cin, cout, dils, H, W, p in (("bn", True, 3, 8, [2, 4], 14, 12, 0.3),
+                                                  ("nobn", False, 5, 6, [2, 4, 6], 13, 17, 0.5)):
+            torch.manual_seed(3)
+            blk = DilatedBlock(2, cin, cout, dils, dils, batch_norm=bn, dropout_=p)
+            out.update({f"{tag}|w|{k}": v.detach().numpy().copy() for k, v in blk.state_dict().items()})
+            N = 2
+            x = rs.randn(N, cin, H, W).astype(np.float32)
+            gy = rs.randn(N, cout, H, W).astype(np.float32)
+            masks = [((rs.rand(N, cout, H, W) >= p).astype(np.float32) / (1 - p)) for _ in dils]
+            out[f"{tag}|x"], out[f"{tag}|gy"], out[f"{tag}|masks"] = x, gy, np.stack(masks)
+            out[f"{tag}|meta"] = np.array([int(bn), cin, cout, H, W, int(round(p * 100))] + dils)
+            for dt, dtag in ((torch.float32, "f32"), (torch.float64, "f64")):
+                b2 = copy.deepcopy(blk).to(dt).train()
+                it = iter(masks)
+                F.dropout = lambda inp, p=0.5, training=True, inplace=False: (
+                    inp * torch.from_numpy(next(it)).to(inp.dtype) if training else inp)
+                xt = torch.from_numpy(x).to(dt).requires_grad_(True)
+                y = b2(xt)
+                y.backward(torch.from_numpy(gy).to(dt))
+                out[f"{tag}|y|{dtag}"] = y.detach().numpy()
+                out[f"{tag}|dx|{dtag}"] = xt.grad.numpy()
+                out.update({f"{tag}|grad|{k}|{dtag}": q.grad.numpy().copy() for k, q in b2.named_parameters()})
+                out.update({f"{tag}|bn|{k}|{dtag}": v.detach().numpy().copy() for k, v in b2.state_dict().items()
+                            if "running" in k})
+                b2.eval()
+                with torch.no_grad():
+                    out[f"{tag}|y_eval|{dtag}"] = b2(torch.from_numpy(x).to(dt)).numpy()
+            print("dil_drop", tag, out[f"{tag}|y|f64"].shape, float(np.abs(out[f"{tag}|y|f32"] - out[f"{tag}|y|f64"]).max()))
+    finally:
+        F.dropout = orig
+    np.savez_compressed(os.path.join(GOLD, "dilated_dropout.npz"), **out)
+
+
+def make_iou(aoi):
+    """IoU.evaluate of the reference (losses_metrics/metrics.py:16-95) on logits / labels.  cv2 is absent in this image:
+    `cv_thresh` (utils/img.py:554-564, a one-line cv2.threshold wrapper) is replaced by the documented THRESH_BINARY
+    semantics, as for the Locator golden; threshold_ / squeeze_channels / bincount / Jaccard are the reference's own."""
+    import atomai.losses_metrics.metrics as rm
+    rm.cv_thresh = lambda img, thr=.5: np.where(img > thr, 1, 0).astype(img.dtype)
+    rs = np.random.RandomState(77)
+    out = {}
+    for name, (N, K, H, W, thr, scale) in {"c3": (3, 3, 20, 24, 0.5, 2.0), "c1": (2, 1, 17, 19, 0.5, 1.5),
+                                           "c4_t03": (2, 4, 16, 16, 0.3, 3.0), "c1_t07": (3, 1, 12, 12, 0.7, 2.0),
+                                           "c3_missing": (2, 3, 16, 16, 0.5, 2.0)}.items():
+        logits = (scale * rs.randn(N, K, H, W)).astype(np.float32)
+        if K == 1:
+            true = (rs.rand(N, 1, H, W) > 0.5).astype(np.float32)
+        else:
+            true = rs.randint(0, K if name != "c3_missing" else 2, (N, H, W)).astype(np.int64)
+            if name == "c3_missing":
+                logits[:, 2] -= 10.0                         # class 2 neither labelled nor predicted: 0 / 1e-10
+        out[f"{name}|logits"], out[f"{name}|true"] = logits, true
+        out[f"{name}|cfg"] = np.array([K, thr])
+        out[f"{name}|iou"] = np.array(rm.IoU(torch.from_numpy(true), torch.from_numpy(logits), True, thr).evaluate())
+        print("iou", name, out[f"{name}|iou"])
+    np.savez_compressed(os.path.join(GOLD, "iou.npz"), **out)
+
+
 def make_gp(aoi):
     """fcFeatureExtractor (nets/gp.py:14-26) exactly as dklGPTrainer builds it (gptrainer.py:162-177, 254-262):
     ``set_seed_and_precision`` (utils/nn.py:149-167) seeds numpy / torch with 42 and makes the chosen precision the
@@ -585,10 +653,10 @@ def make_gp(aoi):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp", "dil_drop", "iou"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp, "dil_drop": make_dil_drop, "iou": make_iou}[w](aoi)
     print("done ->", GOLD)

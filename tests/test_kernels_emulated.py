@@ -159,3 +159,23 @@ def test_dense_layer_autograd():
 def test_convblock_training_dropout(bn):
     import _dropout_checks as D
     D.check_convblock_dropout("cpu", batch_norm=bn)
+
+
+def test_dilatedblock_dropout_vs_reference_golden():
+    import _dropout_checks as D
+    D.check_dilated_dropout_golden("cpu")
+
+
+def test_dilatedblock_without_batchnorm_gradients():
+    import _dropout_checks as D
+    D.check_dilated_no_batchnorm("cpu")
+
+
+def test_iou_vs_reference_golden():
+    import _metrics_checks as M
+    M.check_iou_golden("cpu")
+
+
+def test_fit_with_compute_accuracy(tmp_path):
+    import _metrics_checks as M
+    M.check_fit_with_accuracy(False, tmp_path)

@@ -226,6 +226,16 @@ def test_convblock_training_dropout(bn):
     D.check_convblock_dropout("cuda", N=3, Cin=16, Cout=40, H=70, W=50, p=0.5, batch_norm=bn)
 
 
+def test_dilatedblock_dropout_vs_reference_golden():
+    import _dropout_checks as D
+    D.check_dilated_dropout_golden("cuda")
+
+
+def test_dilatedblock_without_batchnorm_gradients():
+    import _dropout_checks as D
+    D.check_dilated_no_batchnorm("cuda")
+
+
 def test_input_normalisation_inside_the_first_layer_kernel():
     C.check_input_norm_fusion("cuda")
 
@@ -236,3 +246,13 @@ def test_classification_head_in_the_last_conv_epilogue():
 
 def test_dilated_block_sum_in_the_last_conv_epilogue():
     C.check_dsum_fusion("cuda")
+
+
+def test_iou_vs_reference_golden():
+    import _metrics_checks as M
+    M.check_iou_golden("cuda")
+
+
+def test_fit_with_compute_accuracy(tmp_path):
+    import _metrics_checks as M
+    M.check_fit_with_accuracy(True, tmp_path)
