@@ -49,6 +49,9 @@ struct RDecArgs {
     float* pbc;            // [B][HID]
     float* pWz;            // [B][HID][L]
     int B, n, L, NL, skip;
+    float* hsave;          // forward: [B][NL][HID/4][npad][4] post-activation hidden images to keep for backward, or nullptr
+    const float* hsaved;   // backward: the same buffer (then the hidden layers are NOT recomputed), or nullptr
+    int npad;              // pixels per plane of hsave (n rounded up to a multiple of 128)
     unsigned long long* prof;   // AMX_RDEC_PROFILE builds: per-wave phase clocks [workgroup][wave][8], or nullptr
 };
 
@@ -137,7 +140,8 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
 // One hidden layer on a tile: dst = tanh(W src + b) [+ res].  src/dst/res are KG-layout LDS images.
 template <int HID, int MT>
 __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, const float* src, float* dst,
-                                             const float* res, int wave, int lane) {
+                                             const float* res, int wave, int lane, float* gsave = nullptr,
+                                             int npad = 0) {
     using G = Geo<HID, MT>;
     const int p = lane & 15, g = lane >> 4;
     float4 areg[HID / 16];
@@ -172,6 +176,8 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
         const size_t o = ((size_t)(4 * wave + g) * G::PS + 16 * t + p) * 4;
         if (res) { const float4 r = amx_ld4(res + o); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
         amx_st4(dst + o, v);
+        // kept for backward: the same [feature/4][pixel][4] image in HBM (16 lanes = 256 contiguous bytes per plane)
+        if (gsave) amx_st4(gsave + ((size_t)(4 * wave + g) * npad + 16 * t + p) * 4, v);
     }
 }
 
@@ -244,7 +250,9 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
         for (int l = 0; l < a.NL; ++l) {
             float* dst = (src == buf0) ? buf1 : buf0;
             hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, src, dst,
-                                  a.skip ? h0 : nullptr, wave, lane);
+                                  a.skip ? h0 : nullptr, wave, lane,
+                                  a.hsave ? a.hsave + (((size_t)bidx * a.NL + l) * G::KG * a.npad + pix0) * 4 : nullptr,
+                                  a.npad);
             __syncthreads();
             src = dst;
         }
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------
-template <int HID, int MT, int NL>
+template <int HID, int MT, int NL, bool SAVED>
 __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     using G = Geo<HID, MT>;
     AMX_DYN_SMEM(float, smem);
@@ -301,16 +309,46 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     unsigned long long pl = __builtin_amdgcn_s_memtime();
     const unsigned long long pstart = pl;
 #endif
+    // Saved-activation mode (a.hsaved): the forward kernel kept h_1..h_NL in HBM; a tile's images are fetched into
+    // registers ahead of use (SPT float4 per layer and thread, 1 KB contiguous per wave and plane) and dropped into LDS
+    // where the recompute would have written them — no forward MFMAs, no tanh epilogues in this kernel.
+    float4 pre[SAVED ? NL : 1][G::SPT];
+    const float* hs = SAVED ? a.hsaved + (size_t)bidx * NL * G::KG * a.npad * 4 : nullptr;
+    auto fetch = [&](int pix0) {
+        if (!SAVED) return;
+        #pragma unroll
+        for (int l = 0; l < (SAVED ? NL : 1); ++l)
+            #pragma unroll
+            for (int i = 0; i < G::SPT; ++i) {
+                const int s = tid + i * G::NT;
+                const int kg = s / MT, pp = s - kg * MT;
+                pre[l][i] = amx_ld4(hs + (((size_t)l * G::KG + kg) * a.npad + pix0 + pp) * 4);
+            }
+    };
+    if (SAVED) fetch(0);
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
         coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
-        __syncthreads();
-        RD_TICK(0);
-        #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, H[l], H[l + 1],
-                                  a.skip ? H[0] : nullptr, wave, lane);
+        if (SAVED) {
+            #pragma unroll
+            for (int l = 0; l < (SAVED ? NL : 1); ++l)
+                #pragma unroll
+                for (int i = 0; i < G::SPT; ++i) {
+                    const int s = tid + i * G::NT;
+                    const int kg = s / MT, pp = s - kg * MT;
+                    amx_st4(H[l + 1] + ((size_t)kg * G::PS + pp) * 4, pre[l][i]);
+                }
             __syncthreads();
+            RD_TICK(0);
+        } else {
+            __syncthreads();
+            RD_TICK(0);
+            #pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, H[l], H[l + 1],
+                                      a.skip ? H[0] : nullptr, wave, lane);
+                __syncthreads();
+            }
         }
         RD_TICK(1);
         // ---- output layer backward: dout, dWo, dbo, ga_NL (in place over H[NL])
@@ -429,6 +467,10 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         }
         // ---- coordinate layer backward from ga_0 = H[0]
         RD_TICK(5);
+        // saved mode: the next tile's images start their way from HBM now — in flight during the coordinate-layer
+        // backward and the next tile's coordinate layer, i.e. while no MFMA operand / accumulator registers are live
+        // (issued a whole tile ahead they cost 30 spilled registers in the <128, 64, 2> class)
+        if (SAVED && pix0 + MT < a.n) fetch(pix0 + MT);
         float* s_g = H[1];                       // scratch [KG][MT][2] (H[1] is free now; NL >= 1)
         #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
@@ -576,22 +618,27 @@ static int launch_fwd(const RDecArgs& a, hipStream_t s) {
     return 0;
 }
 
-template <int HID, int MT, int NL>
-static int launch_bwd(const RDecArgs& a, hipStream_t s) {
+template <int HID, int MT, int NL, bool SAVED>
+static int launch_bwd_v(const RDecArgs& a, hipStream_t s) {
     const size_t lds = bwd_lds<HID, MT, NL>(a.skip);
     if (lds > 160 * 1024) AMX_BADARG(20);
 #ifndef AMX_EMU
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_bwd_kernel<HID, MT, NL>,
+        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_bwd_kernel<HID, MT, NL, SAVED>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr = true;
     }
 #endif
-    AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL, SAVED>), dim3(a.B), dim3(4 * HID), lds, s, a);
     AMX_CHECK_LAUNCH();
     return 0;
+}
+
+template <int HID, int MT, int NL>
+static int launch_bwd(const RDecArgs& a, hipStream_t s) {
+    return a.hsaved ? launch_bwd_v<HID, MT, NL, true>(a, s) : launch_bwd_v<HID, MT, NL, false>(a, s);
 }
 
 static int check_common(const RDecArgs& a, int hid) {
@@ -602,11 +649,31 @@ static int check_common(const RDecArgs& a, int hid) {
     return 0;
 }
 
+extern "C" long amx_rdecoder_hsave_floats(int B, int n, int hid, int NL) {
+    if (B <= 0 || n <= 0 || NL < 1 || (hid != 32 && hid != 64 && hid != 128)) return -1;
+    const long npad = ((long)n + 127) / 128 * 128;
+    return (long)B * NL * hid * npad;
+}
+
+extern "C" int amx_rdecoder_fwd_save(const float* coords, const float* theta, const float* z, const float* Wc,
+                                     const float* bc, const float* Wz, const float* W, const float* b, const float* Wo,
+                                     const float* bo, float* xrec, float* hsave, int B, int n, int L, int hid, int NL,
+                                     int skip, int C, void* stream);
+
 extern "C" int amx_rdecoder_fwd(const float* coords, const float* theta, const float* z, const float* Wc,
                                 const float* bc, const float* Wz, const float* W, const float* b, const float* Wo,
                                 const float* bo, float* xrec, int B, int n, int L, int hid, int NL, int skip,
                                 int C, void* stream) {
+    return amx_rdecoder_fwd_save(coords, theta, z, Wc, bc, Wz, W, b, Wo, bo, xrec, nullptr, B, n, L, hid, NL, skip, C,
+                                 stream);
+}
+
+extern "C" int amx_rdecoder_fwd_save(const float* coords, const float* theta, const float* z, const float* Wc,
+                                     const float* bc, const float* Wz, const float* W, const float* b, const float* Wo,
+                                     const float* bo, float* xrec, float* hsave, int B, int n, int L, int hid, int NL,
+                                     int skip, int C, void* stream) {
     RDecArgs a = {};
+    a.hsave = hsave; a.npad = (n + 127) / 128 * 128;
     a.coords = coords; a.theta = theta; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.b = b; a.Wo = Wo;
     a.bo = bo; a.xrec = xrec; a.B = B; a.n = n; a.L = L; a.NL = NL; a.skip = skip; a.C = C;
     const int rc = check_common(a, hid);
@@ -620,13 +687,31 @@ extern "C" int amx_rdecoder_fwd(const float* coords, const float* theta, const f
     return (skip || mt == 64) ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
 }
 
+extern "C" int amx_rdecoder_bwd_saved(const float* coords, const float* theta, const float* z, const float* Wc,
+                                      const float* bc, const float* Wz, const float* W, const float* Wt, const float* b,
+                                      const float* Wo, const float* bo, const float* dxrec, const float* hsaved,
+                                      float* dcoords, float* dtheta, float* dz, float* pW, float* pb, float* pWo,
+                                      float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L, int hid,
+                                      int NL, int skip, int C, void* stream);
+
 extern "C" int amx_rdecoder_bwd(const float* coords, const float* theta, const float* z, const float* Wc,
                                 const float* bc, const float* Wz, const float* W, const float* Wt, const float* b,
                                 const float* Wo, const float* bo, const float* dxrec, float* dcoords,
                                 float* dtheta, float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc,
                                 float* pbc, float* pWz, int B, int n, int L, int hid, int NL, int skip, int C,
                                 void* stream) {
+    return amx_rdecoder_bwd_saved(coords, theta, z, Wc, bc, Wz, W, Wt, b, Wo, bo, dxrec, nullptr, dcoords, dtheta, dz,
+                                  pW, pb, pWo, pbo, pWc, pbc, pWz, B, n, L, hid, NL, skip, C, stream);
+}
+
+extern "C" int amx_rdecoder_bwd_saved(const float* coords, const float* theta, const float* z, const float* Wc,
+                                      const float* bc, const float* Wz, const float* W, const float* Wt, const float* b,
+                                      const float* Wo, const float* bo, const float* dxrec, const float* hsaved,
+                                      float* dcoords, float* dtheta, float* dz, float* pW, float* pb, float* pWo,
+                                      float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L, int hid,
+                                      int NL, int skip, int C, void* stream) {
     RDecArgs a = {};
+    a.hsaved = hsaved; a.npad = (n + 127) / 128 * 128;
     a.coords = coords; a.theta = theta; a.z = z; a.Wc = Wc; a.bc = bc; a.Wz = Wz; a.W = W; a.Wt = Wt; a.b = b;
     a.Wo = Wo; a.bo = bo; a.dxrec = dxrec; a.dcoords = dcoords; a.dtheta = dtheta; a.dz = dz;
     a.pW = pW; a.pb = pb; a.pWo = pWo; a.pbo = pbo; a.pWc = pWc; a.pbc = pbc; a.pWz = pWz;

@@ -72,6 +72,10 @@ class coord_latent(nn.Module):
         self.activation = nn.Tanh() if activation else None
 
 
+import os as _os
+RDEC_SAVE = [_os.environ.get("AMX_RDEC_SAVE", "1") != "0"]     # keep hidden activations for backward (see _RDecoderFn)
+RDEC_SAVE_MAX_BYTES = 32 << 30                                   # beyond this the backward recomputes instead
+
 _RDEC_WIDTHS = (32, 64, 128)          # hidden widths the fused kernels are instantiated for (rdecoder.hip)
 
 
@@ -111,10 +115,18 @@ class _RDecoderFn(torch.autograd.Function):
         zz = z.detach().contiguous()
         xrec = torch.empty(B, n, C, dtype=torch.float32, device=coords.device)
         sp = L.stream_ptr(coords)
-        L.call("amx_rdecoder_fwd", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
+        # training: keep the hidden activations for backward (HBM round trip instead of recomputing them there) when the
+        # buffer is affordable; AMX_RDEC_SAVE=0 restores the recompute-only pair
+        hsave = None
+        if any(ctx.needs_input_grad) and RDEC_SAVE[0]:
+            nfl = L.load().amx_rdecoder_hsave_floats(B, n, hid, NL)
+            if 0 < nfl * 4 <= RDEC_SAVE_MAX_BYTES:
+                hsave = torch.empty(nfl, dtype=torch.float32, device=coords.device)
+        L.call("amx_rdecoder_fwd_save", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc.detach()), L.ptr(bc.detach()),
                L.ptr(Wz.detach().contiguous()), L.ptr(W), L.ptr(b), L.ptr(Wo.detach().contiguous()),
-               L.ptr(bo.detach().contiguous()), L.ptr(xrec), B, n, Ldim, hid, NL, int(net.skip), C, sp)
+               L.ptr(bo.detach().contiguous()), L.ptr(xrec), L.ptr(hsave), B, n, Ldim, hid, NL, int(net.skip), C, sp)
         ctx.net, ctx.hid, ctx.fused = net, hid, fused
+        ctx.hsave = hsave
         saved = [coords, zz, W, b] + [p.detach() for p in (Wc, bc, Wz, Wo, bo)] + ([th] if fused else [])
         ctx.save_for_backward(*saved)
         return xrec
@@ -136,10 +148,12 @@ class _RDecoderFn(torch.autograd.Function):
         pW, pb, pWo, pbo = e(B, NL * hid * hid), e(B, NL * hid), e(B, C * hid), e(B, C)
         pWc, pbc, pWz = e(B, hid * 2), e(B, hid), e(B, hid * Ldim)
         sp = L.stream_ptr(coords)
-        L.call("amx_rdecoder_bwd", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc), L.ptr(bc), L.ptr(Wz.contiguous()),
-               L.ptr(W), L.ptr(Wt), L.ptr(b), L.ptr(Wo.contiguous()), L.ptr(bo.contiguous()),
-               L.ptr(dxrec.contiguous()), L.ptr(dcoords), L.ptr(dtheta), L.ptr(dz), L.ptr(pW), L.ptr(pb), L.ptr(pWo),
-               L.ptr(pbo), L.ptr(pWc), L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), C, sp)
+        hsave, ctx.hsave = ctx.hsave, None
+        L.call("amx_rdecoder_bwd_saved", L.ptr(coords), L.ptr(th), L.ptr(zz), L.ptr(Wc), L.ptr(bc),
+               L.ptr(Wz.contiguous()), L.ptr(W), L.ptr(Wt), L.ptr(b), L.ptr(Wo.contiguous()), L.ptr(bo.contiguous()),
+               L.ptr(dxrec.contiguous()), L.ptr(hsave), L.ptr(dcoords), L.ptr(dtheta), L.ptr(dz), L.ptr(pW), L.ptr(pb),
+               L.ptr(pWo), L.ptr(pbo), L.ptr(pWc), L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), C, sp)
+        del hsave
 
         def rsum(part, shape):
             cols = part.shape[1]

@@ -261,6 +261,20 @@ int amx_rdecoder_bwd(const float* coords, const float* theta, const float* z, co
                      const float* bo, const float* dxrec, float* dcoords, float* dtheta, float* dz, float* pW,
                      float* pb, float* pWo, float* pbo, float* pWc, float* pbc, float* pWz, int B, int n, int L,
                      int hid, int NL, int skip, int C, void* stream);
+/* Saved-activation variant of the pair (training): the forward additionally writes the NL post-activation hidden images
+ * to hsave ([B][NL][hid/4][npad][4] floats, npad = n rounded up to 128; size from amx_rdecoder_hsave_floats) and the
+ * backward reads them back one tile ahead instead of recomputing the hidden layers (1/3 of its MFMA work and all of its
+ * tanh epilogues) — bit-identical gradients.  hsave / hsaved == NULL: exactly the functions above. */
+long amx_rdecoder_hsave_floats(int B, int n, int hid, int NL);
+int amx_rdecoder_fwd_save(const float* coords, const float* theta, const float* z, const float* Wc, const float* bc,
+                          const float* Wz, const float* W, const float* b, const float* Wo, const float* bo,
+                          float* xrec, float* hsave, int B, int n, int L, int hid, int NL, int skip, int C,
+                          void* stream);
+int amx_rdecoder_bwd_saved(const float* coords, const float* theta, const float* z, const float* Wc, const float* bc,
+                           const float* Wz, const float* W, const float* Wt, const float* b, const float* Wo,
+                           const float* bo, const float* dxrec, const float* hsaved, float* dcoords, float* dtheta,
+                           float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc, float* pbc, float* pWz,
+                           int B, int n, int L, int hid, int NL, int skip, int C, void* stream);
 
 /* ---- ELBO terms of vae_loss / rvae_loss with 'mse' (atomai/losses_metrics/vi_losses.py:13-137), fwd and bwd */
 int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd, int B, int n,

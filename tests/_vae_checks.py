@@ -139,3 +139,33 @@ def check_rdecoder_shapes(device, hid, nl, skip, hw, B=2):
     assert rel(theta.grad, ref_theta) < REL_TOL
     for a, b in [(zt.grad, z2.grad)] + [(p.grad, P[k].grad) for k, p in net.named_parameters()]:
         assert rel(a, b) < REL_TOL
+
+
+def check_rdecoder_saved_equals_recompute(device, hid, nl, skip, hw, B=3):
+    """The two backward variants of the spatial decoder — hidden activations kept by the forward kernel and read back
+    (default in training) vs recomputed per tile (AMX_RDEC_SAVE=0) — must give BIT-identical outputs and gradients."""
+    import atomai_amd.nets.ed as ed
+    from oracle import vae_oracle as vo
+    from atomai_amd.nets import rDecoderNet
+    torch.manual_seed(1)
+    net = rDecoderNet(hw, 2, nl, hid, bool(skip)).to(device)
+    grid = vo.imcoordgrid(hw[:2]).to(device)
+    theta0 = torch.cat((torch.randn(B, 1), 0.1 * torch.randn(B, 2)), 1)
+    z0 = torch.randn(B, 2)
+    res = []
+    prev = ed.RDEC_SAVE[0]
+    try:
+        for save in (True, False):
+            ed.RDEC_SAVE[0] = save
+            net.zero_grad()
+            theta = theta0.clone().to(device).requires_grad_(True)
+            zt = z0.clone().to(device).requires_grad_(True)
+            y = net.forward_grid(grid, theta, zt)
+            if save and len(res) == 0:
+                gy = torch.randn(*y.shape)
+            y.backward(gy.to(device))
+            res.append([y.detach().cpu(), theta.grad.cpu(), zt.grad.cpu()] + [p.grad.cpu().clone() for p in net.parameters()])
+    finally:
+        ed.RDEC_SAVE[0] = prev
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -75,3 +75,8 @@ def test_subimage_utilities_and_encode_images(golden_dir):
     torch.manual_seed(3)
     rec = v.reconstruct(g["big"][:8, :8][None], num_samples=4)
     assert rec.shape == g["recon"].shape
+
+
+@pytest.mark.parametrize("hid,nl,skip,hw", [(32, 2, 0, (9, 7)), (64, 3, 1, (12, 11, 2))])
+def test_rdecoder_saved_activations_equal_recompute(hid, nl, skip, hw):
+    V.check_rdecoder_saved_equals_recompute("cpu", hid, nl, skip, hw)

@@ -60,3 +60,8 @@ def test_rvae_fit_loss_improves_and_is_deterministic(tmp_path):
         hist.append(list(m.loss_history["train_loss"]))
     assert hist[0] == hist[1]
     assert hist[0][-1] > hist[0][0]          # ELBO increases
+
+
+@pytest.mark.parametrize("hid,nl,skip,hw", [(128, 2, 0, (64, 64)), (128, 3, 1, (24, 24)), (100, 5, 0, (33, 31, 3)), (64, 1, 0, (7, 5))])
+def test_rdecoder_saved_activations_equal_recompute(hid, nl, skip, hw):
+    V.check_rdecoder_saved_equals_recompute("cuda", hid, nl, skip, hw)

@@ -26,14 +26,20 @@ def timed_calls(names):
     return recs
 
 
-def bench_rvae(steps=10, warmup=3, B=512, emit=True):
+def bench_rvae(steps=10, warmup=3, B=512, emit=True, ab=True):
+    """configs[3] on one GPU.  Rooflines are priced on the ALGORITHMIC FLOPs of SURVEY.md section 8-d — forward
+    2*NL*HID^2 per pixel (139 GFLOP at bs 512), backward = dgrad + wgrad = 2x that (278), step = 3x (417) — whatever the
+    backward kernel ISSUES (the recompute variant issues 3x forward; that extra work is not "achieved").  `ab`: the
+    same step with the hidden activations recomputed in backward instead of saved by the forward (in-process A/B)."""
+    import atomai_amd.nets.ed as ed
     rs = np.random.RandomState(0)
     X = rs.rand(B * 2, 64, 64).astype(np.float32)
     m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
     m.dx_prior, m.kdict_["phi_prior"] = 0.1, 0.1
     m.compile_trainer((X, None), None, batch_size=B)
     xs = [torch.from_numpy(X[i * B:(i + 1) * B]).cuda() for i in range(2)]
-    recs = timed_calls({"amx_rdecoder_fwd", "amx_rdecoder_bwd"})
+    names = {"amx_rdecoder_fwd", "amx_rdecoder_bwd", "amx_rdecoder_fwd_save", "amx_rdecoder_bwd_saved"}
+    recs = timed_calls(names)
 
     from atomai_amd.trainers.trainer import _EarlyScalar
 
@@ -44,25 +50,45 @@ def bench_rvae(steps=10, warmup=3, B=512, emit=True):
         (-elbo).backward()
         m.optim.step()
         return early.item()
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize(); recs.clear()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        last = step(i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+
+    def run():
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize(); recs.clear()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        tf = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if "fwd" in n) / steps
+        tb = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if "bwd" in n) / steps
+        return dt, tf, tb, last
+    saved_default = ed.RDEC_SAVE[0]
+    dt, tf, tb, last = run()
     rows = B * 64 * 64
     fl_fwd = rows * 2 * 2 * 128 * 128.0
-    tf = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_rdecoder_fwd") / steps
-    tb = sum(e0.elapsed_time(e1) for n, e0, e1 in recs if n == "amx_rdecoder_bwd") / steps
+    tfl = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 2)          # noqa: E731
     out = {"metric": "rVAE training patches/sec (64x64, bs=512, latent_dim=2)", "value": round(B / dt, 1),
            "unit": "patches/s", "ms_per_step": round(dt * 1e3, 3), "n_gpus": 1, "dtype": "f32", "elbo": last,
+           "backward_variant": "saved activations" if saved_default else "recompute",
+           "flops_note": "algorithmic (SURVEY 8-d): fwd 139 GFLOP, bwd 278, step 417 at bs 512",
            "roofline": {"bound": "mfma", "kernel": "rdecoder_bwd_kernel<128,64,2>",
-                        "achieved": round(3 * fl_fwd / (tb * 1e-3) / 1e12, 2), "peak": PEAK, "unit": "TFLOP/s",
-                        "frac": round(3 * fl_fwd / (tb * 1e-3) / 1e12 / PEAK, 4), "ms": round(tb, 3)},
-           "roofline_fwd": {"kernel": "rdecoder_fwd_kernel<128,128>", "achieved": round(fl_fwd / (tf * 1e-3) / 1e12, 2),
-                            "frac": round(fl_fwd / (tf * 1e-3) / 1e12 / PEAK, 4), "ms": round(tf, 3)}}
+                        "achieved": tfl(2 * fl_fwd, tb), "peak": PEAK, "unit": "TFLOP/s",
+                        "frac": round(tfl(2 * fl_fwd, tb) / PEAK, 4), "ms": round(tb, 3)},
+           "roofline_fwd": {"kernel": "rdecoder_fwd_kernel<128,64>", "achieved": tfl(fl_fwd, tf),
+                            "frac": round(tfl(fl_fwd, tf) / PEAK, 4), "ms": round(tf, 3)},
+           "roofline_decoder_pair": {"achieved": tfl(3 * fl_fwd, tf + tb), "frac": round(tfl(3 * fl_fwd, tf + tb) / PEAK, 4),
+                                     "ms": round(tf + tb, 3)},
+           "step_frac_of_mfma_f32_peak": round(tfl(3 * fl_fwd, dt * 1e3) / PEAK, 4)}
+    if ab:
+        ed.RDEC_SAVE[0] = not saved_default
+        try:
+            dt2, tf2, tb2, _ = run()
+        finally:
+            ed.RDEC_SAVE[0] = saved_default
+        out["ab_other_variant"] = {"backward_variant": "recompute" if saved_default else "saved activations",
+                                   "ms_per_step": round(dt2 * 1e3, 3), "fwd_ms": round(tf2, 3), "bwd_ms": round(tb2, 3),
+                                   "patches_per_s": round(B / dt2, 1)}
     if emit:
         print(json.dumps(out), flush=True)
     return out
