@@ -123,6 +123,43 @@ def bench_predict(frames=256, hw=1024, emit=True):
     return res
 
 
+def bench_predict_full(frames=4096, hw=1024, emit=True):
+    """BASELINE.json configs[2] at its FULL size: dilnet nb_classes=1, model.predict over a 4096-frame 1024x1024 stack
+    (17.2 GB in, 17.2 GB out, through pinned staging buffers; compute_coords=False).  The stack is filled block by
+    block from 64 random frames with a per-block gain (so global min / max live in different blocks); reported:
+    end-to-end seconds / frames/s of the whole call and the steady rate (4096-frame call minus a 256-frame call)."""
+    torch.manual_seed(1)
+    net, _ = aoi.nets.init_fcnn_model("dilnet", 1)
+    rs = np.random.RandomState(0)
+    base = torch.from_numpy(rs.rand(64, hw, hw).astype(np.float32))
+    t0 = time.perf_counter()
+    stack = np.empty((frames, hw, hw), dtype=np.float32)
+    st = torch.from_numpy(stack)
+    for i in range(0, frames, 64):
+        m = min(64, frames - i)
+        torch.mul(base[:m], 0.5 + (i // 64) / 128.0, out=st[i:i + m])
+    t_gen = time.perf_counter() - t0
+    p = aoi.predictors.SegPredictor(net, use_gpu=True, nb_classes=1, downsampling=2, verbose=False)
+    p.run(stack[:16], compute_coords=False)                   # warm-up with a full chunk (pinned staging buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    p.run(stack[:256], compute_coords=False)
+    t256 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = p.run(stack, compute_coords=False)
+    dt = time.perf_counter() - t0
+    chk = float(out[::257].mean())
+    res = {"metric": "dilnet predict over the full 4096-frame 1024x1024 stack (BASELINE configs[2]), end-to-end incl. "
+                     "host min/max, H2D, D2H and the copy into the returned array",
+           "value": round(frames / dt, 2), "unit": "frames/s", "frames": frames, "seconds": round(dt, 3),
+           "steady_frames_per_s": round((frames - 256) / (dt - t256), 2) if frames > 256 else None,
+           "first_256_frames_s": round(t256, 3), "stack_GB": round(stack.nbytes / 1e9, 2),
+           "host_fill_s": round(t_gen, 2), "out_shape": list(out.shape), "out_mean_sample": round(chk, 6)}
+    if emit:
+        print(json.dumps(res), flush=True)
+    return res
+
+
 def bench_dkl(N=16384, D=2, emit=True):
     """configs[4]: RBF covariance on N=16384 embedded points — HBM-write bound (4*N^2 bytes)."""
     from atomai_amd.nets.gp import kernel_matrix, kernel_matvec, convFeatureExtractor
@@ -266,5 +303,6 @@ if __name__ == "__main__":
     os.makedirs("gpurun_out", exist_ok=True)
     res = {}
     for w in what:
-        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl, "locate": bench_locate, "segfamily": bench_segfamily}[w]()
+        res[w] = {"rvae": bench_rvae, "predict": bench_predict, "dkl": bench_dkl, "locate": bench_locate, "segfamily": bench_segfamily,
+                  "predict4096": bench_predict_full}[w]()
     json.dump(res, open("gpurun_out/bench_extra.json", "w"), indent=1)
