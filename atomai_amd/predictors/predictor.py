@@ -219,41 +219,81 @@ class SegPredictor(BasePredictor):
             st["ev_out"] = torch.cuda.Event()
             st["ev_out"].record(copy_out)
 
-        def collect(k):                             # chunk k downloaded -> user-visible output; its staging
-            st = stage.pop(k)                       # buffers and device tensors are free again after this
-            st["ev_out"].synchronize()
-            out[st["s"]:st["s"] + st["m"]] = pin_out[k % NS][:st["m"]]
+        # Chunk k downloaded -> user-visible output.  This runs on a WORKER thread, so that the launch thread never waits
+        # for a download and never spends its time in the 64 MB copy into (first-touched) output pages: at the full size
+        # of BASELINE configs[2] (4096 frames: 17 GB in, 17 GB out) the launch thread then needs ~3 ms per 16-frame chunk
+        # (staging copy 1.5 ms, upload call 0.3 ms, launches 1 ms) against ~20 ms of kernels and waits for a free slot
+        # the rest of the time — the pipeline is GPU-bound (profiles/r03_predict4096.log: 700 frames/s end to end, 720
+        # steady, for a device rate of 752; 626-642 -> 682 frames/s on 256 frames against the single-threaded loop).
+        import queue
+        import threading
+        todo: "queue.SimpleQueue" = queue.SimpleQueue()
+        slot_free = [threading.Event() for _ in range(NS)]
+        for e_ in slot_free:
+            e_.set()
+        failure = []
+
+        def collector():
+            nthr = _host_threads().n
+            if 0 < nthr < torch.get_num_threads():
+                torch.set_num_threads(nthr)
+            while True:
+                k = todo.get()
+                if k is None:
+                    return
+                try:
+                    st = stage[k]
+                    st["ev_out"].synchronize()
+                    out[st["s"]:st["s"] + st["m"]] = pin_out[k % NS][:st["m"]]
+                    stage.pop(k)                    # its staging buffers and device tensors are free again
+                except BaseException as exc:        # surfaced by the main thread
+                    failure.append(exc)
+                finally:
+                    slot_free[k % NS].set()
+
+        worker = threading.Thread(target=collector, name="amx-predict-collect", daemon=True)
+        worker.start()
+
+        def wait_slot(slot):
+            slot_free[slot].wait()
+            if failure:
+                raise failure[0]
 
         nchunks = 0
         trace = [] if os.environ.get("AMX_PREDICT_TRACE") else None      # dev aid: host time per phase and chunk
         import time as _time
-        for k, s in enumerate(range(0, n, chunk)):
-            slot, m = k % NS, min(chunk, n - s)
-            t0 = _time.perf_counter()
-            if k >= NS:
-                collect(k - NS)
-            t1 = _time.perf_counter()
-            pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of the chunks in flight
-            t2 = _time.perf_counter()
-            with torch.cuda.stream(copy_in):        # upload: hipMemcpyAsync with no dependency (see above)
-                d = pin_in[slot][:m].to(dev, non_blocking=True)
-            ev_in = torch.cuda.Event()
-            ev_in.record(copy_in)
-            main.wait_event(ev_in)
-            t3 = _time.perf_counter()
-            prob = self.forward_(d)
-            done = torch.cuda.Event()
-            done.record(main)
-            stage[k] = {"d": d, "prob": prob, "done": done, "s": s, "m": m}
-            finish(k)
-            nchunks = k + 1
-            if trace is not None:
-                trace.append((k, t1 - t0, t2 - t1, t3 - t2, _time.perf_counter() - t3))
+        try:
+            for k, s in enumerate(range(0, n, chunk)):
+                slot, m = k % NS, min(chunk, n - s)
+                t0 = _time.perf_counter()
+                wait_slot(slot)                     # chunk k - NS is in `out`: pin_in / pin_out[slot] may be reused
+                t1 = _time.perf_counter()
+                pin_in[slot][:m].copy_(data[s:s + m])   # host memcpy overlaps the GPU work of the chunks in flight
+                t2 = _time.perf_counter()
+                with torch.cuda.stream(copy_in):    # upload: hipMemcpyAsync with no dependency (see above)
+                    d = pin_in[slot][:m].to(dev, non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(copy_in)
+                main.wait_event(ev_in)
+                t3 = _time.perf_counter()
+                prob = self.forward_(d)
+                done = torch.cuda.Event()
+                done.record(main)
+                stage[k] = {"d": d, "prob": prob, "done": done, "s": s, "m": m}
+                finish(k)
+                slot_free[slot].clear()
+                todo.put(k)
+                nchunks = k + 1
+                if trace is not None:
+                    trace.append((k, t1 - t0, t2 - t1, t3 - t2, _time.perf_counter() - t3))
+        finally:
+            todo.put(None)
+            worker.join()
+        if failure:
+            raise failure[0]
         if trace:
             for k, a, b, c, d_ in trace:
-                print(f"chunk {k:3d}: collect {1e3*a:7.2f}  copy-in {1e3*b:7.2f}  upload {1e3*c:7.2f}  launches {1e3*d_:7.2f} ms")
-        for k in range(max(0, nchunks - NS), nchunks):
-            collect(k)
+                print(f"chunk {k:3d}: wait-slot {1e3*a:7.2f}  copy-in {1e3*b:7.2f}  upload {1e3*c:7.2f}  launches {1e3*d_:7.2f} ms")
         return out
 
     # ------------------------------------------------------------------ multi-GPU
