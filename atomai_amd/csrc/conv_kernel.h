@@ -103,6 +103,11 @@ struct ConvFwdArgs {
 #ifndef AMX_CONV_GLDS
 #define AMX_CONV_GLDS 0
 #endif
+#ifndef AMX_CONV_EPI_PAD
+#define AMX_CONV_EPI_PAD 0          // floats of padding per pixel row of the epilogue's transposition buffer; 4 removes the
+                                    // 4-way bank conflict of the scalar stores but measured SLOWER in the step (18.56 ->
+                                    // 19.01 ms, profiles/r03_conv_epi_pad_ab.log): the b128 read-back then straddles rows
+#endif
 #ifndef AMX_CONV_GLDS_WAVES
 #define AMX_CONV_GLDS_WAVES 5       // waves per SIMD requested for the 8-row thin classes when the weights go by LDS-DMA
 #endif
@@ -444,7 +449,13 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     // transpose: [row m][pixel x][cout] in this wave's LDS region, MH rows at a time
     constexpr int MH = MTW < 2 ? MTW : 2;
     constexpr int CG = NB / 4;                                   // float4 groups per pixel
-    float* s_epi = smem + (size_t)wave * (MH * TILE * NB);
+    // Row stride NB + EPAD floats (experiment switch, default 0): the four lane groups g of a fragment store to pixel rows
+    // 4g + r, i.e. 4 * stride floats apart — with a stride of NB (a multiple of 16) all four land on the same 16 banks, a
+    // 4-way conflict on every scalar store (SQ_LDS_BANK_CONFLICT 0.28-0.41 of the LDS cycles, profiles/r02_pmc_sq.md);
+    // + 4 floats rotates each group by 16 banks — and loses more on the read-back side than it gains (see above).
+    constexpr int EPAD = AMX_CONV_EPI_PAD;
+    constexpr int NBE = NB + EPAD;
+    float* s_epi = smem + (size_t)wave * (MH * TILE * NBE);
     // HEAD: this lane's slice (4 couts) of the folded head weights; lane % CG is the lane's float4 group of a pixel in
     // every iteration of the loops below (64 and MH * TILE * CG are multiples of CG)
     float4 hwq[HEAD ? 3 : 1];
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             for (int q = 0; q < NT; ++q)
                 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s_epi[(mm * TILE + 4 * g + r) * NB + q * 16 + p] = acc[m0 + mm][q][r];
+                    s_epi[(mm * TILE + 4 * g + r) * NBE + q * 16 + p] = acc[m0 + mm][q][r];
         amx_wave_sync();                                         // wave-private region: no workgroup barrier needed
         #pragma unroll
         for (int it = 0; it < MH * TILE * CG / 64; ++it) {
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 // the final 1x1 convolution (own BatchNorm affine folded in) on the transposed tile: each of the CG
                 // lanes of a pixel contracts its 4 couts, a butterfly over those lanes sums them; the activation is
                 // not written at all
-                const float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
+                const float4 v = amx_ld4(s_epi + (size_t)pix * NBE + cgp * 4);
                 float lg[3];
                 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -516,14 +527,14 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                         const float4 r = term(amx_ld4(a.ds_a[l] + o), a.ds_sc[l], a.ds_sh[l]);
                         acc4.x += r.x; acc4.y += r.y; acc4.z += r.z; acc4.w += r.w;
                     }
-                    const float4 r = term(amx_ld4(s_epi + (size_t)pix * NB + cgp * 4), a.ds_sc[a.nds], a.ds_sh[a.nds]);
+                    const float4 r = term(amx_ld4(s_epi + (size_t)pix * NBE + cgp * 4), a.ds_sc[a.nds], a.ds_sh[a.nds]);
                     acc4.x += r.x; acc4.y += r.y; acc4.z += r.z; acc4.w += r.w;
                     amx_st4(a.y + o, acc4);
                 }
                 continue;
             }
             if (oy < a.H && ox < a.W && co < ctot) {
-                float4 v = amx_ld4(s_epi + (size_t)pix * NB + cgp * 4);
+                float4 v = amx_ld4(s_epi + (size_t)pix * NBE + cgp * 4);
                 float* dst; int Cd, cd;
                 if (co < a.Y0s) { dst = a.y; Cd = a.Y0s; cd = co; } else { dst = a.y1; Cd = a.Y1s; cd = co - a.Y0s; }
                 const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
@@ -545,7 +556,7 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
     size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) ;
     {   // the epilogue's transposition buffers: 4 waves x min(MTW, 2) rows x 16 pixels x NB couts
-        const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * NT * 16 * sizeof(float);
+        const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * (NT * 16 + AMX_CONV_EPI_PAD) * sizeof(float);
         if (lds < epi) lds = epi;
     }
     // occupancy experiment: AMX_CONV_MAXWG=k pads the LDS request so that at most k workgroups fit a CU

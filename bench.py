@@ -227,7 +227,7 @@ def extra_configs():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_extra as bx
     out = {}
-    for key, fn, kw in (("config3_dilnet_predict_1024", bx.bench_predict, dict(frames=64)),
+    for key, fn, kw in (("config3_dilnet_predict_4096x1024", bx.bench_predict_full, dict(frames=4096)),
                         ("config4_rvae_bs512_64x64", bx.bench_rvae, dict(steps=20, warmup=3)),
                         ("config5_dkl_rbf_n16384", bx.bench_dkl, dict())):
         t0 = time.perf_counter()

@@ -149,12 +149,22 @@ def bench_predict_full(frames=4096, hw=1024, emit=True):
     out = p.run(stack, compute_coords=False)
     dt = time.perf_counter() - t0
     chk = float(out[::257].mean())
+    del out
+    x = torch.from_numpy(stack[:16, None]).cuda()            # device-only rate of the network itself (16-frame chunk)
+    from atomai_amd.nets.fcnn import predict_proba
+    net.eval()
+    for _ in range(2): predict_proba(net, x)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(5): predict_proba(net, x)
+    torch.cuda.synchronize(); dk = (time.perf_counter() - t1) / 5 / 16
     res = {"metric": "dilnet predict over the full 4096-frame 1024x1024 stack (BASELINE configs[2]), end-to-end incl. "
                      "host min/max, H2D, D2H and the copy into the returned array",
            "value": round(frames / dt, 2), "unit": "frames/s", "frames": frames, "seconds": round(dt, 3),
            "steady_frames_per_s": round((frames - 256) / (dt - t256), 2) if frames > 256 else None,
            "first_256_frames_s": round(t256, 3), "stack_GB": round(stack.nbytes / 1e9, 2),
-           "host_fill_s": round(t_gen, 2), "out_shape": list(out.shape), "out_mean_sample": round(chk, 6)}
+           "host_fill_s": round(t_gen, 2), "out_shape": [frames, hw, hw, 1], "out_mean_sample": round(chk, 6),
+           "device_only_ms_per_frame": round(dk * 1e3, 3), "device_tflops": round(91.62e9 / dk / 1e12, 2),
+           "device_frac_of_mfma_peak": round(91.62e9 / dk / 1e12 / PEAK, 4)}
     if emit:
         print(json.dumps(res), flush=True)
     return res
