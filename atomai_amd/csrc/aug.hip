@@ -295,3 +295,123 @@ extern "C" int amx_aug_labels(const long long* t, long long* out, const float* p
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- zoom / resize
+// apply_zoom (imaug.py:195-227): centred zv x zv crop -> cv2.resize(..., (S, S), interpolation=cv2.INTER_CUBIC), image
+// clipped to [0, 1], masks rounded.  apply_imresize (imaug.py:276-300): cv2.resize(img, (w', h'), rs_method) — the third
+// POSITIONAL parameter of cv2.resize is `dst`, so rs_method never reaches `interpolation` and the call runs with the
+// default INTER_LINEAR; that is what mode 0 provides (mode 1 = INTER_CUBIC).  OpenCV's arithmetic, restated from its
+// documentation / imgproc sources (cv2 is absent in this image: UNPINNED against cv2 itself; the numpy restatement in
+// oracle/aug_oracle.py is checked against torch's F.interpolate(align_corners=False), which documents the same
+// conventions: half-pixel centres, a = -0.75, clamped tap indices):
+//   source coordinate  f = (d + 0.5) * (src / dst) - 0.5,  s = floor(f),  t = f - s
+//   linear:  s < 0 -> (s, t) = (0, 0);  s >= src - 1 -> (src - 1, 0);  value = S[s] * (1 - t) + S[s + 1] * t
+//   cubic:   taps s - 1 .. s + 2 with indices clamped to [0, src - 1];  weights (A = -0.75, formed in float):
+//            w0 = ((A (t + 1) - 5A)(t + 1) + 8A)(t + 1) - 4A,  w1 = ((A + 2) t - (A + 3)) t^2 + 1,
+//            w2 = ((A + 2)(1 - t) - (A + 3))(1 - t)^2 + 1,     w3 = 1 - w0 - w1 - w2
+//   horizontal pass first, then vertical (separable; evaluated per output pixel here).
+// win: per image (y0, x0, h, w) of the source window inside the [Hs][Ws] frame (zoom: centred crop; resize: whole frame).
+struct ResampleTaps { int idx[4]; float w[4]; int n; };
+
+static __device__ __forceinline__ ResampleTaps resample_taps(int d, int src, int dst, int mode) {
+    ResampleTaps r;
+    const double scale = (double)src / (double)dst;          // OpenCV: the coordinate is formed in double, then cast
+    const float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    float t = f - (float)s;
+    if (mode == 0) {
+        if (s < 0) { s = 0; t = 0.f; }
+        if (s >= src - 1) { s = src - 1; t = 0.f; }
+        r.n = 2;
+        r.idx[0] = s; r.idx[1] = s + 1 < src ? s + 1 : src - 1;
+        r.w[0] = 1.f - t; r.w[1] = t;
+        r.idx[2] = r.idx[3] = 0; r.w[2] = r.w[3] = 0.f;
+    } else {
+        const float A = -0.75f;
+        r.n = 4;
+        r.w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+        r.w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+        r.w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+        r.w[3] = 1.f - r.w[0] - r.w[1] - r.w[2];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { int q = s - 1 + j; q = q < 0 ? 0 : (q > src - 1 ? src - 1 : q); r.idx[j] = q; }
+    }
+    return r;
+}
+
+// images: x [N][Hs][Ws] -> y [N][Hd][Wd];  clip01: np.clip(img, 0, 1) of apply_zoom;  round_out: np.around (binary masks)
+__global__ void aug_resample_kernel(const float* __restrict__ x, float* __restrict__ y, const int* __restrict__ win,
+                                    int N, int Hs, int Ws, int Hd, int Wd, int mode, int clip01, int round_out) {
+    const long total = (long)N * Hd * Wd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int dx = (int)(i % Wd); const long r_ = i / Wd; const int dy = (int)(r_ % Hd); const int n = (int)(r_ / Hd);
+        const int y0 = win[n * 4 + 0], x0 = win[n * 4 + 1], wh = win[n * 4 + 2], ww = win[n * 4 + 3];
+        const ResampleTaps ty = resample_taps(dy, wh, Hd, mode), tx = resample_taps(dx, ww, Wd, mode);
+        const float* img = x + (size_t)n * Hs * Ws;
+        float acc = 0.f;
+        for (int a = 0; a < ty.n; ++a) {
+            const float* row = img + (size_t)(y0 + ty.idx[a]) * Ws + x0;
+            float h = 0.f;
+            for (int b = 0; b < tx.n; ++b) h = fmaf(row[tx.idx[b]], tx.w[b], h);       // horizontal pass of this row
+            acc = fmaf(h, ty.w[a], acc);
+        }
+        if (clip01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+        if (round_out) acc = rintf(acc);                                                // np.around: half to even
+        y[i] = acc;
+    }
+}
+
+extern "C" int amx_aug_resample(const float* x, float* y, const int* win, int N, int Hs, int Ws, int Hd, int Wd, int mode,
+                                int clip01, int round_out, void* stream) {
+    if (!x || !y || !win || x == y) AMX_BADARG(1);
+    if (N <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || mode < 0 || mode > 1) AMX_BADARG(2);
+    long nb = ((long)N * Hd * Wd + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    AMX_LAUNCH(aug_resample_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, win, N, Hs, Ws, Hd, Wd,
+               mode, clip01, round_out);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// class maps: the reference resamples the K one-hot masks separately (zoom, then resize, each followed by np.around) and
+// squeezes them back at the end with label = sum_c c * mask_c (squeeze_channels, imaug.py:361-393) — a pixel whose rounded
+// masks are all 0 becomes class 0, one with two masks set becomes the SUM of their indices.  So the class map is expanded
+// to K float planes (amx_aug_onehot), the planes go through amx_aug_resample (round_out = 1) like images, and
+// amx_aug_squeeze forms the sum; values[n]: bit v set if the value v occurs in image n (the reference keeps the pair iff
+// exactly K distinct values occur).
+__global__ void aug_onehot_kernel(const long long* __restrict__ t, float* __restrict__ m, int N, int K, long HW) {
+    const long total = (long)N * K * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW; const long r_ = i / HW; const int c = (int)(r_ % K); const long n = r_ / K;
+        m[i] = t[n * HW + hw] == c ? 1.f : 0.f;
+    }
+}
+extern "C" int amx_aug_onehot(const long long* t, float* masks, int N, int K, long HW, void* stream) {
+    if (!t || !masks || N <= 0 || K < 2 || K > 8 || HW <= 0) AMX_BADARG(1);
+    long nb = ((long)N * K * HW + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    AMX_LAUNCH(aug_onehot_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, t, masks, N, K, HW);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void aug_squeeze_kernel(const float* __restrict__ m, long long* __restrict__ out, int* __restrict__ values,
+                                   int N, int K, long HW) {
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % HW; const long n = i / HW;
+        float v = 0.f;
+        for (int c = 0; c < K; ++c) v = fmaf(m[((size_t)n * K + c) * HW + hw], (float)c, v);     // exact: small integers
+        const int iv = (int)v;
+        out[i] = iv;
+        if (values && iv >= 0 && iv < 32) atomicOr(values + n, 1 << iv);
+    }
+}
+extern "C" int amx_aug_squeeze(const float* masks, long long* out, int* values, int N, int K, long HW, void* stream) {
+    if (!masks || !out || N <= 0 || K < 2 || K > 8 || HW <= 0) AMX_BADARG(1);
+    long nb = ((long)N * HW + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    AMX_LAUNCH(aug_squeeze_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, masks, out, values, N, K, HW);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

@@ -20,9 +20,10 @@ class Segmentor(SegTrainer):
     def fit(self, X_train, y_train, X_test=None, y_test=None, loss: str = 'ce', optimizer=None,
             training_cycles: int = 1000, batch_size: int = 32, compute_accuracy: bool = False,
             full_epoch: bool = False, swa: bool = False, perturb_weights: bool = False, **kwargs):
-        """Compiles the trainer and trains (segmentor.py:61-149).  On-the-fly augmentation keywords (rotation,
-        gauss_noise, poisson_noise, salt_and_pepper, blur, contrast, background) run as HIP kernels on the resident
-        batch (transforms/imaug.py); zoom / resize / jitter / custom_transform raise."""
+        """Compiles the trainer and trains (segmentor.py:61-149).  On-the-fly augmentation keywords (rotation, zoom,
+        resize, gauss_noise, jitter, poisson_noise, salt_and_pepper, blur, contrast, background) run as HIP kernels on
+        the resident batch (transforms/imaug.py); custom_transform raises.  ``distributed=True``: one process per GPU,
+        this rank trains on its shard of ``X_train`` (parallel.py)."""
         self.compile_trainer((X_train, y_train, X_test, y_test), loss, optimizer, training_cycles,
                              batch_size, compute_accuracy, full_epoch, swa, perturb_weights, **kwargs)
         self.augment_fn = seg_augmentor(self.nb_classes, **kwargs)

@@ -18,8 +18,15 @@ and the steps are HIP kernels (csrc/aug.hip).  Same step order and parameter ran
 * ``jitter`` (rows rolled by Poisson-distributed shifts, imaug.py:123-135): the N x H shifts are drawn on the host from
   the same stream (``scipy.stats.poisson.rvs`` draws from numpy's global state, i.e. they are the reference's shifts
   for the same seed) and applied as an index map inside the point pass.
-* Not available (their arithmetic lives in cv2, which is absent here and cannot be pinned): ``zoom``, ``resize``;
-  also ``custom_transform`` (arbitrary host code).  Passing one raises.
+* ``zoom`` / ``resize`` (imaug.py:195-227, 276-300): the window sizes / output size are drawn on the host in the
+  reference's order (same seed -> the reference's choices) and ``cv2.resize`` runs as a resampling kernel
+  (``amx_aug_resample``): INTER_CUBIC (a = -0.75) for zoom; for resize INTER_LINEAR, because the reference's
+  ``cv2.resize(img, (w, h), rs_method)`` passes its method in the position of ``dst`` and so never changes the default
+  interpolation.  OpenCV's arithmetic is restated from its documentation — UNPINNED against cv2 itself (absent in this
+  image); everything around it (draw order, crop windows, size formulas, rounding, the squeeze / drop rule) is pinned to
+  the reference's own code run over that restatement (tests/golden/augment_geom.npz).  Class maps travel as the K
+  one-hot planes the reference resamples and are squeezed back with its ``sum_c c * mask_c`` rule.
+* Not available: ``custom_transform`` (arbitrary host code).  Passing one raises.
 """
 from typing import Callable, Optional, Tuple
 
@@ -29,7 +36,7 @@ import torch
 from .. import _lib as L
 
 _NP = 12
-_UNSUPPORTED = ("zoom", "resize", "custom_transform")
+_UNSUPPORTED = ("custom_transform",)
 
 
 def _minmax(x: torch.Tensor) -> torch.Tensor:
@@ -53,7 +60,7 @@ class datatransform:
     def __init__(self, n_channels: int = None, seed: Optional[int] = None, **kwargs) -> None:
         bad = [k for k in _UNSUPPORTED if kwargs.get(k)]
         if bad:
-            raise NotImplementedError(f"augmentation {bad} is not available on the device path (cv2 / host-code "
+            raise NotImplementedError(f"augmentation {bad} is not available on the device path (host-code "
                                       "transforms, see atomai_amd/transforms/imaug.py)")
         self.ch = n_channels
         rng = lambda key, dflt: (dflt if kwargs.get(key) is True else kwargs.get(key))   # noqa: E731
@@ -65,6 +72,8 @@ class datatransform:
         self.salt_and_pepper = rng("salt_and_pepper", [0, 50])
         self.blur = rng("blur", [1, 50])
         self.contrast = rng("contrast", [5, 20])
+        self.zoom = 2 if kwargs.get("zoom") is True else kwargs.get("zoom")
+        self.resize = [2, 1.5] if kwargs.get("resize") is True else kwargs.get("resize")
         self.rs = np.random.RandomState(seed)                 # np.random.seed(seed) of imaug.py:106
         self.seed = 0 if seed is None else int(seed)
         self.params = None
@@ -74,12 +83,44 @@ class datatransform:
         return isinstance(v, (list, tuple))
 
     # ------------------------------------------------------------------ host: scalar draws in the reference's order
-    def draw(self, n: int, h: int, w: int):
+    def draw_geometry(self, n: int, h: int, w: int):
+        """rotation codes, zoom windows, resize target — the first draws of ``run`` (imaug.py:319-325) — and the image
+        size the remaining steps will see."""
+        rs = self.rs
+        flips = np.full(n, 4.0)
+        if self.rotation:
+            for i in range(n):
+                ft = rs.randint(-1, 3)                       # 3 is never drawn (imaug.py:267); 2 = rot90 ccw if square
+                flips[i] = ft if (ft != 2 or h == w) else 1  # cv2.flip(img, 2) on a non-square image flips horizontally
+        zv = None
+        if self.zoom:                                        # imaug.py:202-208: one np.random.choice per image
+            S = min(h, w)
+            cand = np.arange(int(S // self.zoom), S + 8, 8)
+            cand = cand[cand <= S]
+            zv = np.array([rs.choice(cand) for _ in range(n)], dtype=np.int64)
+            h = w = S
+        out_hw = None
+        if self._is_range(self.resize):                      # imaug.py:283-292: ONE size for the whole batch
+            d, u = 1 / self.resize[0], self.resize[1]
+            s_, p_ = 0.03, 8
+            while np.round((h * s_), 7) % p_ != 0 and np.round((w * s_), 7) % p_ != 0:
+                s_ += 1e-5
+            rs_h = (np.arange(d, u, s_) * h).astype(np.int64)
+            rs_w = (np.arange(d, u, s_) * w).astype(np.int64)
+            k = rs.randint(len(rs_h))
+            if (h, w) != (rs_h[k], rs_w[k]):
+                out_hw = (int(rs_h[k]), int(rs_w[k]))
+                h, w = out_hw
+        return flips, zv, out_hw, h, w
+
+    def draw(self, n: int, h: int, w: int, flips=None):
         rs = self.rs
         P = np.zeros((n, _NP), dtype=np.float64)        # float64 here (the oracle's input), fp32 on the device
         P[:, 0] = 4
         extra = {}
-        if self.rotation:
+        if flips is not None:
+            P[:, 0] = flips
+        elif self.rotation:
             for i in range(n):
                 ft = rs.randint(-1, 3)                       # 3 is never drawn (imaug.py:267); 2 = rot90 ccw if square
                 P[i, 0] = ft if (ft != 2 or h == w) else 1   # cv2.flip(img, 2) on a non-square image flips horizontally
@@ -123,13 +164,51 @@ class datatransform:
                L.ptr(keep[2]), L.ptr(keep[3]), L.ptr(jd), N, H, W, self.seed, L.stream_ptr(x))
         return y
 
+    @staticmethod
+    def _resample(x, win, out_hw, mode: int, clip01: bool, round_out: bool):
+        """x (M, Hs, Ws) fp32 planes, win (M, 4) int32 source windows -> (M, Hd, Wd)."""
+        M, Hs, Ws = x.shape
+        y = torch.empty((M,) + tuple(out_hw), dtype=torch.float32, device=x.device)
+        wd = torch.from_numpy(np.ascontiguousarray(win, dtype=np.int32)).to(x.device)
+        L.call("amx_aug_resample", L.ptr(x), L.ptr(y), L.ptr(wd), M, Hs, Ws, int(out_hw[0]), int(out_hw[1]), mode,
+               int(clip01), int(round_out), L.stream_ptr(x))
+        return y
+
+    def _geometry(self, planes, zv, out_hw, reps: int, is_mask: bool):
+        """zoom (centred zv x zv crop -> short side, INTER_CUBIC) then resize (whole frame -> out_hw, INTER_LINEAR as the
+        reference's call executes) of (N * reps, H, W) planes; images are clipped after the zoom, masks rounded."""
+        M, H, W = planes.shape
+        if zv is not None:
+            S = min(H, W)
+            z = np.repeat(zv, reps)
+            win = np.stack([H // 2 - z // 2, W // 2 - z // 2, 2 * (z // 2), 2 * (z // 2)], 1)
+            planes = self._resample(planes, win, (S, S), 1, not is_mask, is_mask)
+            H = W = S
+        if out_hw is not None:
+            win = np.tile(np.array([[0, 0, H, W]]), (M, 1))
+            planes = self._resample(planes, win, out_hw, 0, False, is_mask)
+        return planes
+
     def run(self, images: torch.Tensor, targets: torch.Tensor, fields: dict = None) -> Tuple[torch.Tensor]:
         """images (N, H, W) or (N, 1, H, W) fp32 on the device; targets (N, H, W) int64 class maps or (N, 1, H, W)
         fp32 binary masks.  ``fields`` (tests): {'gauss','poisson','sp_flip','sp_salt'} -> (N, H, W) tensors, 'jitter' -> (N, H) ints."""
         x = images[:, 0] if images.ndim == 4 else images
         x = x.float().contiguous()
         N, H, W = x.shape
-        P, extra = self.draw(N, H, W)
+        H0, W0 = H, W
+        flips, zv, out_hw, H, W = self.draw_geometry(N, H, W)
+        geo = zv is not None or out_hw is not None
+        self.geometry = {"flips": flips, "zoom_zv": zv, "resize_hw": out_hw}
+        if geo:
+            # (x - min) / ptp and the flips first, then the resampling steps; the point passes below then run on the
+            # resampled batch with the normalisation and the flip switched off
+            P0 = np.zeros((N, _NP))
+            P0[:, 0] = flips
+            x = self._point(x, P0, _minmax(x), None, None)
+            x = self._geometry(x, zv, out_hw, 1, False)
+            P, extra = self.draw(N, H, W, flips=np.full(N, 4.0))
+        else:
+            P, extra = self.draw(N, H, W, flips=flips)
         self.params, self.extra = P, extra
         fields = dict(fields or {})
         zero = np.zeros_like(P)
@@ -146,7 +225,7 @@ class datatransform:
             PA = P                                            # everything in ONE pass
         if "jitter" in fields:                                # tests: explicit shifts
             extra["jitter"] = np.asarray(fields["jitter"], dtype=np.int32)
-        x = self._point(x, PA, _minmax(x), fields, extra.get("jitter"))
+        x = self._point(x, PA, None if geo else _minmax(x), fields, extra.get("jitter"))
         if need_split:
             # ---- pass B: poisson (its scale needs the number of distinct values of the image so far), salt & pepper
             PB = zero.copy()
@@ -173,17 +252,33 @@ class datatransform:
             t = targets.contiguous()
             out_t = torch.empty_like(t)
             present = torch.zeros(N, dtype=torch.int32, device=t.device)
-            Pd = torch.from_numpy(P.astype(np.float32)).to(t.device)
-            L.call("amx_aug_labels", L.ptr(t), L.ptr(out_t), L.ptr(Pd), L.ptr(present), N, H, W, L.stream_ptr(t))
+            PL = np.zeros((N, _NP), dtype=np.float32)
+            PL[:, 0] = flips
+            Pd = torch.from_numpy(PL).to(t.device)
+            L.call("amx_aug_labels", L.ptr(t), L.ptr(out_t), L.ptr(Pd), L.ptr(present), N, H0, W0, L.stream_ptr(t))
             targets = out_t
-            if self.ch and self.ch > 1:
+            if geo:
+                if not self.ch or self.ch < 2:
+                    raise NotImplementedError("zoom / resize of integer class maps needs n_channels >= 2")
+                K = self.ch
+                masks = torch.empty((N * K, H0, W0), dtype=torch.float32, device=t.device)
+                L.call("amx_aug_onehot", L.ptr(out_t), L.ptr(masks), N, K, H0 * W0, L.stream_ptr(t))
+                masks = self._geometry(masks, zv, out_hw, K, True)
+                targets = torch.empty((N, H, W), dtype=torch.int64, device=t.device)
+                values = torch.zeros(N, dtype=torch.int32, device=t.device)
+                L.call("amx_aug_squeeze", L.ptr(masks), L.ptr(targets), L.ptr(values), N, K, H * W, L.stream_ptr(t))
+                # squeeze_channels (imaug.py:390): the pair survives iff exactly K distinct label values occur
+                keep = np.array([bin(int(v) & 0xffffffff).count("1") == K for v in values.cpu().numpy()])
+            elif self.ch and self.ch > 1:
                 full = (1 << self.ch) - 1
                 keep = (present.cpu().numpy() & full) == full         # host sync: the batch size may change
         else:
             t = (targets[:, 0] if targets.ndim == 4 else targets).float().contiguous()
             PF = zero.copy()
-            PF[:, 0] = P[:, 0]
+            PF[:, 0] = flips
             t = self._point(t, PF, None, None)
+            if geo:
+                t = self._geometry(t, zv, out_hw, 1, True)
             targets = t[:, None] if targets.ndim == 4 else t
         if keep is not None and not keep.all():
             idx = torch.from_numpy(np.nonzero(keep)[0]).to(x.device)

@@ -234,6 +234,18 @@ int amx_aug_renorm(float* x, long n, const float* mnmx, void* stream);
 int amx_aug_blur(const float* x, float* y, const float* sigma, int N, int H, int W, int axis, void* stream);
 int amx_aug_labels(const long long* t, long long* out, const float* params, int* present, int N, int H, int W,
                    void* stream);
+/* apply_zoom / apply_imresize (transforms/imaug.py:195-227, 276-300): cv2.resize of a per-image source window win[n] =
+ * (y0, x0, h, w) of the [Hs][Ws] frame to [Hd][Wd]; mode 0 = INTER_LINEAR (what apply_imresize executes: its method
+ * argument lands in cv2.resize's `dst` slot), 1 = INTER_CUBIC (a = -0.75; apply_zoom).  clip01: np.clip(img, 0, 1);
+ * round_out: np.around (masks).  int64 class maps travel as the reference moves them: amx_aug_onehot expands them to K
+ * float planes ([N][K][HW], unsqueeze_channels imaug.py:396-403), the planes are resampled like images with round_out,
+ * amx_aug_squeeze forms label = sum_c c * mask_c (squeeze_channels, imaug.py:361-393) and values[n] |= 1 << label (caller
+ * zeroes it; the reference keeps a pair iff exactly K distinct values occur).
+ * OpenCV's arithmetic restated from its documentation: UNPINNED against cv2 (absent), see oracle/aug_oracle.py. */
+int amx_aug_resample(const float* x, float* y, const int* win, int N, int Hs, int Ws, int Hd, int Wd, int mode,
+                     int clip01, int round_out, void* stream);
+int amx_aug_onehot(const long long* t, float* masks, int N, int K, long HW, void* stream);
+int amx_aug_squeeze(const float* masks, long long* out, int* values, int N, int K, long HW, void* stream);
 
 /* ---- dense layers (nn.Linear + Tanh / ReLU of fcEncoderNet / fcDecoderNet / the convEncoderNet heads,
  * atomai/nets/ed.py:231-343, 530-580, and of fcFeatureExtractor, atomai/nets/gp.py:14-26): one fp32-MFMA GEMM

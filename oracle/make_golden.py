@@ -611,6 +611,58 @@ def make_iou(aoi):
     np.savez_compressed(os.path.join(GOLD, "iou.npz"), **out)
 
 
+def make_augment_geom(aoi):
+    """rotation -> zoom -> resize of the reference's OWN seg_augmentor / datatransform code (imaug.py:195-227, 253-300,
+    302-432).  cv2 is absent in this image: its three entry points are replaced by their documented semantics —
+    cv2.flip / cv2.rotate by numpy index reversals / rot90, cv2.resize by oracle/aug_oracle.cv_resize (OpenCV's
+    INTER_LINEAR / INTER_CUBIC arithmetic restated; note the shim keeps cv2.resize's real signature, so the reference's
+    ``cv2.resize(img, (w, h), rs_method)`` hands rs_method to `dst` and runs INTER_LINEAR, as with the real cv2).  Pinned
+    by this golden: draw order and counts under a seed, crop windows, candidate sizes, clipping / rounding, one-hot
+    travel of the class maps, squeeze_channels incl. the dropped pairs.  NOT pinned: cv2's arithmetic itself."""
+    import atomai.transforms.imaug as ri
+    import aug_oracle as ao
+    cv2 = ri.cv2
+    cv2.INTER_LINEAR, cv2.INTER_CUBIC, cv2.INTER_AREA = 1, 2, 3
+    cv2.ROTATE_90_CLOCKWISE, cv2.ROTATE_90_COUNTERCLOCKWISE = 0, 2
+
+    def resize(src, dsize, dst=None, fx=0, fy=0, interpolation=1):
+        mode = {1: "linear", 2: "cubic"}[interpolation]
+        if src.ndim == 2:
+            return ao.cv_resize(src, (dsize[1], dsize[0]), mode)
+        out = np.stack([ao.cv_resize(src[..., c], (dsize[1], dsize[0]), mode) for c in range(src.shape[-1])], -1)
+        return out[..., 0] if out.shape[-1] == 1 else out       # cv2 drops a trailing singleton channel
+    cv2.resize = resize
+    cv2.flip = lambda img, code: ao.flip(img, 0 if code == 0 else (1 if code > 0 else -1))
+    cv2.rotate = lambda img, code: np.rot90(img, -1 if code == 0 else 1)
+    out = {}
+    rs = np.random.RandomState(61)
+    for name, (K, N, H, W, kw, seed) in {
+            "c3_zoom": (3, 6, 48, 48, dict(zoom=True), 3), "c3_resize": (3, 5, 40, 40, dict(resize=True), 4),
+            "c3_rot_zoom_resize": (3, 6, 48, 48, dict(rotation=True, zoom=True, resize=[2, 1.5]), 5),
+            "c1_zoom_resize": (1, 4, 32, 48, dict(zoom=3, resize=True), 6),
+            "c4_all": (4, 5, 64, 64, dict(rotation=True, zoom=True, resize=True), 7),
+            "c3_drop": (3, 6, 48, 48, dict(zoom=4, rotation=True), 8)}.items():
+        x = rs.rand(N, 1, H, W).astype(np.float32)
+        # blob-like class maps so that every class survives most crops
+        yy, xx = np.mgrid[0:H, 0:W]
+        if K == 1:
+            lab = ((np.sin(yy / 5.0)[None] + np.cos(xx / 4.0)[None] + rs.rand(N, 1, 1)) > 0.6).astype(np.float32)[:, None]
+        else:
+            lab = ((yy[None] // 6 + xx[None] // 5 + rs.randint(0, K, (N, 1, 1))) % K).astype(np.int64)
+        if name == "c3_drop":                                # images 1 and 3 hold class 2 only in a corner: lost by most crops
+            for i in (1, 3):
+                lab[i] = lab[i] % 2
+                lab[i, :3, :3] = 2
+        aug = ri.seg_augmentor(K, **kw)
+        xi, li = aug(torch.from_numpy(x), torch.from_numpy(lab), seed)
+        out[f"{name}|x"], out[f"{name}|lab"] = x, lab
+        out[f"{name}|cfg"] = np.array([K, seed])
+        out[f"{name}|kw"] = np.array(repr(kw))
+        out[f"{name}|x_out"], out[f"{name}|lab_out"] = xi.numpy(), li.numpy()
+        print("augment_geom", name, tuple(x.shape), "->", tuple(xi.shape), tuple(li.shape))
+    np.savez_compressed(os.path.join(GOLD, "augment_geom.npz"), **out)
+
+
 def make_gp(aoi):
     """fcFeatureExtractor (nets/gp.py:14-26) exactly as dklGPTrainer builds it (gptrainer.py:162-177, 254-262):
     ``set_seed_and_precision`` (utils/nn.py:149-167) seeds numpy / torch with 42 and makes the chosen precision the
@@ -653,10 +705,10 @@ def make_gp(aoi):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp", "dil_drop", "iou"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp", "dil_drop", "iou", "augment_geom"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp, "dil_drop": make_dil_drop, "iou": make_iou}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp, "dil_drop": make_dil_drop, "iou": make_iou, "augment_geom": make_augment_geom}[w](aoi)
     print("done ->", GOLD)

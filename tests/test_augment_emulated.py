@@ -35,3 +35,7 @@ def test_generator_statistics():
 
 def test_class_drop_and_trainer_hook():
     A.check_class_drop_and_trainer_hook("cpu")
+
+
+def test_zoom_and_resize_vs_reference_golden():
+    A.check_augment_geometry_golden("cpu")

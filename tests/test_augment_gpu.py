@@ -21,3 +21,7 @@ def test_generator_statistics():
 
 def test_class_drop_and_trainer_hook():
     A.check_class_drop_and_trainer_hook("cuda")
+
+
+def test_zoom_and_resize_vs_reference_golden():
+    A.check_augment_geometry_golden("cuda")
