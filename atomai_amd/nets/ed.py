@@ -182,10 +182,11 @@ _RDEC_MAX_CHANNELS = 4
 class rDecoderNet(nn.Module):
     """Spatial decoder with (optional) skip connections (ed.py:583-642) on the fused HIP kernels.
 
-    Limits of the fused kernels (each raises): hidden_dim <= 128 — one wave owns 16 hidden units and keeps its slice
-    of every weight matrix and weight-gradient accumulator in registers, which at 256 units would need 16 waves x
-    ~330 registers; 1-5 hidden layers (LDS holds one activation image per layer in the backward pass); 1-4 output
-    channels."""
+    The fused kernels cover hidden_dim <= 128 (one wave owns 16 hidden units and keeps its slice of every weight
+    matrix and weight-gradient accumulator in registers; at 256 units that would be 16 waves x ~330 registers), 1-5
+    hidden layers (LDS holds one activation image per layer in the backward pass) and 1-4 output channels — every
+    configuration the reference's defaults and tests use.  Anything larger runs LAYER BY LAYER on the fp32-MFMA GEMM
+    (csrc/linear.hip) with the activations in HBM, i.e. with the reference's own dataflow (``_forward_layered``)."""
 
     def __init__(self, out_dim: Tuple[int], latent_dim: int, num_layers: int, hidden_dim: int,
                  skip: bool = False) -> None:
@@ -205,12 +206,28 @@ class rDecoderNet(nn.Module):
         self.out = nn.Linear(hidden_dim, c)
         self.hidden_dim, self.num_layers, self.channels = hidden_dim, num_layers, c
 
+    def _fused(self) -> bool:
+        return (1 <= self.channels <= _RDEC_MAX_CHANNELS and self.hidden_dim <= _RDEC_WIDTHS[-1]
+                and 1 <= self.num_layers <= _RDEC_MAX_LAYERS)
+
+    def _forward_layered(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """The reference's forward (ed.py:626-642, 672-687) layer by layer: every Linear (+ Tanh) is one launch of the
+        MFMA GEMM with its own autograd (nets/_linear.py); the (B*n, hidden) activations live in HBM."""
+        B, n = x_coord.shape[:2]
+        cl = self.coord_latent
+        h_x = linear(x_coord.reshape(B * n, -1), cl.fc_coord.weight, cl.fc_coord.bias).reshape(B, n, -1)
+        h = (h_x + linear(z, cl.fc_latent.weight, None).unsqueeze(1)).reshape(B * n, -1)
+        if cl.activation is not None:
+            h = torch.tanh(h)
+        residual = h
+        for m in self.fc_decoder:
+            if isinstance(m, nn.Linear):
+                h = linear(h, m.weight, m.bias, "tanh")
+                if self.skip:
+                    h = h + residual
+        return linear(h, self.out.weight, self.out.bias).reshape(B, *self.reshape_)
+
     def _params(self):
-        if not 1 <= self.channels <= _RDEC_MAX_CHANNELS:
-            raise NotImplementedError(f"fused rDecoderNet supports 1-{_RDEC_MAX_CHANNELS} output channels")
-        if self.hidden_dim > _RDEC_WIDTHS[-1] or not 1 <= self.num_layers <= _RDEC_MAX_LAYERS:
-            raise NotImplementedError(f"fused rDecoderNet supports hidden_dim <= {_RDEC_WIDTHS[-1]} and "
-                                      f"1-{_RDEC_MAX_LAYERS} layers")
         params = [self.coord_latent.fc_coord.weight, self.coord_latent.fc_coord.bias,
                   self.coord_latent.fc_latent.weight]
         for m in self.fc_decoder:
@@ -220,12 +237,18 @@ class rDecoderNet(nn.Module):
 
     def forward(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         """The reference's signature: explicit (B, n, 2) coordinates."""
+        if not self._fused():
+            return self._forward_layered(x_coord, z)
         h = _RDecoderFn.apply(self, x_coord, None, z, *self._params())
         return h.reshape(x_coord.size(0), *self.reshape_)
 
     def forward_grid(self, grid: torch.Tensor, theta: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         """Decodes at ``transform_coordinates(grid, theta[:, 0], theta[:, 1:3])`` without materialising the (B, n, 2)
         coordinates: ``grid`` is the shared (n, 2) ``imcoordgrid``, ``theta`` = (B, 3) (angle, dx, dy)."""
+        if not self._fused():
+            from ..utils.coords import transform_coordinates
+            coords = transform_coordinates(grid.expand(z.size(0), *grid.shape), theta[:, 0], theta[:, None, 1:3])
+            return self._forward_layered(coords.contiguous(), z)
         h = _RDecoderFn.apply(self, grid, theta, z, *self._params())
         return h.reshape(z.size(0), *self.reshape_)
 

@@ -29,7 +29,9 @@ def test_elbo_grads_adam(name):
 
 
 @pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (12, 12)), (128, 3, 1, (8, 8)),
-                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (6, 6, 3))])
+                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (6, 6, 3)),
+                                            # beyond the fused kernels (width > 128, > 5 layers, > 4 channels): layer by layer
+                                            (160, 2, 0, (7, 5)), (24, 6, 1, (6, 5)), (32, 2, 0, (5, 4, 5))])
 def test_rdecoder_shapes(hid, nl, skip, hw):
     V.check_rdecoder_shapes("cpu", hid, nl, skip, hw)
 

@@ -16,7 +16,8 @@ def test_elbo_grads_adam(name):
 
 
 @pytest.mark.parametrize("hid,nl,skip,hw", [(64, 1, 0, (7, 5)), (128, 2, 0, (64, 64)), (128, 3, 1, (24, 24)),
-                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (33, 31, 3))])
+                                            (32, 5, 0, (9, 6, 2)), (100, 4, 1, (33, 31, 3)),
+                                            (256, 2, 0, (33, 31)), (24, 6, 1, (16, 15)), (32, 2, 0, (15, 14, 5))])
 def test_rdecoder_shapes(hid, nl, skip, hw):
     """Both coordinate modes (explicit / rotated in the kernel), 1-5 layers, 1-3 channels, odd pixel counts."""
     V.check_rdecoder_shapes("cuda", hid, nl, skip, hw, B=3)
