@@ -428,3 +428,64 @@ extern "C" int amx_reduce_rows_chunked(const float* part, int rows, long ncols, 
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------ column sums of SEVERAL partial-row tensors at once
+// The rVAE decoder backward leaves seven per-sample partial tensors part_k[rows][cols_k] (dW, db per hidden layer, dWo,
+// dbo, dWc, dbc, dWz; rdecoder.hip); summing each with its own pair of launches put 14 five-to-eighteen-microsecond kernels on the
+// stream after every backward (profiles/r03_rvae_step_timeline.txt).  Here the column spaces are concatenated: ONE
+// stage-1 launch (chunk sums in row order, fp64 accumulation) and ONE stage-2 launch (chunks in order) serve all of
+// them; out_k receives cols_k floats.  Same arithmetic and order as amx_reduce_rows_chunked twice -> identical values.
+#define AMX_MAXSEG 16
+struct SegArgs { const float* part[AMX_MAXSEG]; float* out[AMX_MAXSEG]; long stride[AMX_MAXSEG]; long start[AMX_MAXSEG + 1]; int nseg; };
+
+__global__ __launch_bounds__(256) void reduce_rows_segments_kernel(SegArgs s, int rows, int chunk, float* __restrict__ tmp) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= s.start[s.nseg]) return;
+    int k = 0;
+    while (j >= s.start[k + 1]) ++k;
+    const long c = j - s.start[k], ncols = s.stride[k];          // (row stride of this segment, >= its column count)
+    const float* part = s.part[k];
+    const int r0 = blockIdx.y * chunk;
+    const int r1 = r0 + chunk < rows ? r0 + chunk : rows;
+    double a = 0.0;
+    for (int r = r0; r < r1; r += 8) {
+        float v[8];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (r + q < r1) ? part[(size_t)(r + q) * ncols + c] : 0.f;
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) a += (double)v[q];
+    }
+    tmp[(size_t)blockIdx.y * s.start[s.nseg] + j] = (float)a;
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_segments_final_kernel(SegArgs s, int nch, const float* __restrict__ tmp) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    const long tot = s.start[s.nseg];
+    if (j >= tot) return;
+    int k = 0;
+    while (j >= s.start[k + 1]) ++k;
+    double a = 0.0;
+    for (int r = 0; r < nch; ++r) a += (double)tmp[(size_t)r * tot + j];
+    s.out[k][j - s.start[k]] = (float)a;
+}
+
+// tmp: nchunks * (sum of cols) floats; strides[k] >= cols[k]: floats between consecutive rows of parts[k]
+extern "C" int amx_reduce_rows_segments(const float* const* parts, const long* cols, const long* strides,
+                                        float* const* outs, int nseg, int rows, int nchunks, float* tmp, void* stream) {
+    if (!parts || !cols || !strides || !outs || !tmp || nseg < 1 || nseg > AMX_MAXSEG || rows <= 0 || nchunks <= 0) AMX_BADARG(1);
+    SegArgs s;
+    s.nseg = nseg; s.start[0] = 0;
+    for (int k = 0; k < AMX_MAXSEG; ++k) { s.part[k] = nullptr; s.out[k] = nullptr; s.stride[k] = 0; }
+    for (int k = 0; k < nseg; ++k) {
+        if (!parts[k] || !outs[k] || cols[k] <= 0 || strides[k] < cols[k]) AMX_BADARG(2);
+        s.part[k] = parts[k]; s.out[k] = outs[k]; s.stride[k] = strides[k]; s.start[k + 1] = s.start[k] + cols[k];
+    }
+    const int chunk = amx_ceil_div(rows, nchunks);
+    const int nch = amx_ceil_div(rows, chunk);
+    const unsigned nb = (unsigned)((s.start[nseg] + 255) / 256);
+    AMX_LAUNCH(reduce_rows_segments_kernel, dim3(nb, nch), dim3(256), 0, (hipStream_t)stream, s, rows, chunk, tmp);
+    AMX_CHECK_LAUNCH();
+    AMX_LAUNCH(reduce_rows_segments_final_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, s, nch, tmp);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}

@@ -30,6 +30,9 @@ struct GemmArgs {
     int M, N, K;
     int act;                            // 0 none, 1 tanh, 2 relu
     int vecA, vecB;                     // 1: k-contiguous, aligned float4 path is legal for this operand
+    int kchunk;                         // split-K: k range of blockIdx.z is [z * kchunk, min(K, (z + 1) * kchunk)) (multiple
+                                        // of 16); 0 = the whole K in one workgroup
+    float* work;                        // split-K: raw partial sums [splits][M][N] (bias / activation in the reduce kernel)
 };
 
 // One operand tile (ROWS rows x 16 k) -> 4 registers per thread.  `rs` / `ks` are the row / k strides.
@@ -72,20 +75,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         #pragma unroll
         for (int j = 0; j < TW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // split-K (deterministic: every slice is a k-ascending chain, the slices are added in slice order by
+    // gemm_splitk_reduce_kernel): a 512 x 128 x 4096 layer is 64 workgroups of 256 serial k steps otherwise (167 us)
+    const int kbeg = a.kchunk ? (int)blockIdx.z * a.kchunk : 0;
+    const int kend = a.kchunk ? (kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K) : a.K;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     if (loader) {
-        ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, 0, a.K, a.vecA, tid);
-        rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, 0, a.K, a.vecB, tid);
+        ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, kbeg, kend, a.vecA, tid);
+        rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, kbeg, kend, a.vecB, tid);
     }
-    for (int k0 = 0; k0 < a.K; k0 += LBK) {
+    for (int k0 = kbeg; k0 < kend; k0 += LBK) {
         if (loader) {
             amx_st4(sA + ((tid & 3) * LB + (tid >> 2)) * 4, ra);
             amx_st4(sB + ((tid & 3) * LB + (tid >> 2)) * 4, rb);
         }
         __syncthreads();
-        if (loader && k0 + LBK < a.K) {
-            ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, k0 + LBK, a.K, a.vecA, tid);
-            rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, k0 + LBK, a.K, a.vecB, tid);
+        if (loader && k0 + LBK < kend) {
+            ra = gemm_load(a.A, a.sam, a.sak, m0, a.M, k0 + LBK, kend, a.vecA, tid);
+            rb = gemm_load(a.B, a.sbn, a.sbk, n0, a.N, k0 + LBK, kend, a.vecB, tid);
         }
         float4 af[TW], bf[TW];
         #pragma unroll
@@ -102,6 +109,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         __syncthreads();
     }
     // D fragment: column n = p, rows 4 g + r
+    if (a.kchunk) {                                              // raw partial sums of this k slice
+        float* W = a.work + (size_t)blockIdx.z * a.M * a.N;
+        #pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int n = n0 + (wn * TW + j) * 16 + p;
+            if (n >= a.N) continue;
+            #pragma unroll
+            for (int i = 0; i < TW; ++i)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + (wm * TW + i) * 16 + 4 * g + r;
+                    if (m < a.M) W[(size_t)m * a.N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     #pragma unroll
     for (int j = 0; j < TW; ++j) {
         const int n = n0 + (wn * TW + j) * 16 + p;
@@ -123,13 +146,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
 
 static int aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// C[m][n] = act(bias[n] + sum_z work[z][m][n]), z ascending
+__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ work, int splits, float* __restrict__ C, long scm,
+                                          const float* __restrict__ bias, int M, int N, int act) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N); const long m = i / N;
+        float v = work[i];
+        for (int z = 1; z < splits; ++z) v += work[(size_t)z * total + i];
+        v += bias ? bias[n] : 0.f;
+        if (act == 1) v = tanhf(v);
+        else if (act == 2) v = v > 0.f ? v : 0.f;
+        C[m * scm + n] = v;
+    }
+}
+
 // C[M][N] = act(A * B + bias) with arbitrary operand strides (see the file header for the three uses).
+// Number of k slices amx_gemm_f32_splitk will use for this problem (1 = no split: plain amx_gemm_f32); the caller
+// provides splits * M * N floats of workspace.
+extern "C" int amx_gemm_f32_splits(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 1;
+    const long wg = (long)amx_ceil_div(N, 32) * amx_ceil_div(M, 32);     // 32 x 32 tiles (the small-problem plan)
+    if (wg >= 128 || K < 1024) return 1;
+    int s = (int)((512 + wg - 1) / wg);                          // aim at ~512 workgroups
+    if (s > K / 256) s = K / 256;                                // >= 256 k per slice
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
+extern "C" int amx_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+                                   long scm, const float* bias, int M, int N, int K, int act, float* work, int splits,
+                                   void* stream);
+
 extern "C" int amx_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
                             long scm, const float* bias, int M, int N, int K, int act, void* stream) {
+    return amx_gemm_f32_splitk(A, sam, sak, B, sbk, sbn, C, scm, bias, M, N, K, act, nullptr, 1, stream);
+}
+
+extern "C" int amx_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C,
+                                   long scm, const float* bias, int M, int N, int K, int act, float* work, int splits,
+                                   void* stream) {
     if (!A || !B || !C) AMX_BADARG(1);
     if (M <= 0 || N <= 0 || K <= 0) AMX_BADARG(2);
     if (act < 0 || act > 2 || scm < N) AMX_BADARG(3);
+    if (splits < 1 || splits > 64 || (splits > 1 && !work)) AMX_BADARG(5);
     GemmArgs a;
+    a.kchunk = 0; a.work = nullptr;
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.scm = scm; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.act = act;
     a.vecA = sak == 1 && (sam & 3) == 0 && aligned16(A);
@@ -140,9 +202,22 @@ extern "C" int amx_gemm_f32(const float* A, long sam, long sak, const float* B, 
     if (const char* e = getenv("AMX_GEMM_TILE")) { const int v = atoi(e); if (v == 32 || v == 64) tile = v; }
     dim3 grid(amx_ceil_div(N, tile), amx_ceil_div(M, tile));
     if (grid.y > 65535) AMX_BADARG(4);
+    if (splits > 1) {
+        a.kchunk = amx_round_up(amx_ceil_div(K, splits), LBK);
+        a.work = work;
+        grid.z = amx_ceil_div(K, a.kchunk);
+        tile = 32; grid.x = amx_ceil_div(N, 32); grid.y = amx_ceil_div(M, 32);
+    }
     if (tile == 32) AMX_LAUNCH(gemm_f32_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else AMX_LAUNCH(gemm_f32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
     AMX_CHECK_LAUNCH();
+    if (splits > 1) {
+        long nb = ((long)M * N + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        AMX_LAUNCH(gemm_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, work, (int)grid.z, C,
+                   scm, bias, M, N, act);
+        AMX_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -13,11 +13,31 @@ from .. import _lib as L
 ACT = {None: 0, "none": 0, "tanh": 1, "relu": 2}
 
 
-def _gemm(A, sam, sak, B, sbk, sbn, M, N, K, bias=None, act=0):
-    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    L.call("amx_gemm_f32", L.ptr(A), sam, sak, L.ptr(B), sbk, sbn, L.ptr(C), N, L.ptr(bias), M, N, K, act,
-           L.stream_ptr(A))
+def _gemm(A, sam, sak, B, sbk, sbn, M, N, K, bias=None, act=0, out=None):
+    """C[M][N] = act(A * B + bias); ``out``: write into this (M, N) contiguous tensor (a view of the optimizer's flat
+    gradient bucket for weight gradients) instead of a fresh one.  Long-K problems with few output tiles are split
+    along k (deterministic two-stage sum, csrc/linear.hip)."""
+    C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    splits = L.load().amx_gemm_f32_splits(M, N, K)
+    if splits > 1:
+        work = torch.empty(splits * M * N, dtype=torch.float32, device=A.device)
+        L.call("amx_gemm_f32_splitk", L.ptr(A), sam, sak, L.ptr(B), sbk, sbn, L.ptr(C), N, L.ptr(bias), M, N, K, act,
+               L.ptr(work), splits, L.stream_ptr(A))
+    else:
+        L.call("amx_gemm_f32", L.ptr(A), sam, sak, L.ptr(B), sbk, sbn, L.ptr(C), N, L.ptr(bias), M, N, K, act,
+               L.stream_ptr(A))
     return C
+
+
+def _grad_target(param, shape, like):
+    """The optimizer's flat-bucket view for this parameter's gradient (engine.grad_buffer) when it can be written
+    directly — the FusedAdam step then finds the gradient in place instead of copying it (17 device-to-device copies
+    per rVAE step, 80 us) — else None."""
+    from ..engine import grad_buffer
+    if param is None or getattr(param, "_amx_grad", None) is None or tuple(param.shape) != tuple(shape):
+        return None
+    v = grad_buffer(param, like)
+    return v if (v.data_ptr() == param._amx_grad.data_ptr() and v.is_contiguous()) else None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -29,6 +49,7 @@ class _LinearFn(torch.autograd.Function):
         N = w.shape[0]
         y = _gemm(x2, K, 1, w, 1, K, M, N, K, None if bias is None else bias.detach().contiguous(), act)
         ctx.act, ctx.has_bias = act, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias                # (the Parameters themselves: their flat-bucket gradient views)
         ctx.save_for_backward(x2, w, y if act else None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -47,7 +68,10 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:                      # dx[M][K] = dpre[M][N] * W[N][K]
             dx = _gemm(dpre, N, 1, w, K, 1, M, K, N).reshape(*dy.shape[:-1], K)
         if ctx.needs_input_grad[1]:                      # dW[N][K] = dpre^T[N][M] * x[M][K]
-            dw = _gemm(dpre, 1, N, x2, K, 1, N, K, M)
+            tgt = _grad_target(ctx.wparam, (N, K), dpre)
+            dw = _gemm(dpre, 1, N, x2, K, 1, N, K, M, out=tgt)
+            if tgt is not None:
+                dw = dw.view(N, K)                       # a fresh tensor object over the bucket: autograd adopts it as .grad
         if ctx.has_bias and ctx.needs_input_grad[2]:     # column sums in (at most) two deterministic stages
             rows, src = M, dpre
             if rows > 64:
@@ -55,8 +79,10 @@ class _LinearFn(torch.autograd.Function):
                 tmp = torch.empty(nch, N, dtype=torch.float32, device=dpre.device)
                 L.call("amx_reduce_rows_chunked", L.ptr(src), rows, N, nch, L.ptr(tmp), sp)
                 src, rows = tmp, -(-rows // -(-rows // nch))
-            db = torch.empty(N, dtype=torch.float32, device=dpre.device)
+            tgt = _grad_target(ctx.bparam, (N,), dpre)
+            db = tgt.view(N) if tgt is not None else torch.empty(N, dtype=torch.float32, device=dpre.device)
             L.call("amx_reduce_rows_chunked", L.ptr(src), rows, N, 1, L.ptr(db), sp)
+        ctx.wparam = ctx.bparam = None
         return dx, dw, db, None
 
 

@@ -155,23 +155,43 @@ class _RDecoderFn(torch.autograd.Function):
                L.ptr(pWo), L.ptr(pbo), L.ptr(pWc), L.ptr(pbc), L.ptr(pWz), B, n, Ldim, hid, NL, int(net.skip), C, sp)
         del hsave
 
-        def rsum(part, shape):
-            cols = part.shape[1]
-            out = e(cols)
-            rows, src = B, part
-            if rows > 64:
-                nch = 32
-                tmp = e(nch, cols)
-                L.call("amx_reduce_rows_chunked", L.ptr(src), rows, cols, nch, L.ptr(tmp), sp)
-                src, rows = tmp, -(-rows // -(-rows // nch))
-            L.call("amx_reduce_rows_chunked", L.ptr(src), rows, cols, 1, L.ptr(out), sp)
-            return out.view(shape)
-        gW = rsum(pW, (NL, hid, hid))[:, :hid0, :hid0]
-        gb = rsum(pb, (NL, hid))[:, :hid0]
-        grads = [rsum(pWc, (hid, 2))[:hid0], rsum(pbc, (hid,))[:hid0], rsum(pWz, (hid, Ldim))[:hid0]]
+        # column sums of the seven per-sample partial tensors in TWO launches (amx_reduce_rows_segments), written straight
+        # into the optimizer's flat gradient bucket where the (unpadded) parameter shape allows it
+        import ctypes
+        from ._linear import _grad_target
+        plist = net._params()                                   # Wc, bc, Wz, (W_l, b_l)*, Wo, bo
+        exact = hid == hid0
+        def target(param, shape):
+            t = _grad_target(param, shape, coords) if exact else None
+            return t if t is not None else e(*shape)
+        # one segment per parameter: (partial tensor, first column, columns, row stride) -> gradient tensor
+        segs = [(pWc, 0, hid * 2, plist[0], (hid, 2)), (pbc, 0, hid, plist[1], (hid,)), (pWz, 0, hid * Ldim, plist[2], (hid, Ldim))]
         for l in range(NL):
-            grads += [gW[l], gb[l]]
-        grads += [rsum(pWo, (C, hid))[:, :hid0], rsum(pbo, (C,))]
+            segs += [(pW, l * hid * hid, hid * hid, plist[3 + 2 * l], (hid, hid)), (pb, l * hid, hid, plist[4 + 2 * l], (hid,))]
+        segs += [(pWo, 0, C * hid, plist[3 + 2 * NL], (C, hid)), (pbo, 0, C, plist[4 + 2 * NL], (C,))]
+        outs = [target(prm, shp) for _, _, _, prm, shp in segs]
+        cols = [c for _, _, c, _, _ in segs]
+        nch = 32 if B > 64 else 1
+        tmp = e(nch * sum(cols))
+        n_ = len(segs)
+        PP, LL = ctypes.c_void_p * n_, ctypes.c_long * n_
+        L.call("amx_reduce_rows_segments", PP(*[t.data_ptr() + 4 * off for t, off, _, _, _ in segs]), LL(*cols),
+               LL(*[t.shape[1] for t, _, _, _, _ in segs]), PP(*[t.data_ptr() for t in outs]), n_, B, nch, L.ptr(tmp), sp)
+        cut = {1: lambda t: t[:hid0], 2: lambda t: t[:hid0, :hid0]}
+        grads = []
+        for (_, _, _, prm, shp), o in zip(segs, outs):
+            o = o.view(*shp)
+            if not exact:                                       # padded kernels: cut back to the parameter's shape
+                if prm is plist[0] or prm is plist[2]:
+                    o = o[:hid0]
+                elif prm is plist[3 + 2 * NL]:
+                    o = o[:, :hid0]
+                elif prm is plist[4 + 2 * NL]:
+                    pass
+                else:
+                    o = cut[len(shp)](o)
+            grads.append(o)
+        del outs, segs
         return (None, dcoords, dtheta, dz) + tuple(grads)
 
 

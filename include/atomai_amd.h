@@ -165,6 +165,12 @@ int amx_reduce_rows(const float* part, int rows, int stride, int C, float scale,
 int amx_bn_stats_merge(const float* stats, int rows, int cop, int mode, int N, int H, int W, int rows_pix, int lat,
                        int nchunks, float* out, void* stream);
 int amx_reduce_rows_chunked(const float* part, int rows, long ncols, int nchunks, float* out, void* stream);
+/* column sums of up to 16 partial-row tensors in two launches (chunk sums in row order, then the chunks in order: the
+ * arithmetic of amx_reduce_rows_chunked applied twice): row r of segment k starts at parts[k] + r * strides[k] and has
+ * cols[k] columns; outs[k]: cols[k] floats; tmp: nchunks * sum(cols) floats.  Serves the per-sample gradient partials
+ * of amx_rdecoder_bwd (one segment per parameter, each summed straight into its gradient buffer). */
+int amx_reduce_rows_segments(const float* const* parts, const long* cols, const long* strides, float* const* outs,
+                             int nseg, int rows, int nchunks, float* tmp, void* stream);
 
 /* ---- F.max_pool2d(x,2,2) (fcnn.py:123-127,219), F.interpolate x2 (blocks.py:130-131), DilatedBlock sum
  * (blocks.py:321-329).  mode: 0 bilinear (align_corners=False), 1 nearest. */
@@ -255,6 +261,12 @@ int amx_aug_squeeze(const float* masks, long long* out, int* values, int N, int 
  * amx_act_bwd: dpre = dy * act'(y) from the layer OUTPUT y (tanh: 1 - y^2, relu: y > 0). */
 int amx_gemm_f32(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
                  const float* bias, int M, int N, int K, int act, void* stream);
+/* the same with the k range cut into `splits` slices (amx_gemm_f32_splits(M, N, K): 1 = not worth it) whose raw partial
+ * sums go to work[splits][M][N] and are added in slice order before bias / activation — deterministic; for long-K layers
+ * with few output tiles (the 512 x 128 x 4096 first encoder layer of the VAEs: 64 workgroups of 256 serial k steps). */
+int amx_gemm_f32_splits(int M, int N, int K);
+int amx_gemm_f32_splitk(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long scm,
+                        const float* bias, int M, int N, int K, int act, float* work, int splits, void* stream);
 int amx_act_bwd(const float* dy, const float* y, float* out, long n, int act, void* stream);
 
 /* ---- rVAE spatial decoder (rDecoderNet + coord_latent, atomai/nets/ed.py:583-687): per-pixel MLP with all

@@ -61,3 +61,36 @@ def check_linear_autograd(device):
     ref = seq.double()(x.double()) if device == "cpu" else seq(x).double()
     seq.float()
     assert float((run_dense(seq, x).double() - ref).abs().max()) < 1e-5
+
+
+def check_gemm_splitk(device, sizes=((37, 5, 4099), (40, 24, 1500), (512, 128, 4096))):
+    """Long-K problems with few output tiles go through the split-K path (amx_gemm_f32_splitk: k slices summed in slice
+    order, then bias / activation): against float64 matmul, bit-identical between two runs, and reached through
+    nets/_linear.linear with its autograd."""
+    from atomai_amd import _lib as L
+    from atomai_amd.nets._linear import linear
+    rs = np.random.RandomState(1)
+    for (M, N, K) in sizes:
+        splits = L.load().amx_gemm_f32_splits(M, N, K)
+        assert splits > 1, (M, N, K)
+        x = torch.from_numpy(rs.randn(M, K).astype(np.float32)).to(device)
+        w = torch.from_numpy((rs.randn(N, K) / np.sqrt(K)).astype(np.float32)).to(device)
+        b = torch.from_numpy(rs.randn(N).astype(np.float32)).to(device)
+        ref = torch.tanh(x.double().cpu() @ w.double().cpu().T + b.double().cpu())
+        outs = []
+        for _ in range(2):
+            y = torch.empty(M, N, device=device)
+            work = torch.empty(splits * M * N, device=device)
+            L.call("amx_gemm_f32_splitk", L.ptr(x), K, 1, L.ptr(w), 1, K, L.ptr(y), N, L.ptr(b), M, N, K, 1, L.ptr(work),
+                   splits, L.stream_ptr(x))
+            outs.append(y.cpu())
+        assert torch.equal(outs[0], outs[1])
+        assert float((outs[0].double() - ref).abs().max()) < 2e-5
+        wp = w.clone().requires_grad_(True)
+        yl = linear(x, wp, b, "tanh")
+        assert float((yl.detach().cpu().double() - ref).abs().max()) < 2e-5
+        yl.sum().backward()
+        xr, wr = x.double().cpu(), w.double().cpu().requires_grad_(True)
+        torch.tanh(xr @ wr.T + b.double().cpu()).sum().backward()
+        assert float((wp.grad.cpu().double() - wr.grad).abs().max()) < 1e-4 * max(1.0, float(wr.grad.abs().max()))
+    assert L.load().amx_gemm_f32_splits(16384, 1000, 256) == 1 and L.load().amx_gemm_f32_splits(64, 64, 512) == 1

@@ -150,6 +150,11 @@ def test_dense_gemm_strides_and_activations():
     C.check_gemm_strides("cpu", sizes=((37, 5, 259), (64, 64, 16), (70, 33, 17), (1, 1, 1)))
 
 
+def test_dense_gemm_split_k():
+    import _linear_checks as C
+    C.check_gemm_splitk("cpu", sizes=((37, 5, 1100), (40, 24, 1500)))
+
+
 def test_dense_layer_autograd():
     import _linear_checks as C
     C.check_linear_autograd("cpu")

@@ -13,3 +13,7 @@ def test_dense_gemm_strides_and_activations():
 
 def test_dense_layer_autograd():
     C.check_linear_autograd("cuda")
+
+
+def test_dense_gemm_split_k():
+    C.check_gemm_splitk("cuda")

@@ -80,7 +80,7 @@ def bench_rvae(steps=10, warmup=3, B=512, emit=True, ab=True):
            "roofline_decoder_pair": {"achieved": tfl(3 * fl_fwd, tf + tb), "frac": round(tfl(3 * fl_fwd, tf + tb) / PEAK, 4),
                                      "ms": round(tf + tb, 3)},
            "step_frac_of_mfma_f32_peak": round(tfl(3 * fl_fwd, dt * 1e3) / PEAK, 4)}
-    if ab:
+    if ab and not os.environ.get("AMX_RVAE_NO_AB"):
         ed.RDEC_SAVE[0] = not saved_default
         try:
             dt2, tf2, tb2, _ = run()
