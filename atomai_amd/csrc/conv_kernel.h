@@ -96,7 +96,7 @@ struct ConvFwdArgs {
 // AMX_CONV_GLDS 1: the weight image of a chunk goes global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of
 // through WLD float4 registers per thread (-20 VGPRs on the 32-cout classes, no ds_write pass); the DMA of chunk c+1 can
 // only be issued after the barrier that ends chunk c (the weight image is single-buffered), so its latency is exposed.
-// Measured (gpurun_out/r02y_probe.log, r02y_step_ab.log): at 4 waves/SIMD +1..5 % on the <= 32-channel layers, -1.5 % on
+// Measured (profiles/r02_logs/r02y_probe.log, r02y_step_ab.log): at 4 waves/SIMD +1..5 % on the <= 32-channel layers, -1.5 % on
 // the 128-channel ones, 19.28 -> 19.35 ms in the step; asking for 5 waves/SIMD (AMX_CONV_GLDS_WAVES) spills 15 registers
 // on the 32-cout class and is 3-10 % slower, and the 16-cout class, which fits 5 waves without spilling, gains nothing.
 // Off by default.

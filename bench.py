@@ -46,7 +46,8 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32 = 157.3     # TFLOP/s, MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
 H = W = 512
 BS = 32
-PMC_FILE = "profiles/r02_pmc_hbm_traffic.json"
+_pmc = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_hbm_traffic.json")))
+PMC_FILE = os.path.join("profiles", os.path.basename(_pmc[-1])) if _pmc else "profiles/none"    # the latest round's PMC pass
 
 
 def unet_conv_table(nb_filters=16, nb_classes=3, hw=512):
