@@ -6,6 +6,13 @@
 //   c1 = ConvBlock(2, nbl[0], 1, nb_filters): Conv2d(1, F, 3, padding=1) -> LeakyReLU -> BN stats
 //                                                   atomai/nets/fcnn.py:66-69, 186-189; blocks.py:61-76
 #include "amx_device.h"
+#ifndef AMX_CONV1_UNROLL
+#define AMX_CONV1_UNROLL 4      // weight gradient: pixels of a thread in flight together (a thread walks rows_pix / PL
+                                // pixels, each a global-load round trip): 192 -> 160 us per launch at bs 32, 512^2
+#endif
+#ifndef AMX_CONV1_UNROLL_FWD
+#define AMX_CONV1_UNROLL_FWD 1  // forward: 4 in flight cost occupancy (131 VGPRs) and measured slower (207 -> 242 us)
+#endif
 #ifndef AMX_CONV1_FAST
 #define AMX_CONV1_FAST 1        // compile-time experiment switch: interior pixels skip the per-tap bounds arithmetic
 #endif
@@ -37,42 +44,28 @@ struct PixCursor {
     }
 };
 
-// The 3x3 neighbourhood of pixel (yy, xx) of a single-channel image, zero padded.  Interior pixels (all but the
-// image border: > 99 % at 512^2) take the branch without the four bounds compares and the address arithmetic per tap:
-// three row pointers and, for dilation 1, immediate offsets (forward: 265 vs 450 us at 512^2 x 32).
+// The 3x3 neighbourhood of pixel (yy, xx) of a single-channel image, zero padded — BRANCH-FREE: row / column indices
+// are clamped into the image (every load is legal), out-of-image taps are zeroed by selects afterwards.  The round-1/2
+// form (an interior fast path, per-tap branches on the border) compiled to a load + s_waitcnt inside every branch, so a
+// thread had ONE global load in flight at a time and the unrolled pixel loop could not overlap pixels either: the two
+// first-layer kernels ran at 2.8-2.9 TB/s, latency-bound.  With straight-line code the 9 x AMX_CONV1_UNROLL loads of a
+// thread are issued back to back.
 // in_sub / in_div: the predictor's stack normalisation (x - min) / ptp (utils/preproc.py:822-823) applied to in-bounds
-// values while loading (the padding stays zero); (0, 1) is the exact identity.
+// values (the padding stays zero); (0, 1) is the exact identity.
 template <bool FAST>
 static __device__ __forceinline__ void load_3x3(const float* __restrict__ img, int yy, int xx, int H, int W, int dil,
                                                 float v[9], bool norm = false, float in_sub = 0.f, float in_div = 1.f) {
-    if (AMX_CONV1_FAST && FAST && yy >= dil && yy < H - dil && xx >= dil && xx < W - dil) {
-        const float* r1 = img + (size_t)yy * W + xx;
-        const float* r0 = r1 - (size_t)dil * W;
-        const float* r2 = r1 + (size_t)dil * W;
-        if (dil == 1) {
-            v[0] = r0[-1]; v[1] = r0[0]; v[2] = r0[1];
-            v[3] = r1[-1]; v[4] = r1[0]; v[5] = r1[1];
-            v[6] = r2[-1]; v[7] = r2[0]; v[8] = r2[1];
-        } else {
-            v[0] = r0[-dil]; v[1] = r0[0]; v[2] = r0[dil];
-            v[3] = r1[-dil]; v[4] = r1[0]; v[5] = r1[dil];
-            v[6] = r2[-dil]; v[7] = r2[0]; v[8] = r2[dil];
-        }
-        if (norm) {
-            #pragma unroll
-            for (int t = 0; t < 9; ++t) { const float d = v[t] - in_sub; v[t] = d / in_div; }
-        }
-        return;
-    }
+    const int ym = yy - dil, yp = yy + dil, xm = xx - dil, xp = xx + dil;
+    const bool oky[3] = {ym >= 0, true, yp < H}, okx[3] = {xm >= 0, true, xp < W};
+    const float* r[3] = {img + (size_t)(ym >= 0 ? ym : 0) * W, img + (size_t)yy * W, img + (size_t)(yp < H ? yp : H - 1) * W};
+    const int c[3] = {xm >= 0 ? xm : 0, xx, xp < W ? xp : W - 1};
+    #pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = r[t / 3][c[t % 3]];
     #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
-        float u = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            u = img[(size_t)iy * W + ix];
-            if (norm) { const float d = u - in_sub; u = d / in_div; }
-        }
-        v[t] = u;
+        float u = v[t];
+        if (norm) { const float d = u - in_sub; u = d / in_div; }
+        v[t] = (oky[t / 3] && okx[t % 3]) ? u : 0.f;
     }
 }
 
@@ -112,22 +105,34 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     if (active)
     {
         PixCursor cur; cur.init(p0 + pl < npix ? p0 + pl : 0, H, W);
-        for (long p = p0 + pl; p < p1; p += PL, cur.advance(PL, H, W)) {
-            const int xx = cur.xx, yy = cur.yy;
-            const float* img = x + (size_t)cur.nimg * H * W;
-            float4 acc = b4;
-            float xv[9];
-            load_3x3<true>(img, yy, xx, H, W, dil, xv, norm, in_sub, in_div);
+        constexpr int U = AMX_CONV1_UNROLL_FWD;
+        for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+            // U pixels of this thread in flight: all their neighbourhood loads are issued before the first FMA
+            float xv[U][9];
+            bool ok[U];
             #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float v = xv[t];
-                acc.x = fmaf(v, wt[t].x, acc.x); acc.y = fmaf(v, wt[t].y, acc.y);
-                acc.z = fmaf(v, wt[t].z, acc.z); acc.w = fmaf(v, wt[t].w, acc.w);
+            for (int u = 0; u < U; ++u) {
+                ok[u] = p + (long)u * PL < p1;
+                const long ni = ok[u] ? cur.nimg : 0;
+                load_3x3<true>(x + (size_t)ni * H * W, ok[u] ? cur.yy : 0, ok[u] ? cur.xx : 0, H, W, dil, xv[u], norm,
+                               in_sub, in_div);
+                if (ok[u]) cur.advance(PL, H, W);
             }
-            acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
-            acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
-            amx_st4(y + (size_t)p * Cs + cg * 4, acc);
-            sh_push(st, acc);
+            #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                float4 acc = b4;
+                #pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float v = xv[u][t];
+                    acc.x = fmaf(v, wt[t].x, acc.x); acc.y = fmaf(v, wt[t].y, acc.y);
+                    acc.z = fmaf(v, wt[t].z, acc.z); acc.w = fmaf(v, wt[t].w, acc.w);
+                }
+                acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+                acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+                amx_st4(y + (size_t)(p + (long)u * PL) * Cs + cg * 4, acc);
+                sh_push(st, acc);
+            }
         }
     }
     if (!stats) return;
@@ -201,25 +206,39 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     if (active)
     {
         PixCursor cur; cur.init(p0 + pl < npix ? p0 + pl : 0, H, W);
-        for (long p = p0 + pl; p < p1; p += PL, cur.advance(PL, H, W)) {
-            const int xx = cur.xx, yy = cur.yy;
-            const float* img = x + (size_t)cur.nimg * H * W;
-            float4 g = amx_ld4(dpre + (size_t)p * Cs + cg * 4);
-            if (aux) {
-                const float4 t = amx_ld4(aux + (size_t)p * Cs + cg * 4);
-                g.x = (t.x > 0.f ? 1.f : bslope) * fmaf(c1.x, g.x, fmaf(c2.x, t.x, c3.x));
-                g.y = (t.y > 0.f ? 1.f : bslope) * fmaf(c1.y, g.y, fmaf(c2.y, t.y, c3.y));
-                g.z = (t.z > 0.f ? 1.f : bslope) * fmaf(c1.z, g.z, fmaf(c2.z, t.z, c3.z));
-                g.w = (t.w > 0.f ? 1.f : bslope) * fmaf(c1.w, g.w, fmaf(c2.w, t.w, c3.w));
-            }
-            acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
-            float xv[9];
-            load_3x3<false>(img, yy, xx, H, W, dil, xv);    // (the interior branch measured 6 % slower here: 199 vs 187 us)
+        constexpr int U = AMX_CONV1_UNROLL;
+        for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+            float xv[U][9];
+            float4 gq[U], tq[U];
+            bool ok[U];
             #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float v = xv[t];
-                acc[t].x = fmaf(v, g.x, acc[t].x); acc[t].y = fmaf(v, g.y, acc[t].y);
-                acc[t].z = fmaf(v, g.z, acc[t].z); acc[t].w = fmaf(v, g.w, acc[t].w);
+            for (int u = 0; u < U; ++u) {                    // all loads of U pixels first
+                ok[u] = p + (long)u * PL < p1;
+                const long pu = ok[u] ? p + (long)u * PL : p;
+                gq[u] = amx_ld4(dpre + (size_t)pu * Cs + cg * 4);
+                tq[u] = aux ? amx_ld4(aux + (size_t)pu * Cs + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long ni = ok[u] ? cur.nimg : 0;
+                load_3x3<false>(x + (size_t)ni * H * W, ok[u] ? cur.yy : 0, ok[u] ? cur.xx : 0, H, W, dil, xv[u]);
+                if (ok[u]) cur.advance(PL, H, W);
+            }
+            #pragma unroll
+            for (int u = 0; u < U; ++u) {                    // accumulation in pixel order (as with one pixel at a time)
+                if (!ok[u]) continue;
+                float4 g = gq[u];
+                if (aux) {
+                    const float4 t = tq[u];
+                    g.x = (t.x > 0.f ? 1.f : bslope) * fmaf(c1.x, g.x, fmaf(c2.x, t.x, c3.x));
+                    g.y = (t.y > 0.f ? 1.f : bslope) * fmaf(c1.y, g.y, fmaf(c2.y, t.y, c3.y));
+                    g.z = (t.z > 0.f ? 1.f : bslope) * fmaf(c1.z, g.z, fmaf(c2.z, t.z, c3.z));
+                    g.w = (t.w > 0.f ? 1.f : bslope) * fmaf(c1.w, g.w, fmaf(c2.w, t.w, c3.w));
+                }
+                acc[9].x += g.x; acc[9].y += g.y; acc[9].z += g.z; acc[9].w += g.w;
+                #pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float v = xv[u][t];
+                    acc[t].x = fmaf(v, g.x, acc[t].x); acc[t].y = fmaf(v, g.y, acc[t].y);
+                    acc[t].z = fmaf(v, g.z, acc[t].z); acc[t].w = fmaf(v, g.w, acc[t].w);
+                }
             }
         }
     }

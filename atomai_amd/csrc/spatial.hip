@@ -166,43 +166,44 @@ __device__ __forceinline__ void up_taps(int o, int n, int mode, int& i0, int& i1
     else { i0 = i > 0 ? i - 1 : 0; i1 = i; w0 = 0.25f; w1 = 0.75f; }
 }
 
-__global__ void upsample_fwd_kernel(const float* __restrict__ v, float* __restrict__ u, int N, int h,
-                                    int w, int G, int mode) {
+// One workgroup = 256 (x, channel group) slots of ONE output image row (blockIdx.x = n * H + y, blockIdx.y = slot chunk):
+// the only integer divisions are two 32-bit ones per thread (the flat 1-D mapping of round 1 ran three 64-bit div / mod
+// chains per 16-byte store — more instructions than the interpolation itself; 3.8 TB/s).
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ v, float* __restrict__ u, int N,
+                                                           int h, int w, int G, int mode) {
     const int H = 2 * h, W = 2 * w;
-    const size_t total = (size_t)N * H * W * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % G);
-        size_t r = i / G;
-        const int x = (int)(r % W); r /= W;
-        const int y = (int)(r % H); const int n = (int)(r / H);
-        int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-        up_taps(y, h, mode, y0, y1, wy0, wy1);
-        up_taps(x, w, mode, x0, x1, wx0, wx1);
-        const float* base = v + (size_t)n * h * w * G * 4 + cg * 4;
-        const float4 a00 = amx_ld4(base + ((size_t)y0 * w + x0) * G * 4);
-        float4 o;
-        if (mode == 1) { o = a00; }
-        else {
-            const float4 a01 = amx_ld4(base + ((size_t)y0 * w + x1) * G * 4);
-            const float4 a10 = amx_ld4(base + ((size_t)y1 * w + x0) * G * 4);
-            const float4 a11 = amx_ld4(base + ((size_t)y1 * w + x1) * G * 4);
-            // same association order as ATen's upsample_bilinear2d: rows first, then columns
-            o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
-            o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
-            o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
-            o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
-        }
-        amx_st4(u + i * 4, o);
+    const unsigned slot = blockIdx.y * 256u + threadIdx.x;       // x * G + cg within the row
+    if (slot >= (unsigned)(W * G)) return;
+    const int x = (int)(slot / (unsigned)G), cg = (int)(slot - (unsigned)x * G);
+    const int n = (int)(blockIdx.x / (unsigned)H), y = (int)(blockIdx.x - (unsigned)n * H);
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    up_taps(y, h, mode, y0, y1, wy0, wy1);
+    up_taps(x, w, mode, x0, x1, wx0, wx1);
+    const float* base = v + (size_t)n * h * w * G * 4 + cg * 4;
+    const float4 a00 = amx_ld4(base + ((size_t)y0 * w + x0) * G * 4);
+    float4 o;
+    if (mode == 1) { o = a00; }
+    else {
+        const float4 a01 = amx_ld4(base + ((size_t)y0 * w + x1) * G * 4);
+        const float4 a10 = amx_ld4(base + ((size_t)y1 * w + x0) * G * 4);
+        const float4 a11 = amx_ld4(base + ((size_t)y1 * w + x1) * G * 4);
+        // same association order as ATen's upsample_bilinear2d: rows first, then columns
+        o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+        o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+        o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+        o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
     }
+    amx_st4(u + ((size_t)blockIdx.x * W * G + slot) * 4, o);
 }
 
 extern "C" int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode,
                                   void* stream) {
     if (!v || !u || (Cs & 3) || Cs <= 0 || h <= 0 || w <= 0 || (mode != 0 && mode != 1)) AMX_BADARG(1);
-    const size_t total = (size_t)N * 4 * h * w * (Cs / 4);
-    AMX_LAUNCH(upsample_fwd_kernel, GRID_FOR(total), dim3(256), 0, (hipStream_t)stream, v, u, N, h, w,
-               Cs / 4, mode);
+    const int G = Cs / 4;
+    if ((long)N * 2 * h >= 2147483647L || (long)2 * w * G >= 2147483647L) AMX_BADARG(2);
+    if (amx_ceil_div(2 * w * G, 256) > 65535) AMX_BADARG(3);
+    AMX_LAUNCH(upsample_fwd_kernel, dim3((unsigned)(N * 2 * h), amx_ceil_div(2 * w * G, 256)), dim3(256), 0,
+               (hipStream_t)stream, v, u, N, h, w, G, mode);
     AMX_CHECK_LAUNCH();
     return 0;
 }
