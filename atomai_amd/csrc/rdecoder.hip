@@ -49,7 +49,8 @@ struct RDecArgs {
     float* pbc;            // [B][HID]
     float* pWz;            // [B][HID][L]
     int B, n, L, NL, skip;
-    float* hsave;          // forward: [B][NL][HID/4][npad][4] post-activation hidden images to keep for backward, or nullptr
+    float* hsave;          // forward: [B][planes][HID/4][npad][4] activation images to keep for backward (planes = h0 [RD_SAVE_H0],
+                           // h_1 .. h_NL), or nullptr
     const float* hsaved;   // backward: the same buffer (then the hidden layers are NOT recomputed), or nullptr
     int npad;              // pixels per plane of hsave (n rounded up to a multiple of 128)
     unsigned long long* prof;   // AMX_RDEC_PROFILE builds: per-wave phase clocks [workgroup][wave][8], or nullptr
@@ -68,6 +69,13 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
 #ifndef RD_PLANE_PAD
 #define RD_PLANE_PAD 4        // compile-time experiment switch: 0 = the unpadded round-1 layout
 #endif
+#ifndef RD_SAVE_H0
+#define RD_SAVE_H0 0          // experiment switch: 1 = the saved-activation mode also keeps h0 (the coordinate layer's output) so
+                              // that the backward skips its 16 tanh + 32 FMA per lane and tile.  Measured SLOWER in the step
+                              // (5.553 -> 5.620 ms, profiles/r03_rvae_h0_ab.log): 16 more prefetch registers (spill 120 ->
+                              // 184 B in the <128, 64, 2> class) and 1.07 GB more HBM traffic each way.
+#endif
+#define RD_PLANES(NL_) ((NL_) + (RD_SAVE_H0 ? 1 : 0))
 #define MAXL 8
 #define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
 
@@ -107,7 +115,8 @@ struct Geo {
 // h0 tile -> dst (KG layout).  Also stores x',y' per pixel when s_xy != nullptr.
 template <int HID, int MT>
 __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix0, const float* s_zc,
-                                            float* dst, float* s_xy, const float* s_th, int tid) {
+                                            float* dst, float* s_xy, const float* s_th, int tid,
+                                            float* gsave = nullptr) {
     using G = Geo<HID, MT>;
     #pragma unroll
     for (int i = 0; i < G::SPT; ++i) {
@@ -134,6 +143,27 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
             if (!a.skip) { h.x = rd_tanh(h.x); h.y = rd_tanh(h.y); h.z = rd_tanh(h.z); h.w = rd_tanh(h.w); }
         }
         amx_st4(dst + ((size_t)kg * G::PS + p) * 4, h);
+        if (gsave) amx_st4(gsave + ((size_t)kg * a.npad + p) * 4, h);
+    }
+}
+
+// (x', y') of the tile's pixels only (saved mode of the backward kernel: h0 itself comes from HBM)
+template <int MT>
+__device__ __forceinline__ void coord_xy(const RDecArgs& a, int bidx, int pix0, float* s_xy, const float* s_th, int tid) {
+    if (tid < MT) {
+        const int q = pix0 + tid;
+        float xx = 0.f, yy = 0.f;
+        if (q < a.n) {
+            if (s_th) {
+                const float gx = a.coords[(size_t)q * 2 + 0], gy = a.coords[(size_t)q * 2 + 1];
+                xx = gx * s_th[0] - gy * s_th[1] + s_th[2];
+                yy = gx * s_th[1] + gy * s_th[0] + s_th[3];
+            } else {
+                xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
+                yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+            }
+        }
+        s_xy[2 * tid] = xx; s_xy[2 * tid + 1] = yy;
     }
 }
 
@@ -244,14 +274,15 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     const float* th = a.theta ? s_th : nullptr;
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         float* h0 = a.skip ? buf2 : buf0;
-        coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid);
+        coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid,
+                             (RD_SAVE_H0 && a.hsave) ? a.hsave + ((size_t)bidx * RD_PLANES(a.NL) * G::KG * a.npad + pix0) * 4 : nullptr);
         __syncthreads();
         const float* src = h0;
         for (int l = 0; l < a.NL; ++l) {
             float* dst = (src == buf0) ? buf1 : buf0;
             hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, src, dst,
                                   a.skip ? h0 : nullptr, wave, lane,
-                                  a.hsave ? a.hsave + (((size_t)bidx * a.NL + l) * G::KG * a.npad + pix0) * 4 : nullptr,
+                                  a.hsave ? a.hsave + (((size_t)bidx * RD_PLANES(a.NL) + l + (RD_SAVE_H0 ? 1 : 0)) * G::KG * a.npad + pix0) * 4 : nullptr,
                                   a.npad);
             __syncthreads();
             src = dst;
@@ -312,12 +343,14 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     // Saved-activation mode (a.hsaved): the forward kernel kept h_1..h_NL in HBM; a tile's images are fetched into
     // registers ahead of use (SPT float4 per layer and thread, 1 KB contiguous per wave and plane) and dropped into LDS
     // where the recompute would have written them — no forward MFMAs, no tanh epilogues in this kernel.
-    float4 pre[SAVED ? NL : 1][G::SPT];
-    const float* hs = SAVED ? a.hsaved + (size_t)bidx * NL * G::KG * a.npad * 4 : nullptr;
+    constexpr int NPL = SAVED ? RD_PLANES(NL) : 1;               // planes fetched per tile
+    constexpr int P0 = RD_SAVE_H0 ? 0 : 1;                       // H[] image the first plane belongs to
+    float4 pre[NPL][G::SPT];
+    const float* hs = SAVED ? a.hsaved + (size_t)bidx * RD_PLANES(NL) * G::KG * a.npad * 4 : nullptr;
     auto fetch = [&](int pix0) {
         if (!SAVED) return;
         #pragma unroll
-        for (int l = 0; l < (SAVED ? NL : 1); ++l)
+        for (int l = 0; l < NPL; ++l)
             #pragma unroll
             for (int i = 0; i < G::SPT; ++i) {
                 const int s = tid + i * G::NT;
@@ -328,15 +361,16 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     if (SAVED) fetch(0);
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
-        coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
+        if (SAVED && RD_SAVE_H0) coord_xy<MT>(a, bidx, pix0, s_xy, th, tid);
+        else coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
         if (SAVED) {
             #pragma unroll
-            for (int l = 0; l < (SAVED ? NL : 1); ++l)
+            for (int l = 0; l < NPL; ++l)
                 #pragma unroll
                 for (int i = 0; i < G::SPT; ++i) {
                     const int s = tid + i * G::NT;
                     const int kg = s / MT, pp = s - kg * MT;
-                    amx_st4(H[l + 1] + ((size_t)kg * G::PS + pp) * 4, pre[l][i]);
+                    amx_st4(H[l + P0] + ((size_t)kg * G::PS + pp) * 4, pre[l][i]);
                 }
             __syncthreads();
             RD_TICK(0);
@@ -652,7 +686,7 @@ static int check_common(const RDecArgs& a, int hid) {
 extern "C" long amx_rdecoder_hsave_floats(int B, int n, int hid, int NL) {
     if (B <= 0 || n <= 0 || NL < 1 || (hid != 32 && hid != 64 && hid != 128)) return -1;
     const long npad = ((long)n + 127) / 128 * 128;
-    return (long)B * NL * hid * npad;
+    return (long)B * RD_PLANES(NL) * hid * npad;
 }
 
 extern "C" int amx_rdecoder_fwd_save(const float* coords, const float* theta, const float* z, const float* Wc,

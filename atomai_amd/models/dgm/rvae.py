@@ -9,6 +9,38 @@ from ...utils import set_train_rng, to_onehot
 from .vae import BaseVAE
 
 
+class _LatentFn(torch.autograd.Function):
+    """(z_mean, z_logsd, eps) -> (theta (B, 3), content latents): reparameterisation, the (phi, dx, dy) split, the
+    translation prior and the concatenation of rvae.py:118-137 in one kernel each way (csrc/elbo.hip)."""
+
+    @staticmethod
+    def forward(ctx, z_mean, z_logsd, eps, translation: bool, dx_prior: float):
+        from ... import _lib as L
+        zm, zl, ep = z_mean.detach().contiguous(), z_logsd.detach().contiguous(), eps.detach().contiguous()
+        B, Z = zm.shape
+        skip = 3 if translation else 1
+        theta = torch.empty(B, 3, dtype=torch.float32, device=zm.device)
+        zc = torch.empty(B, Z - skip, dtype=torch.float32, device=zm.device)
+        L.call("amx_rvae_latent_fwd", L.ptr(zm), L.ptr(zl), L.ptr(ep), B, Z, int(translation), float(dx_prior),
+               L.ptr(theta), L.ptr(zc) if Z > skip else None, L.stream_ptr(zm))
+        ctx.save_for_backward(zl, ep)
+        ctx.meta = (translation, float(dx_prior))
+        return theta, zc
+
+    @staticmethod
+    def backward(ctx, dtheta, dzc):
+        from ... import _lib as L
+        zl, ep = ctx.saved_tensors
+        translation, dx_prior = ctx.meta
+        B, Z = zl.shape
+        dm, dl = torch.empty_like(zl), torch.empty_like(zl)
+        dt = None if dtheta is None else dtheta.contiguous()
+        dc = None if (dzc is None or dzc.numel() == 0) else dzc.contiguous()
+        L.call("amx_rvae_latent_bwd", L.ptr(zl), L.ptr(ep), L.ptr(dt), L.ptr(dc), B, Z, int(translation), dx_prior,
+               L.ptr(dm), L.ptr(dl), L.stream_ptr(zl))
+        return dm, dl, None, None, None
+
+
 class rVAE(BaseVAE):
     """``rVAE(in_dim, latent_dim=2, translation=True, seed=0, **kwargs)`` with the spatial decoder on the fused
     HIP kernels.  z = (angle, [dx, dy], content...)."""
@@ -28,6 +60,12 @@ class rVAE(BaseVAE):
     def elbo_fn(self, x, x_reconstr, *args, **kwargs) -> torch.Tensor:
         return rvae_loss(self.loss, self.in_dim, x, x_reconstr, *args, **kwargs)
 
+    def _default_reparameterize(self) -> bool:
+        """True unless ``reparameterize`` was overridden (subclass or instance attribute, as tests do to inject eps)."""
+        from ...trainers import viBaseTrainer
+        return ("reparameterize" not in self.__dict__
+                and getattr(type(self).reparameterize, "__func__", None) is viBaseTrainer.reparameterize.__func__)
+
     def forward_compute_elbo(self, x: torch.Tensor, y: Optional[torch.Tensor] = None,
                              mode: str = "train") -> torch.Tensor:
         """Same dataflow as rvae.py:110-147: encoder -> reparameterise -> split (phi, dx, z) [-> append the one-hot
@@ -36,6 +74,13 @@ class rVAE(BaseVAE):
             z_mean, z_logsd = self.encoder_net(x)
             if mode != "eval":
                 self.kdict_["num_iter"] += 1
+            if y is None and self._default_reparameterize() and z_mean.dtype == torch.float32:
+                # the same draw as reparameterize() (one normal_() on the compute device), then ONE kernel for
+                # z = mean + sd * eps, the (phi, dx, dy) / content split and the translation prior
+                eps = z_mean.new(z_mean.size(0), z_mean.size(1)).normal_()
+                theta, z = _LatentFn.apply(z_mean, z_logsd, eps, bool(self.translation), float(self.dx_prior or 0.0))
+                x_reconstr = self.decoder_net.forward_grid(self.x_coord, theta, z)
+                return self.elbo_fn(x, x_reconstr, z_mean, z_logsd, **self.kdict_)
             z = self.reparameterize(z_mean, torch.exp(z_logsd))
             phi = z[:, :1]
             if self.translation:

@@ -306,6 +306,20 @@ int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, co
 int amx_elbo_terms_bwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
                        const float* g_recon, const float* g_klz, const float* g_klrot, int B, int n, int Z,
                        int rot, float phi_prior, float* dxrec, float* dmean, float* dlogsd, void* stream);
+/* Scalar ELBO without a capacity term (vi_losses.py:105-108, 129-137): out[0] = -mean(recon) - mean(klz) - mean(klrot)
+ * (klrot may be NULL), fixed-order fp64 sum; amx_elbo_bwd_scalar = amx_elbo_terms_bwd with all three per-sample upstream
+ * gradients equal to coef * gscalar[0] (gscalar: the device scalar autograd hands to the loss; coef = -1 / B). */
+int amx_elbo_combine(const float* recon, const float* klz, const float* klrot, int B, float* out, void* stream);
+int amx_elbo_bwd_scalar(const float* x, const float* xrec, const float* zmean, const float* zlogsd, const float* gscalar,
+                        float coef, int B, int n, int Z, int rot, float phi_prior, float* dxrec, float* dmean,
+                        float* dlogsd, void* stream);
+/* rVAE latent plumbing (models/dgm/rvae.py:118-137) in one pass each way: z = mean + exp(logsd) * eps; theta [B][3] =
+ * (z0, z1 * dx_prior, z2 * dx_prior) (translation) or (z0, 0, 0); zc [B][Z - 3 | Z - 1] = the content latents. */
+int amx_rvae_latent_fwd(const float* zmean, const float* zlogsd, const float* eps, int B, int Z, int translation,
+                        float dx_prior, float* theta, float* zc, void* stream);
+int amx_rvae_latent_bwd(const float* zlogsd, const float* eps, const float* dtheta, const float* dzc, int B, int Z,
+                        int translation, float dx_prior, float* dmean, float* dlogsd, void* stream);
+
 
 /* ---- DKL covariance evaluation: ScaleKernel(RBFKernel(ard)) / MaternKernel(2.5) on the embeddings
  * (selected at atomai/nets/gp.py:41-46,95-106; arithmetic in gpytorch).  kind 0 = RBF, 1 = Matern-5/2;

@@ -169,3 +169,32 @@ def check_rdecoder_saved_equals_recompute(device, hid, nl, skip, hw, B=3):
         ed.RDEC_SAVE[0] = prev
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def check_rvae_fused_latent_path(device):
+    """rVAE.forward_compute_elbo with the default reparameterize takes the fused path (one kernel for z = mean + sd * eps,
+    the (phi, dx, dy) / content split and the translation prior; scalar ELBO in one combine): same ELBO and gradients as
+    the step-by-step torch path fed with the same eps, with and without translation."""
+    import atomai_amd as aoi
+    for translation in (True, False):
+        m = aoi.models.rVAE((16, 16), latent_dim=2, seed=0, translation=translation, numhidden_encoder=32,
+                            numhidden_decoder=32)
+        m.dx_prior, m.kdict_["phi_prior"] = 0.1, 0.1
+        assert m._default_reparameterize()
+        x = torch.rand(6, 16, 16).to(device)
+        params = list(m.encoder_net.parameters()) + list(m.decoder_net.parameters())
+        res = []
+        for fused in (True, False):
+            torch.manual_seed(3)
+            for p in params:
+                p.grad = None
+            if not fused:                                        # an instance-level override selects the torch path
+                m.reparameterize = lambda zm, zs: zm + zs * zm.new(zm.size(0), zm.size(1)).normal_()
+                assert not m._default_reparameterize()
+            m.encoder_net.train(), m.decoder_net.train()
+            elbo = m.forward_compute_elbo(x)
+            (-elbo).backward()
+            res.append((elbo.item(), [p.grad.detach().cpu().clone() for p in params]))
+        assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[1][0])
+        for a, b in zip(res[0][1], res[1][1]):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max()))

@@ -82,3 +82,7 @@ def test_subimage_utilities_and_encode_images(golden_dir):
 @pytest.mark.parametrize("hid,nl,skip,hw", [(32, 2, 0, (9, 7)), (64, 3, 1, (12, 11, 2))])
 def test_rdecoder_saved_activations_equal_recompute(hid, nl, skip, hw):
     V.check_rdecoder_saved_equals_recompute("cpu", hid, nl, skip, hw)
+
+
+def test_rvae_fused_latent_and_scalar_elbo_path():
+    V.check_rvae_fused_latent_path("cpu")

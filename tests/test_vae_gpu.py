@@ -66,3 +66,7 @@ def test_rvae_fit_loss_improves_and_is_deterministic(tmp_path):
 @pytest.mark.parametrize("hid,nl,skip,hw", [(128, 2, 0, (64, 64)), (128, 3, 1, (24, 24)), (100, 5, 0, (33, 31, 3)), (64, 1, 0, (7, 5))])
 def test_rdecoder_saved_activations_equal_recompute(hid, nl, skip, hw):
     V.check_rdecoder_saved_equals_recompute("cuda", hid, nl, skip, hw)
+
+
+def test_rvae_fused_latent_and_scalar_elbo_path():
+    V.check_rvae_fused_latent_path("cuda")
