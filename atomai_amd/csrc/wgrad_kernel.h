@@ -52,6 +52,10 @@ extern void* amx_wgrad_profile_buffer;
 template <int TAPS, int NT, int WM, int MAXHALO, int TH, int LAT = 0>
 // Forcing two waves per SIMD for the wide variant (191 + 72 registers -> 256 with 6 spills) was measured in-step with
 // tools/gpu_lib_ab.py: 20.82 ms (256 workgroups) / 20.50 ms (384) against 20.34 ms for one wave per SIMD -> rejected.
+// Re-measured in round 3 with every 4-row class bounded to 256 registers (so that two 128-register convolution waves of
+// the main stream could share a SIMD with a weight-gradient wave instead of one): 18.51 -> 19.03 ms per step
+// (profiles/r03_wgrad_regs_ab.log) — the convolution waves then take MFMA issue slots from the weight-gradient stream,
+// whose kernels already span the whole backward pass (11.7 ms in-step for 5.9 ms stand-alone).
 #ifndef AMX_WGRAD_WAVES
 #define AMX_WGRAD_WAVES 1
 #endif
