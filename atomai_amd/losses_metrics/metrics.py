@@ -39,12 +39,14 @@ class IoU:
                L.stream_ptr(x))
 
     def evaluate(self) -> float:
-        per_frame = self.hist.cpu().float()                   # the only host transfer: N*K*K integers
-        hist = torch.zeros((self.nb_classes, self.nb_classes))
-        for h in per_frame:                                   # metrics.py:86-87: hist += compute_hist(frame)
-            hist += h
-        A_inter_B = torch.diag(hist)
-        A = torch.sum(hist, dim=1)
-        B = torch.sum(hist, dim=0)
-        jcd = A_inter_B / (A + B - A_inter_B + 1e-10)
-        return torch.mean(jcd[jcd == jcd]).item()
+        """Mean Jaccard index over the classes (metrics.py:80-95), in float32 like the reference: the per-frame count
+        matrices are added frame by frame, then inter / (row + col - inter + 1e-10) per class."""
+        import numpy as np
+        counts = self.hist.cpu().numpy().astype(np.float32)          # the only host transfer: N * K * K integers
+        total = np.zeros((self.nb_classes, self.nb_classes), dtype=np.float32)
+        for frame in counts:
+            total += frame
+        inter = np.diagonal(total)
+        union = total.sum(axis=1, dtype=np.float32) + total.sum(axis=0, dtype=np.float32) - inter + np.float32(1e-10)
+        jcd = inter / union
+        return float(jcd[~np.isnan(jcd)].mean(dtype=np.float32))
