@@ -76,7 +76,7 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
                               // 184 B in the <128, 64, 2> class) and 1.07 GB more HBM traffic each way.
 #endif
 #define RD_PLANES(NL_) ((NL_) + (RD_SAVE_H0 ? 1 : 0))
-#define MAXL 8
+#define MAXL 32           // latent dimensions (content latents + one-hot classes) the kernels keep in LDS
 #define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
 
 // tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware exp / reciprocal units: 5 VALU instructions instead of the ~35 of

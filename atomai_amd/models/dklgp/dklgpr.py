@@ -16,8 +16,19 @@ class dklGPR(dklGPTrainer):
     def fit(self, X, y, training_cycles: int = 1, **kwargs) -> None:
         _ = self.run(X, y, training_cycles, **kwargs)
 
-    def fit_ensemble(self, *args, **kwargs):
-        raise NotImplementedError("ensembles of DKL models are outside this build's scope")
+    def fit_ensemble(self, X, y, training_cycles: int = 1, n_models: int = 5, **kwargs) -> None:
+        """Trains ``n_models`` independently initialised DKL-GP models on the same scalar target (dklgpr.py:95-131)."""
+        import warnings
+        if y.ndim == 1:
+            y = y[None]
+        if y.shape[0] > 1:
+            raise NotImplementedError("The ensemble training is currently supported only for scalar targets")
+        y = y.repeat(n_models, 0) if isinstance(y, np.ndarray) else y.repeat(n_models, 1)
+        if self.correlated_output:
+            warnings.warn("Replacing a single shared embedding space with {} independent ones".format(n_models))
+            self.correlated_output = False
+        self.ensemble = True
+        _ = self.run(X, y, training_cycles, **kwargs)
 
     def _compute_posterior(self, X: torch.Tensor, full_cov: bool = False):
         self.gp_model.eval()
@@ -26,8 +37,17 @@ class dklGPR(dklGPTrainer):
     def _draw(self, X, num_samples):
         mean, cov = self._compute_posterior(X, full_cov=True)
         n = cov.shape[-1]
-        jitter = 1e-6 * cov.diagonal(dim1=-2, dim2=-1).mean(-1).clamp_min(1e-12)
-        Lc = torch.linalg.cholesky(cov + jitter[:, None, None] * torch.eye(n, dtype=cov.dtype, device=cov.device))
+        cov = 0.5 * (cov + cov.transpose(-1, -2))
+        eye = torch.eye(n, dtype=cov.dtype, device=cov.device)
+        base = cov.diagonal(dim1=-2, dim2=-1).mean(-1).clamp_min(1e-12)
+        Lc, scale = None, 1e-6 if cov.dtype == torch.float32 else 1e-8
+        for _ in range(7):                    # growing diagonal jitter, as gpytorch's psd_safe_cholesky does
+            Lc, info = torch.linalg.cholesky_ex(cov + (scale * base)[:, None, None] * eye)
+            if int(info.abs().max()) == 0:
+                break
+            scale *= 10
+        else:
+            raise RuntimeError("posterior covariance is not positive definite even with a 1e0 relative jitter")
         eps = torch.randn(num_samples, cov.shape[0], n, 1, dtype=cov.dtype, device=cov.device)
         return mean[None] + (Lc[None] @ eps).squeeze(-1)
 

@@ -195,6 +195,7 @@ class _RDecoderFn(torch.autograd.Function):
         return (None, dcoords, dtheta, dz) + tuple(grads)
 
 
+_RDEC_MAX_LATENT = 32          # MAXL of csrc/rdecoder.hip (content latents + one-hot classes)
 _RDEC_MAX_LAYERS = 5
 _RDEC_MAX_CHANNELS = 4
 
@@ -228,7 +229,8 @@ class rDecoderNet(nn.Module):
 
     def _fused(self) -> bool:
         return (1 <= self.channels <= _RDEC_MAX_CHANNELS and self.hidden_dim <= _RDEC_WIDTHS[-1]
-                and 1 <= self.num_layers <= _RDEC_MAX_LAYERS)
+                and 1 <= self.num_layers <= _RDEC_MAX_LAYERS
+                and 1 <= self.coord_latent.fc_latent.in_features <= _RDEC_MAX_LATENT)
 
     def _forward_layered(self, x_coord: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         """The reference's forward (ed.py:626-642, 672-687) layer by layer: every Linear (+ Tanh) is one launch of the

@@ -241,3 +241,37 @@ class GPRegressionModel(nn.Module):
             else:
                 vars_.append((s2 - (Ks * v).sum(0)).clamp_min(0))
         return torch.stack(means), torch.stack(vars_)
+
+
+class GPModelList(nn.Module):
+    """q INDEPENDENT DKL GPs, one per output row of ``y``, each with its own feature extractor (the reference's
+    ``gpytorch.models.IndependentModelList`` of ``GPRegressionModel``s: trainers/gptrainer.py:181-243).  ``models[i]``
+    is a single-output ``GPRegressionModel``; the training objective is the sum of their marginal log likelihoods
+    (``SumMarginalLogLikelihood``)."""
+
+    def __init__(self, models) -> None:
+        super().__init__()
+        self.models = nn.ModuleList(models)
+
+    @property
+    def train_targets(self):
+        return [m.train_targets for m in self.models]
+
+    @property
+    def train_inputs(self):
+        return [m.train_inputs for m in self.models]
+
+    def mll(self) -> torch.Tensor:
+        tot = 0
+        for m in self.models:
+            tot = tot + m.mll()
+        return tot
+
+    def posterior(self, x_new: torch.Tensor, full_cov: bool = False):
+        """Stacked latent posterior of the q models at the SAME points: mean (q, n), variance (q, n) [or (q, n, n)]."""
+        outs = [m.posterior(x_new, full_cov) for m in self.models]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+
+    def embed(self, x: torch.Tensor) -> torch.Tensor:
+        """(q, n, embedim): every model's own embedding of x."""
+        return torch.stack([m.embed(x) for m in self.models])

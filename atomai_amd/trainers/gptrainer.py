@@ -1,12 +1,14 @@
-"""dklGPTrainer: deep-kernel-learning GP training loop (reference: atomai/trainers/gptrainer.py:144-349).
-Shared-embedding path (``compile_trainer``); the per-output independent-network variant
-(``compile_multi_model_trainer``) is out of this build's scope."""
+"""dklGPTrainer: deep-kernel-learning GP training loop (reference: atomai/trainers/gptrainer.py:144-349): the
+shared-embedding path (``compile_trainer``) and the independent per-output networks / ensembles
+(``compile_multi_model_trainer``)."""
 from typing import Tuple
 
 import numpy as np
 import torch
 
-from ..nets.gp import GPRegressionModel, fcFeatureExtractor
+import copy
+
+from ..nets.gp import GPModelList, GPRegressionModel, fcFeatureExtractor
 
 
 class dklGPTrainer:
@@ -57,8 +59,43 @@ class dklGPTrainer:
             torch.set_default_dtype(prev)
         return net.to(self.dtype).to(self.device)
 
-    def compile_multi_model_trainer(self, *args, **kwargs):
-        raise NotImplementedError("independent per-output networks / ensembles are outside this build's scope")
+    def compile_multi_model_trainer(self, X, y, training_cycles: int = 1, **kwargs) -> None:
+        """One feature extractor + one GP PER OUTPUT (gptrainer.py:181-243): for vector-valued targets with independent
+        latent spaces every model starts from a copy of the same initial network; in ensemble mode (``self.ensemble``,
+        set by ``dklGPR.fit_ensemble``) every member draws its own initialisation.  Adam(lr=0.01) over all parameters,
+        loss = - sum of the members' marginal log likelihoods."""
+        if self.correlated_output:
+            raise NotImplementedError("To compile a DKL-GP trainer for correlated outputs "
+                                      "use compile_trainer(*args, **kwargs)")
+        X, y = self.set_data(X, y)
+        if y.shape[0] < 2:
+            raise ValueError("The training targets must be vector-valued (d >1)")
+        input_dim, embedim = self.dimdict["input_dim"], self.dimdict["embedim"]
+        feature_net = kwargs.get("feature_extractor", fcFeatureExtractor)
+        freeze = kwargs.get("freeze_weights", False)
+
+        def new_extractor():
+            fx = self._build_extractor(feature_net, input_dim, embedim)
+            if freeze:
+                for p in fx.parameters():
+                    p.requires_grad = False
+            return fx
+        shared_init = None if self.ensemble else new_extractor()
+        models = []
+        for i in range(y.shape[0]):
+            fx = new_extractor() if self.ensemble else copy.deepcopy(shared_init)
+            models.append(GPRegressionModel(X, y[i:i + 1], fx, embedim, kwargs.get("base_kernel", "rbf")))
+        self.gp_model = GPModelList(models).to(self.device)
+        self.likelihood = self.gp_model
+        self.gp_model.train()
+        params = []
+        for m in self.gp_model.models:
+            params += [m.raw_lengthscale, m.raw_outputscale, m.mean_constant, m.raw_noise]
+            if not freeze:
+                params += list(m.feature_extractor.parameters())
+        self.optimizer = torch.optim.Adam(params, lr=0.01)
+        self.training_cycles = training_cycles
+        self.compiled = True
 
     def compile_trainer(self, X, y, training_cycles: int = 1, **kwargs) -> None:
         """feature extractor NN + base kernel + Adam(lr=0.01) over kernel, mean, noise (+ NN) parameters."""
@@ -95,7 +132,10 @@ class dklGPTrainer:
 
     def run(self, X=None, y=None, training_cycles: int = 1, **kwargs):
         if not self.compiled:
-            self.compile_trainer(X, y, training_cycles, **kwargs)
+            if self.correlated_output:
+                self.compile_trainer(X, y, training_cycles, **kwargs)
+            else:
+                self.compile_multi_model_trainer(X, y, training_cycles, **kwargs)
         for e in range(self.training_cycles):
             self.train_step()
             if e == 0 or (e + 1) % kwargs.get("print_loss", 10) == 0 or e == self.training_cycles - 1:
