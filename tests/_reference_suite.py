@@ -35,7 +35,7 @@ def loss_selection():
     assert str(_trainer(binary=False).criterion) == "CrossEntropyLoss()"
 
 
-def segtrainer_determinism(model_type, tmp, **kw):
+def segtrainer_determinism(model_type, tmp, cycles=5, **kw):
     """(``kw``: the emulator tier trains narrow nets — nb_filters=4 — the gpu tier the reference's default widths)"""
     out = []
     for _ in range(2):
@@ -43,7 +43,7 @@ def segtrainer_determinism(model_type, tmp, **kw):
         X, Xt = _images()
         y, yt = _labels(True)
         t = SegTrainer(model_type, upsampling="nearest", seed=1, **kw)
-        t.compile_trainer((X, y, Xt, yt), training_cycles=5, batch_size=4, plot_training_history=False,
+        t.compile_trainer((X, y, Xt, yt), training_cycles=cycles, batch_size=4, plot_training_history=False,
                           filename=str(tmp / "m"))
         t.run()
         out.append((t.loss_acc["train_loss"][-1], [p.detach().cpu().numpy().copy() for p in t.net.parameters()]))
@@ -306,3 +306,139 @@ def dkl_sampling(reg_dim, shared=True):
     assert isinstance(s, np.ndarray) and s.shape == (100, reg_dim, 50)
     sample, xnext = t.thompson(Xt)
     assert isinstance(sample, np.ndarray) and isinstance(xnext, np.ndarray) and sample.shape == (reg_dim, 50)
+
+
+# ------------------------------------------------------------------ trainers/test_gptrainer.py (dklGPTrainer tests)
+def _state_equal(a, b):
+    return all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+
+
+def dkltrainer_precision(precision, dtype):
+    from atomai_amd.trainers import dklGPTrainer
+    X, y, _ = _dkl_data()
+    X_, y_ = dklGPTrainer(32, precision=precision).set_data(X, y)
+    assert X_.dtype == dtype and y_.dtype == dtype
+
+
+def dkltrainer_compile_train_run(tmp):
+    import copy
+    from atomai_amd.trainers import dklGPTrainer
+    X, y, _ = _dkl_data()
+    t = dklGPTrainer(32, precision="single")
+    t.compile_trainer(X, y, 2)
+    assert t.gp_model is not None and t.likelihood is not None
+    w0 = copy.deepcopy(t.gp_model.feature_extractor.state_dict())
+    t.train_step()
+    assert not _state_equal(w0, t.gp_model.feature_extractor.state_dict())
+    t = dklGPTrainer(32, precision="single")                   # frozen extractor: transfer learning
+    t.compile_trainer(X, y, freeze_weights=True)
+    w0 = copy.deepcopy(t.gp_model.feature_extractor.state_dict())
+    t.train_step()
+    assert _state_equal(w0, t.gp_model.feature_extractor.state_dict())
+    t = dklGPTrainer(32, precision="single")
+    t.compile_trainer(X, y, training_cycles=3)
+    t.run()
+    assert len(t.train_loss) == 3
+    t = dklGPTrainer(32, precision="single")
+    t.run(X, y, 3)
+    assert len(t.train_loss) == 3
+    w1 = copy.deepcopy(t.gp_model.feature_extractor.state_dict())
+    t.save_weights(str(tmp / "m.pt"))
+    t.gp_model.feature_extractor.load_state_dict(torch.load(str(tmp / "m.pt")))
+    assert _state_equal(w1, t.gp_model.feature_extractor.state_dict())
+
+
+def dkltrainer_multi_model():
+    import copy
+    from atomai_amd.trainers import dklGPTrainer
+    X, y, _ = _dkl_data((2, 50))
+    t = dklGPTrainer(32, shared_embedding_space=False, precision="single")
+    t.compile_multi_model_trainer(X, y, 2)
+    assert t.gp_model is not None and t.likelihood is not None
+    w1 = copy.deepcopy(t.gp_model.models[0].feature_extractor.state_dict())
+    w2 = copy.deepcopy(t.gp_model.models[1].feature_extractor.state_dict())
+    assert _state_equal(w1, w2)                              # independent outputs start from the same initial network
+    t.train_step()
+    f1, f2 = t.gp_model.models[0].feature_extractor.state_dict(), t.gp_model.models[1].feature_extractor.state_dict()
+    assert not _state_equal(f1, f2) and not _state_equal(w1, f1) and not _state_equal(w2, f2)
+    t = dklGPTrainer(32, precision="single", shared_embedding_space=False)     # ensemble: own initialisation each
+    t.ensemble = True
+    t.compile_multi_model_trainer(X, np.repeat(y[:1], 3, axis=0))
+    assert not _state_equal(t.gp_model.models[0].state_dict(), t.gp_model.models[2].state_dict())
+    try:
+        dklGPTrainer(32, precision="single").compile_multi_model_trainer(X, y)
+        raise AssertionError("shared embedding space must refuse compile_multi_model_trainer")
+    except NotImplementedError:
+        pass
+
+
+# ------------------------------------------------------------------ models/test_loaders.py
+def _opt_equal(o1, o2):
+    for g1, g2 in zip(o1.param_groups, o2.param_groups):
+        for p1, p2 in zip(g1["params"], g2["params"]):
+            if not np.array_equal(p1.detach().cpu().numpy(), p2.detach().cpu().numpy()):
+                return False
+    return True
+
+
+def io_segmentor(model, tmp, **kw):
+    import atomai_amd as aoi
+    X, Xt = _images()
+    y, yt = _labels(False)
+    seg = aoi.models.Segmentor(model, nb_classes=3, **kw)
+    seg.fit(X, y, Xt, yt, training_cycles=4, batch_size=2, filename=str(tmp / model), plot_training_history=False)
+    loaded = aoi.models.load_model(str(tmp / f"{model}_metadict_final.tar"))
+    for p1, p2 in zip(loaded.net.parameters(), seg.net.parameters()):
+        assert np.array_equal(p1.detach().cpu().numpy(), p2.detach().cpu().numpy())
+    assert _opt_equal(seg.optimizer, loaded.optimizer)
+
+
+def io_vae(kind, tmp):
+    import atomai_amd as aoi
+    X = _images()[0][:, 0].astype(np.float32)
+    cls = aoi.models.VAE if kind == "VAE" else aoi.models.rVAE
+    m = cls((8, 8), numhidden_encoder=16, numhidden_decoder=16)
+    m.fit(X, training_cycles=4, batch_size=2, filename=str(tmp / "vae_metadict"))
+    loaded = aoi.models.load_model(str(tmp / "vae_metadict.tar"))
+    for a, b in ((loaded.encoder_net, m.encoder_net), (loaded.decoder_net, m.decoder_net)):
+        for p1, p2 in zip(a.parameters(), b.parameters()):
+            assert np.array_equal(p1.detach().cpu().numpy(), p2.detach().cpu().numpy())
+    assert _opt_equal(m.optim, loaded.optim)
+    loss0 = abs(m.loss_history["train_loss"][0])             # resume: the loaded model keeps improving
+    loaded.fit(X, training_cycles=4, batch_size=2, filename=str(tmp / "vae_metadict"))
+    loss1 = abs(loaded.loss_history["train_loss"][0])
+    assert not np.isnan(loss1) and loss1 < loss0
+
+
+# ------------------------------------------------------------------ trainers/test_etrainer.py, predictors/test_epredictor.py
+def ensemble_seg(model, binary, full_epoch, tmp, **kw):
+    import atomai_amd as aoi
+    X, Xt = _images()
+    y, yt = _labels(binary)
+    et = aoi.trainers.EnsembleTrainer(model, nb_classes=1 if binary else 3, upsampling="nearest", **kw)
+    et.compile_ensemble_trainer(training_cycles=4, full_epoch=full_epoch, batch_size=2, filename=str(tmp / "model"),
+                                plot_training_history=False)
+    smodel, ensemble = et.train_ensemble_from_scratch(X, y, Xt, yt, n_models=3)
+    for i in ensemble:
+        for j in ensemble:
+            same = all(np.array_equal(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+                       for a, b in zip(ensemble[i].values(), ensemble[j].values()))
+            assert same == (i == j)
+    if not binary and not full_epoch:                         # test_io_ensemble_seg
+        _, loaded = aoi.models.load_ensemble(str(tmp / "model_ensemble_metadict.tar"))
+        for i in ensemble:
+            for a, b in zip(ensemble[i].values(), loaded[i].values()):
+                assert np.array_equal(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+
+
+def epredictor_seg(model, tmp, **kw):
+    import atomai_amd as aoi
+    rs = np.random.RandomState(9)
+    X, Xt = rs.random_sample((5, 1, 32, 32)), rs.random_sample((5, 1, 32, 32))
+    y, yt = rs.randint(0, 3, (5, 32, 32)), rs.randint(0, 3, (5, 32, 32))
+    et = aoi.trainers.EnsembleTrainer(model, batch_norm=False, nb_classes=3, **kw)
+    et.compile_ensemble_trainer(training_cycles=32, batch_size=2, compute_accuracy=False, filename=str(tmp / "model"),
+                                plot_training_history=False)
+    smodel, ensemble = et.train_swag(X, y, Xt, yt, n_models=7)
+    mean, var = aoi.predictors.EnsemblePredictor(smodel, ensemble, nb_classes=3).predict(Xt)
+    assert mean.shape == var.shape == (5, 32, 32, 3)

@@ -193,7 +193,7 @@ def check_dilated_ragged(device, cases=((28, 50, 37, 29, 2), (16, 20, 23, 41, 1)
             np.testing.assert_allclose(a.running_mean.cpu().numpy(), b.running_mean.numpy(), rtol=1e-4, atol=1e-6)
 
 
-def check_head_fusion(device):
+def check_head_fusion(device, wide=True):
     """Eval mode: the final 1x1 convolution (+ sigmoid / softmax) evaluated in the epilogue of the last 3x3 layer must
     agree with the separate head kernel (different summation order: 1e-6), for probabilities and for raw logits."""
     import atomai_amd as aoi
@@ -209,8 +209,8 @@ def check_head_fusion(device):
     engine.HeadNode.__init__ = counting
     try:
         for name, ncls, kw, hw in (("Unet", 3, dict(nb_filters=4), (24, 40)), ("dilnet", 1, dict(nb_filters=5), (22, 38)),
-                                   ("Unet", 1, dict(nb_filters=16, batch_norm=False), (16, 16)),
-                                   ("dilnet", 2, dict(nb_filters=25), (12, 20))):
+                                   ("Unet", 1, dict(nb_filters=16 if wide else 6, batch_norm=False), (16, 16)),
+                                   ("dilnet", 2, dict(nb_filters=25 if wide else 9), (12, 20))):
             torch.manual_seed(6)
             net, _ = aoi.nets.init_fcnn_model(name, ncls, **kw)
             net = net.to(device)

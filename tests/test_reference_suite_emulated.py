@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 import _reference_suite as R  # noqa: E402
 
 DEV = "cpu"
+NARROW = dict(nb_filters=4)          # the emulator tier trains narrow nets; the gpu tier the default widths
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -25,7 +26,7 @@ def test_trainer_loss_selection():
 
 @pytest.mark.parametrize("model_type", ["Unet", "dilnet"])
 def test_segtrainer_determinism(model_type, tmp_path):
-    R.segtrainer_determinism(model_type, tmp_path, nb_filters=4)
+    R.segtrainer_determinism(model_type, tmp_path, cycles=3, nb_filters=4)
 
 
 @pytest.mark.parametrize("binary", [True, False])
@@ -150,3 +151,36 @@ def test_dkl_ensemble_predict(shared_emb, ydim):
 @pytest.mark.parametrize("reg_dim,shared", [(1, True), (2, True), (2, False)])
 def test_dkl_sampling_and_thompson(reg_dim, shared):
     R.dkl_sampling(reg_dim, shared)
+
+
+@pytest.mark.parametrize("precision,dtype", [("single", torch.float32), ("double", torch.float64)])
+def test_dkltrainer_precision(precision, dtype):
+    R.dkltrainer_precision(precision, dtype)
+
+
+def test_dkltrainer_compile_train_run(tmp_path):
+    R.dkltrainer_compile_train_run(tmp_path)
+
+
+def test_dkltrainer_multi_model():
+    R.dkltrainer_multi_model()
+
+
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet", "ResHedNet"])
+def test_io_segmentor(model, tmp_path):
+    R.io_segmentor(model, tmp_path, **NARROW)
+
+
+@pytest.mark.parametrize("kind", ["VAE", "rVAE"])
+def test_io_vae_and_resume(kind, tmp_path):
+    R.io_vae(kind, tmp_path)
+
+
+@pytest.mark.parametrize("model,binary,full_epoch", [("Unet", 0, 0), ("SegResNet", 1, 1)])
+def test_ensemble_seg(model, binary, full_epoch, tmp_path):
+    R.ensemble_seg(model, binary, full_epoch, tmp_path, **NARROW)
+
+
+@pytest.mark.parametrize("model", ["Unet"])
+def test_epredictor_seg(model, tmp_path):
+    R.epredictor_seg(model, tmp_path, **NARROW)

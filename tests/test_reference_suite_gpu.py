@@ -9,6 +9,7 @@ import _reference_suite as R  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+NARROW = {}                          # default widths on the MI355X
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -150,3 +151,38 @@ def test_dkl_ensemble_predict(shared_emb, ydim):
 @pytest.mark.parametrize("reg_dim,shared", [(1, True), (2, True), (2, False)])
 def test_dkl_sampling_and_thompson(reg_dim, shared):
     R.dkl_sampling(reg_dim, shared)
+
+
+@pytest.mark.parametrize("precision,dtype", [("single", torch.float32), ("double", torch.float64)])
+def test_dkltrainer_precision(precision, dtype):
+    R.dkltrainer_precision(precision, dtype)
+
+
+def test_dkltrainer_compile_train_run(tmp_path):
+    R.dkltrainer_compile_train_run(tmp_path)
+
+
+def test_dkltrainer_multi_model():
+    R.dkltrainer_multi_model()
+
+
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet", "ResHedNet"])
+def test_io_segmentor(model, tmp_path):
+    R.io_segmentor(model, tmp_path, **NARROW)
+
+
+@pytest.mark.parametrize("kind", ["VAE", "rVAE"])
+def test_io_vae_and_resume(kind, tmp_path):
+    R.io_vae(kind, tmp_path)
+
+
+@pytest.mark.parametrize("full_epoch", [0, 1])
+@pytest.mark.parametrize("binary", [1, 0])
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "SegResNet", "ResHedNet"])
+def test_ensemble_seg(model, binary, full_epoch, tmp_path):
+    R.ensemble_seg(model, binary, full_epoch, tmp_path, **NARROW)
+
+
+@pytest.mark.parametrize("model", ["Unet", "dilnet", "ResHedNet"])
+def test_epredictor_seg(model, tmp_path):
+    R.epredictor_seg(model, tmp_path, **NARROW)
