@@ -115,6 +115,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.th = pl.th;
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     const bool tail = a.tail_kg < KG;                       // partial last chunk: cheaper tail path
+    if (amx_conv_ws_supported(a, taps, dil, pl.th / 4, in_slope0, in_slope1)) return amx_conv_launch_ws(a, s);
     if (amx_lattice_mode(taps, dil)) {                          // tiles of the (largest) residue-class sub-image
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);

@@ -579,6 +579,9 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// wave-specialised kernel of the thin plain-3x3 layers (conv_ws.hip)
+bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, float in_slope0, float in_slope1);
+int amx_conv_launch_ws(ConvFwdArgs& a, hipStream_t s);
 // dispatchers of the three instantiation units (nt in {1,2,4}; th in {8,16})
 int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);

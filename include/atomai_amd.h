@@ -69,6 +69,9 @@ int amx_conv2d_num_tiles(int N, int H, int W, int th);
  * amx_conv2d_stats_rows: the number of rows amx_conv2d_fwd writes (== amx_conv2d_num_tiles(N,H,W,tile_h) when 0). */
 int amx_conv2d_stats_lattice(int taps, int dil);
 int amx_conv2d_stats_rows(int Cin_s, int cout, int taps, int dil, int N, int H, int W);
+/* Diagnostic: launches of amx_conv2d_fwd / amx_conv2d_dgrad that the wave-specialised kernel of the thin plain-3x3
+ * layers (conv_ws.hip) has taken since the library was loaded (AMX_CONV_WS=0 routes them to the general kernel). */
+long amx_conv2d_ws_launches(void);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d; trainer.py:205 loss.backward()).
  * part: [amx_conv2d_wgrad_rows][taps][round_up(C0s+C1s,16)][round_up(cout,16)] partial rows. */

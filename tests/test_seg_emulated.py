@@ -162,3 +162,9 @@ def test_classification_head_in_the_last_conv_epilogue():
 
 def test_dilated_block_sum_in_the_last_conv_epilogue():
     C.check_dsum_fusion("cpu")
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 16), (16, 16)])
+def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
+    """conv_ws.hip against the general kernel and fp64 autograd (32x32 images, 4 emulated CUs)."""
+    C.check_wave_specialised_conv("cpu", cin, cout, monkeypatch)

@@ -256,3 +256,10 @@ def test_iou_vs_reference_golden():
 def test_fit_with_compute_accuracy(tmp_path):
     import _metrics_checks as M
     M.check_fit_with_accuracy(True, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 16), (16, 16)])
+def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
+    """conv_ws.hip against the general kernel and fp64 autograd (128x128 images: 2 tiles per CU and more)."""
+    C.check_wave_specialised_conv("cuda", cin, cout, monkeypatch, hw=128, batch=12)

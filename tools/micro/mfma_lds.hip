@@ -124,3 +124,101 @@ extern "C" double mfma_rand_tflops(int zero, int wgs_per_cu, int iters, int reps
     hipFree(out); hipFree(src);
     return (double)reps * wgs * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;
 }
+
+// ---- mode 7/8: WAVE-SPECIALISED workgroup — the experiment behind a producer/consumer convolution kernel.
+// Waves [0, NC) are consumers: per phase 2 chunks x 9 bursts of (4 ds_read_b128 + 16 MFMA) = 288 MFMAs, i.e. the matrix
+// work of one 8x16-pixel tile of a 32->32 3x3 layer for one wave (MTW = NT = 2).  Waves [NC, 2 NC) are producers: per
+// phase they fetch `NLD` float4 per lane from a big global array (the next tile), run `NVALU` dependent-free FMAs on them
+// (index arithmetic + BatchNorm affine + activation + statistics of the real kernel), write them to LDS, read 4 float4
+// back (the accumulators handed over by the consumers) and store 4 float4 to global (the finished tile).  One
+// __syncthreads() per phase.  The question: how close to the pure-MFMA ceiling does the pipe stay?
+template <int NC, int NLD, int NVALU>
+__global__ __launch_bounds__(NC * 128) void k_spec(float* out, const float4* src, float4* dst, int iters, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 8192; i += NC * 128) smem[i] = src[i & 1023].x;
+    __syncthreads();
+    if (wave < NC) {
+        f32x4 acc[4];
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4* base = reinterpret_cast<const float4*>(smem) + lane;
+        float4 f[4];
+        for (int it = 0; it < iters; ++it) {
+            #pragma unroll
+            for (int t = 0; t < 18; ++t) {
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = base[((t * 4 + j) & 7) * 64 + ((it & 1) ? 512 : 0)];
+                #define M(C) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[0].C, f[2].C, acc[0], 0, 0, 0); \
+                             acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[0].C, f[3].C, acc[1], 0, 0, 0); \
+                             acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[1].C, f[2].C, acc[2], 0, 0, 0); \
+                             acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[1].C, f[3].C, acc[3], 0, 0, 0);
+                M(x) M(y) M(z) M(w)
+                #undef M
+            }
+            // hand the accumulators over (4 ds_write_b128 per lane) and start the next tile from zero
+            float4* hand = reinterpret_cast<float4*>(smem + 4096) + (wave * 64 + lane) * 4;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) { hand[i] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]); acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            __syncthreads();
+        }
+    } else {
+        const int pw = wave - NC;
+        float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+        size_t tile = (size_t)blockIdx.x * 977u;
+        for (int it = 0; it < iters; ++it) {
+            float4 r[NLD];
+            tile = (tile + 7919u) % (size_t)ntiles;
+            #pragma unroll
+            for (int i = 0; i < NLD; ++i) r[i] = src[tile * 2048 + (size_t)((i * NC * 64 + pw * 64 + lane) & 2047)];
+            float4 h[4];
+            const float4* hand = reinterpret_cast<const float4*>(smem + 4096) + (pw * 64 + lane) * 4;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = hand[i];
+            // VALU ballast on the handed-over tile (bias, activation, statistics, transposition of the real epilogue)
+            #pragma unroll
+            for (int v = 0; v < NVALU / 2; ++v) { float* q = reinterpret_cast<float*>(h); q[v & 15] = __builtin_fmaf(q[v & 15], 1.0001f, 0.5f); }   // 16 independent chains
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) dst[tile * 1024 + (size_t)((i * NC * 64 + pw * 64 + lane) & 1023)] = h[i];
+            // VALU ballast on the fetched tile (affine + activation), then stage it
+            #pragma unroll
+            for (int v = 0; v < NVALU / 2; ++v) { float* q = reinterpret_cast<float*>(r); q[v % (4 * NLD)] = __builtin_fmaf(q[v % (4 * NLD)], 1.0001f, 0.5f); }
+            float4* stage = reinterpret_cast<float4*>(smem + ((it & 1) ? 0 : 2048));
+            #pragma unroll
+            for (int i = 0; i < NLD; ++i) stage[(i * NC * 64 + pw * 64 + lane) & 511] = r[i];
+            keep.x += r[0].x;
+            __syncthreads();
+        }
+        if (keep.x == 123.456f) out[0] = keep.x;
+    }
+}
+
+template <int NC, int NLD, int NVALU>
+static double run_spec(int wgs_per_cu, int iters, int reps) {
+    float* out; float4* src; float4* dst;
+    const int ntiles = 16384;
+    hipMalloc(&out, 4); hipMalloc(&src, (size_t)ntiles * 2048 * 16); hipMalloc(&dst, (size_t)ntiles * 1024 * 16);
+    hipMemset(src, 0x3c, (size_t)ntiles * 2048 * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const size_t lds = (size_t)(160 * 1024 / wgs_per_cu) / 1024 * 1024 - (wgs_per_cu > 1 ? 1024 : 0);
+    auto kern = k_spec<NC, NLD, NVALU>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int wgs = 256 * wgs_per_cu;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(NC * 128), lds, 0, out, src, dst, iters, ntiles);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(NC * 128), lds, 0, out, src, dst, iters, ntiles);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipFree(out); hipFree(src); hipFree(dst);
+    return (double)reps * wgs * NC * iters * 288.0 * 2048.0 / (ms * 1e-3) / 1e12;
+}
+
+// variant 0: 4+4 waves, 6 loads, 600 VALU; 1: 8+8 waves (one workgroup per CU); 2: 4+4, 1200 VALU; 3: 4+4, 6 loads, 0 VALU
+extern "C" double mfma_spec_tflops(int variant, int wgs_per_cu, int iters, int reps) {
+    switch (variant) {
+        case 0: return run_spec<4, 6, 600>(wgs_per_cu, iters, reps);
+        case 1: return run_spec<8, 6, 600>(wgs_per_cu, iters, reps);
+        case 2: return run_spec<4, 6, 1200>(wgs_per_cu, iters, reps);
+        default: return run_spec<4, 6, 0>(wgs_per_cu, iters, reps);
+    }
+}
