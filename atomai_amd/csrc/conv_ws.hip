@@ -5,21 +5,31 @@
 // a wave spends 25 % of its life issuing MFMAs and the rest in index arithmetic, staging, epilogue and statistics
 // (profiles/r02_conv_phases.md); four co-resident waves per SIMD in random phases leave the pipe idle whenever all four
 // are outside their MFMA phase (1 - 0.75^4 = 0.68, the measured utilisation).  Here the two kinds of work run in
-// DIFFERENT waves of one persistent 16-wave workgroup per CU (profiles/r03_micro_wave_specialised.md: a consumer /
+// DIFFERENT waves of one persistent 16-wave workgroup per CU (profiles/r03_wave_specialised.md: a consumer /
 // producer pair per SIMD keeps the pipe at 0.90 of the pure-MFMA ceiling in the micro-benchmark):
 //
 //   waves 0..7  (consumers): nothing but ds_read_b128 operand fetches + v_mfma_f32_16x16x4_f32 on a 16x16-pixel tile
-//                            (2 image rows x NT cout tiles per wave — the inner loop of conv_kernel.h), then bias +
-//                            LeakyReLU on the accumulators and a hand-over of the finished tile through LDS;
-//   waves 8..15 (producers): global loads of tile k+2 into registers, BatchNorm affine + zero padding and the LDS image
-//                            of tile k+1 (double-buffered), and the epilogue of tile k-1: per-strip batch statistics
-//                            (sum, M2 about the strip mean — the same strips, rows and row order as conv_kernel.h, so
-//                            bn.hip merges them unchanged) and 16-byte NHWC stores to one or two outputs.
+//                            (2 image rows x NT cout tiles per wave — the inner loop of conv_kernel.h), then ONE b128
+//                            store per accumulator tile into a cout-major hand-over buffer (the four registers of a
+//                            C/D fragment are four consecutive pixels of one cout);
+//   waves 8..15 (producers, s_setprio 3): global loads of tile k+2 into registers, BatchNorm affine + zero padding and
+//                            the LDS image of tile k+1 (double-buffered), and the epilogue of tile k-1: bias +
+//                            LeakyReLU, per-strip batch statistics (sum, M2 about the strip mean — the same strips,
+//                            rows and row order as conv_kernel.h, so bn.hip merges them unchanged) and 16-byte NHWC
+//                            stores to one or two outputs.
 //
 // The weight image of the whole layer (<= 36 KB) is LDS-resident for the life of the workgroup; tiles are walked with a
 // stride of gridDim.x so neighbouring tiles are in flight on neighbouring CUs (shared halo rows hit L2).  Two
 // __syncthreads() per tile: A = "tile k computed, tile k+1 staged, hand-over buffer drained", B = "accumulators handed
-// over".  LDS: weights + 2 input images + hand-over buffer = 156 KB for 32 -> 32 channels.
+// over".  LDS: weights + 2 input images + hand-over buffer = 153 KB for 32 -> 32 channels.
+//
+// What the phase clocks showed while it was built (tools/gpu_ws_phases.py, profiles/r03_wave_specialised.md):
+//   * without raised priority the producers only advance when the consumers stop at a barrier (the issue arbiter serves
+//     the oldest ready wave and a consumer always has an MFMA waiting for the pipe): staging took "sweep + 1.8 k clocks";
+//   * a predicated load, or separate interior / border code paths, makes the compiler copy loaded registers at the
+//     merge and wait for them where they were issued: every load here is unconditional (clamped address, zeroed later);
+//   * the 64-bit address arithmetic of 10 accesses per tile is worth precomputing: the producers share the VALU port
+//     with the MFMAs and get about one slot in 10-16 clocks.
 //
 // Same arguments, results and partial-statistics layout as amx_conv2d_fwd / amx_conv2d_dgrad; conv_fwd.hip routes a
 // launch here when amx_conv_ws_supported() says so (AMX_CONV_WS=0 switches it off for A/B measurements).
@@ -33,25 +43,42 @@ static __device__ __forceinline__ int amx_wave_uniform(int v) {
 #endif
 }
 
+// AMX_CONV_PROFILE (dev builds, tools/gpu_ws_phases.py): every wave accumulates the shader clocks of its phases over all its
+// tiles and writes [workgroup][wave][8] totals: 0 MFMA sweep, 1 wait at barrier A, 2 hand-over, 3 wait at barrier B,
+// 4 staging (incl. the wait for the tile's loads), 5 issuing loads, 6 epilogue, 7 lifetime.
+#ifdef AMX_CONV_PROFILE
+#define WS_TICK(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt[i] += n_ - pl; pl = n_; } while (0)
+#else
+#define WS_TICK(i) do { } while (0)
+#endif
+
+#ifndef AMX_WS_PRODUCER_PRIO
+#define AMX_WS_PRODUCER_PRIO 3   // s_setprio of the producer waves (0 = leave the default; experiment switch)
+#endif
 #define WS_IW 18                 // input image: (16 + 2) x (16 + 2) pixel slots
 #define WS_SLOTS 324
-#define WS_PLANE 336             // slots per 4-channel plane (== 0 mod 16: conflict-free b128 fragment reads)
 #define WS_CONS 8                // consumer waves (2 image rows each); as many producer waves
+#define WS_PS 260                // hand-over buffer [cout][256 pixels + 4]: the 16 couts of a b128 store land 4 banks apart
+
+// slots (16 B) per 4-channel plane of the input image: the staging stores of 16 consecutive lanes (channel group fastest,
+// then slot) must cover all 64 banks -> plane stride == 8 (two chunks: 8 groups x 2 slots) or 16 (one chunk: 4 x 4) mod 64
+// floats; the consumers' fragment reads are contiguous within a plane and do not care
+template <int NCH> struct WsPlane { static constexpr int value = NCH == 2 ? 338 : 340; };
 
 template <int NCH, int NT>
 __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
     constexpr int COP = 16 * NT;
     constexpr int G = KG * NCH;                                   // 4-channel groups of the concatenated input
-    constexpr int IN_FLOATS = G * WS_PLANE * 4;
+    constexpr int PLANE = WsPlane<NCH>::value;
+    constexpr int IN_FLOATS = G * PLANE * 4;
     constexpr int W_FLOATS = NCH * 9 * KG * COP * 4;
-    constexpr int HS = COP + 4;                                   // hand-over row stride: lane groups g land 16 banks apart
     constexpr int SH = NT == 2 ? 2 : 4;                           // rows of a statistics strip (plan_conv: th / 4)
     constexpr int CG = COP / 4;                                   // float4 groups per output pixel
     constexpr int XLD = (WS_SLOTS * G + 511) / 512;               // float4 loads per producer thread and tile
     AMX_DYN_SMEM(float, smem);
     float* s_w = smem;                                            // [NCH][9][KG][COP][4]
-    float* s_in = smem + W_FLOATS;                                // [2][G][WS_PLANE][4]
-    float* s_hand = s_in + 2 * IN_FLOATS;                         // [256 pixels][HS]
+    float* s_in = smem + W_FLOATS;                                // [2][G][PLANE][4]
+    float* s_hand = s_in + 2 * IN_FLOATS;                         // [COP][WS_PS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = amx_wave_uniform(tid >> 6);
@@ -59,16 +86,18 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
     const int first = blockIdx.x, step = gridDim.x;
     const int my_tiles = (ntiles - first + step - 1) / step;      // >= 1: the launcher starts at most ntiles workgroups
 
+#ifdef AMX_CONV_PROFILE
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pl = __builtin_amdgcn_s_memtime();
+    const unsigned long long p0 = pl;
+#endif
     for (int i = tid; i < W_FLOATS / 4; i += 1024) amx_st4(s_w + 4 * i, amx_ld4(a.wpk + 4 * i));
 
     if (wave < WS_CONS) {
         // ------------------------------------------------------------------ consumers: operand reads + MFMA only
         const int p = lane & 15, g = lane >> 4;
-        float bias_q[NT];
-        #pragma unroll
-        for (int q = 0; q < NT; ++q) bias_q[q] = a.bias ? a.bias[q * 16 + p] : 0.f;
-        const float slope = a.slope;
         __syncthreads();                                          // weights + image of the first tile are in LDS
+        WS_TICK(3);
         for (int k = 0; k < my_tiles; ++k) {
             const float* in = s_in + (k & 1) * IN_FLOATS;
             f32x4 acc[2][NT];
@@ -84,7 +113,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
                     float4 af[2], bf[NT];
                     #pragma unroll
                     for (int m = 0; m < 2; ++m)
-                        af[m] = amx_ld4(in + ((size_t)(chunk * KG + g) * WS_PLANE + (wave * 2 + m + 1 + dy) * WS_IW + (p + 1 + dx)) * 4);
+                        af[m] = amx_ld4(in + ((size_t)(chunk * KG + g) * PLANE + (wave * 2 + m + 1 + dy) * WS_IW + (p + 1 + dx)) * 4);
                     #pragma unroll
                     for (int q = 0; q < NT; ++q)
                         bf[q] = amx_ld4(s_w + ((size_t)((chunk * 9 + tap) * KG + g) * COP + q * 16 + p) * 4);
@@ -96,36 +125,52 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
                     #undef WS_MFMA
                 }
             }
+            WS_TICK(0);
             __syncthreads();                                      // A: the hand-over buffer is drained
-            // C/D fragment: cout = lane & 15, pixel x = 4 * (lane >> 4) + reg
+            WS_TICK(1);
+            // C/D fragment: cout = lane & 15, pixels x = 4 * (lane >> 4) + reg: the four registers are four CONSECUTIVE
+            // pixels of one cout -> one b128 store per accumulator tile into the cout-major hand-over buffer
             #pragma unroll
             for (int m = 0; m < 2; ++m)
                 #pragma unroll
                 for (int q = 0; q < NT; ++q)
-                    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[m][q][r] + bias_q[q];
-                        v = v > 0.f ? v : v * slope;
-                        s_hand[(size_t)((wave * 2 + m) * TILE + 4 * g + r) * HS + q * 16 + p] = v;
-                    }
+                    amx_st4(s_hand + (size_t)(q * 16 + p) * WS_PS + (wave * 2 + m) * TILE + 4 * g,
+                            make_float4(acc[m][q][0], acc[m][q][1], acc[m][q][2], acc[m][q][3]));
+            WS_TICK(2);
             __syncthreads();                                      // B: handed over
+            WS_TICK(3);
         }
     } else {
         // ------------------------------------------------------------------ producers: loads, staging, epilogue
+        // Everything a producer does shares the SIMD's VALU issue port with the consumers' MFMAs (about one slot per
+        // 10-16 clocks next to a saturated matrix pipe, profiles/r03_wave_specialised.md), so the per-tile
+        // instruction count is what matters here: per-thread byte offsets are computed once, a tile costs one 64-bit
+        // multiply-add per base pointer plus one 64-bit add per access, and tiles that do not touch the image border
+        // skip every bounds predicate.
+#if !defined(AMX_EMU) && AMX_WS_PRODUCER_PRIO
+        // The issue arbiter serves the oldest ready wave first, and a consumer's next MFMA waiting for the busy matrix pipe
+        // sits in front of a producer's VALU / LDS / memory instructions; raised priority lets the few producer
+        // instructions through while the pipe works off its queue.
+        __builtin_amdgcn_s_setprio(AMX_WS_PRODUCER_PRIO);
+#endif
         const int ptid = tid - 64 * WS_CONS, pw = wave - WS_CONS;
         const int c8 = ptid % G;                                  // this thread's 4-channel group (512 % G == 0)
         const int slot0 = ptid / G;                               // its slots: slot0 + i * (512 / G)
         const int ch = c8 * 4;
-        const float* src; int Cs, c;
+        const char* src; unsigned cs_bytes;                       // this thread's source (bytes) at its channel group
         float4 r_sc = make_float4(1.f, 1.f, 1.f, 1.f), r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch < a.C0s) { src = a.x0; Cs = a.C0s; c = ch; if (a.sc0) { r_sc = amx_ld4(a.sc0 + c); r_sh = amx_ld4(a.sh0 + c); } }
-        else { src = a.x1; Cs = a.C1s; c = ch - a.C0s; if (a.sc1) { r_sc = amx_ld4(a.sc1 + c); r_sh = amx_ld4(a.sh1 + c); } }
-        int rel[XLD], yx[XLD];                                    // pixel offset from the tile's halo origin; (iy << 8) | ix or -1
+        if (ch < a.C0s) {
+            src = (const char*)(a.x0 + ch); cs_bytes = (unsigned)a.C0s * 4u;
+            if (a.sc0) { r_sc = amx_ld4(a.sc0 + ch); r_sh = amx_ld4(a.sh0 + ch); }
+        } else {
+            src = (const char*)(a.x1 + (ch - a.C0s)); cs_bytes = (unsigned)a.C1s * 4u;
+            if (a.sc1) { r_sc = amx_ld4(a.sc1 + (ch - a.C0s)); r_sh = amx_ld4(a.sh1 + (ch - a.C0s)); }
+        }
+        int yx[XLD];                                              // (iy << 8) | ix of the thread's slots (the last may be past the image: -1)
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
             const int slot = slot0 + i * (512 / G);
             const int iy = slot / WS_IW, ix = slot - iy * WS_IW;
-            rel[i] = iy * a.W + ix;
             yx[i] = slot < WS_SLOTS ? ((iy << 8) | ix) : -1;
         }
         float4 xr[XLD];
@@ -135,50 +180,70 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
             tx = t % a.tiles_x; t /= a.tiles_x;
             ty = t % a.tiles_y; n = t / a.tiles_y;
         };
+        // Every load is UNCONDITIONAL: a predicated load (or two code paths for interior / border tiles) makes the
+        // compiler merge old and new register values, and the copy it inserts waits for the load right where it was
+        // issued — the whole prefetch distance is lost.  Halo slots outside the image read a clamped (valid) address
+        // instead and are zeroed when the tile is staged.
         auto issue = [&](int k) {
             int n, ty, tx;
             tile_of(k, n, ty, tx);
-            const int gy0 = ty * TILE - 1, gx0 = tx * TILE - 1;
-            const long base = ((long)n * a.H + gy0) * a.W + gx0;
+            const int ylo = ty == 0 ? 1 : 0, yhi = ty + 1 == a.tiles_y ? TILE : TILE + 1;     // valid slot rows / columns
+            const int xlo = tx == 0 ? 1 : 0, xhi = tx + 1 == a.tiles_x ? TILE : TILE + 1;
+            const long origin = ((long)n * a.H + ty * TILE - 1) * a.W + tx * TILE - 1;        // halo origin (may be < 0)
+            const char* base = src + origin * (long)cs_bytes;
             xvalid = 0;
             #pragma unroll
             for (int i = 0; i < XLD; ++i) {
-                const int gy = gy0 + (yx[i] >> 8), gx = gx0 + (yx[i] & 255);
-                const bool ok = yx[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) { xr[i] = amx_ld4(src + (size_t)(base + rel[i]) * Cs + c); xvalid |= 1u << i; }
+                const int iy = yx[i] >> 8, ix = yx[i] & 255;      // (-1 -> row -1, column 255: clamped like any other)
+                const int cy = min(max(iy, ylo), yhi), cx = min(max(ix, xlo), xhi);
+                if (cy == iy && cx == ix) xvalid |= 1u << i;
+                xr[i] = *reinterpret_cast<const float4*>(base + (unsigned)(cy * a.W + cx) * cs_bytes);
             }
         };
         auto stage = [&](int buf) {
-            float* dst = s_in + (size_t)buf * IN_FLOATS + (size_t)c8 * WS_PLANE * 4;
+            float* dst = s_in + (size_t)buf * IN_FLOATS + (size_t)c8 * PLANE * 4 + (size_t)slot0 * 4;
             #pragma unroll
             for (int i = 0; i < XLD; ++i) {
-                if (yx[i] < 0) continue;
-                float4 v = xr[i];
-                if (xvalid & (1u << i)) {                         // the zero padding stays zero AFTER the affine
-                    v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
-                    v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
-                }
-                amx_st4(dst + (size_t)(slot0 + i * (512 / G)) * 4, v);
+                if (i + 1 == XLD && yx[i] < 0) continue;          // (only the last load of a thread can fall off the image)
+                const float4 v = xr[i];
+                float4 w = make_float4(fmaf(v.x, r_sc.x, r_sh.x), fmaf(v.y, r_sc.y, r_sh.y),
+                                       fmaf(v.z, r_sc.z, r_sh.z), fmaf(v.w, r_sc.w, r_sh.w));
+                if (!(xvalid & (1u << i))) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding (AFTER the affine)
+                amx_st4(dst + (size_t)i * (512 / G) * 4, w);
             }
         };
+        // epilogue: wave pw owns statistics strip pw (SH rows x 16 pixels) of the tile; lane -> (pixel, 4 couts)
+        const int cg = lane % CG, co = cg * 4;
+        const bool epi_wave = pw < TILE / SH;
+        char* outp; unsigned cd_bytes;                            // this lane's output (bytes) at its cout group
+        if (co < a.Y0s) { outp = (char*)(a.y + co); cd_bytes = (unsigned)a.Y0s * 4u; }
+        else { outp = (char*)(a.y1 + (co - a.Y0s)); cd_bytes = (unsigned)a.Y1s * 4u; }
+        unsigned orel[4]; int hoff[4];
+        #pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ps = (it * 64 + lane) / CG;                 // pixel of the strip: row ps / 16, column ps % 16
+            const int row = (epi_wave ? pw : 0) * SH + ps / TILE, x = ps % TILE;
+            orel[it] = (unsigned)(row * a.W + x) * cd_bytes;
+            hoff[it] = co * WS_PS + row * TILE + x;
+        }
+        const float4 b4 = a.bias ? amx_ld4(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float slope = a.slope;
         auto epilogue = [&](int k) {
-            if (pw >= TILE / SH) return;                          // one statistics strip (SH rows x 16 pixels) per wave
+            if (!epi_wave) return;
             int n, ty, tx;
             tile_of(k, n, ty, tx);
+            char* obase = outp + (((long)n * a.H + ty * TILE) * a.W + tx * TILE) * (long)cd_bytes;
             float4 v[4];
             float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int cg = lane % CG;
-            const int co = cg * 4;
             #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int ps = (it * 64 + lane) / CG;             // pixel of the strip: row ps / 16, column ps % 16
-                const int row = pw * SH + ps / TILE, x = ps % TILE;
-                v[it] = amx_ld4(s_hand + (size_t)(row * TILE + x) * HS + co);
-                sm.x += v[it].x; sm.y += v[it].y; sm.z += v[it].z; sm.w += v[it].w;
-                const size_t pix = ((size_t)n * a.H + ty * TILE + row) * a.W + tx * TILE + x;
-                if (co < a.Y0s) amx_st4(a.y + pix * a.Y0s + co, v[it]);
-                else amx_st4(a.y1 + pix * a.Y1s + (co - a.Y0s), v[it]);
+                const float* h = s_hand + hoff[it];
+                float4 t = make_float4(h[0] + b4.x, h[WS_PS] + b4.y, h[2 * WS_PS] + b4.z, h[3 * WS_PS] + b4.w);
+                t.x = t.x > 0.f ? t.x : t.x * slope; t.y = t.y > 0.f ? t.y : t.y * slope;
+                t.z = t.z > 0.f ? t.z : t.z * slope; t.w = t.w > 0.f ? t.w : t.w * slope;
+                v[it] = t;
+                sm.x += t.x; sm.y += t.y; sm.z += t.z; sm.w += t.w;
+                *reinterpret_cast<float4*>(obase + orel[it]) = t;
             }
             if (a.stats) {
                 #pragma unroll
@@ -207,24 +272,38 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
         issue(0);
         stage(0);
         if (my_tiles > 1) issue(1);
+        WS_TICK(4);
         __syncthreads();
+        WS_TICK(3);
         for (int k = 0; k < my_tiles; ++k) {
             if (k + 1 < my_tiles) {
                 stage((k + 1) & 1);
+                WS_TICK(4);
                 if (k + 2 < my_tiles) issue(k + 2);
+                WS_TICK(5);
             }
             if (k >= 1) epilogue(k - 1);
+            WS_TICK(6);
             __syncthreads();                                      // A
+            WS_TICK(1);
             __syncthreads();                                      // B
+            WS_TICK(3);
         }
         epilogue(my_tiles - 1);
+        WS_TICK(6);
     }
+#ifdef AMX_CONV_PROFILE
+    if (a.prof && lane == 0) {
+        pt[7] = __builtin_amdgcn_s_memtime() - p0;
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)blockIdx.x * 16 + (tid >> 6)) * 8 + i] = pt[i];
+    }
+#endif
 }
 
 template <int NCH, int NT>
 static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
     constexpr int COP = 16 * NT;
-    const size_t lds = ((size_t)NCH * 9 * KG * COP * 4 + 2 * (size_t)KG * NCH * WS_PLANE * 4 + (size_t)256 * (COP + 4)) * sizeof(float);
+    const size_t lds = ((size_t)NCH * 9 * KG * COP * 4 + 2 * (size_t)KG * NCH * WsPlane<NCH>::value * 4 + (size_t)COP * WS_PS) * sizeof(float);
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
     int wgs = amx_num_cus();
     if (wgs > ntiles) wgs = ntiles;
@@ -246,9 +325,16 @@ static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
 // image sides in multiples of 16 and enough tiles for one persistent workgroup per CU; no fused head / block sum /
 // residual addend / post-affine activation.  `strip` is the statistics strip height the layer's plan reports.
 bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, float in_slope0, float in_slope1) {
-    static int enabled = -1;
-    if (const char* e = getenv("AMX_CONV_WS")) enabled = atoi(e) != 0; else if (enabled < 0) enabled = 1;
-    if (!enabled) return false;
+    // AMX_CONV_WS: 0 = off, 1 = forward and data-gradient launches, 2 (default) = forward only (a bias is present),
+    // 3 = data gradient only.  Stand-alone the kernel is 12-27 % faster than conv_kernel.h on every thin shape, forward
+    // and data gradient alike (profiles/r03_wave_specialised.md); inside the training step only the forward launches
+    // gain (18.67 -> 18.48 ms): a persistent 16-wave workgroup owns its CU's LDS and registers, so the weight-gradient
+    // kernels of the side stream cannot run next to the data gradients any more and the overlap that is lost cancels
+    // what the faster kernel wins.
+    int mode = 2;
+    if (const char* e = getenv("AMX_CONV_WS")) mode = atoi(e);
+    if (mode <= 0) return false;
+    if ((mode == 2 && !a.bias) || (mode == 3 && a.bias)) return false;
     if (taps != 9 || dil != 1 || a.hout || a.nds || a.addend || in_slope0 != 1.f || in_slope1 != 1.f) return false;
     const int cin = a.C0s + a.C1s;
     if ((cin != 16 && cin != 32) || (a.C0s & 15) || (a.C1s & 15)) return false;

@@ -333,7 +333,7 @@ def check_wave_specialised_conv(device, cin, cout, monkeypatch, hw=32, batch=2):
     from atomai_amd.nets import ConvBlock
     out = {}
     for ws in ("1", "0"):
-        monkeypatch.setenv("AMX_CONV_WS", ws)
+        monkeypatch.setenv("AMX_CONV_WS", ws)            # 1: forward AND data-gradient launches (the default is forward only)
         torch.manual_seed(3)
         m = ConvBlock(2, 2, cin, cout, batch_norm=True).to(device)
         ref = nn.Sequential(*[copy.deepcopy(l) for l in m.block]).double()
@@ -361,3 +361,24 @@ def check_wave_specialised_conv(device, cin, cout, monkeypatch, hw=32, batch=2):
     assert float((out["1"][1] - out["0"][1]).abs().max()) < 2e-5 * max(1.0, float(out["0"][1].abs().max()))
     for a, b in zip(out["1"][2], out["0"][2]):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+
+
+def check_wave_specialised_concat(device, monkeypatch, hw=32, batch=2):
+    """U-Net's last block on conv_ws.hip: a layer reading torch.cat([skip, upsampled], 1) from two 16-channel sources,
+    each through its own BatchNorm affine, and its data gradient written to two outputs — against the general kernel."""
+    import atomai_amd as aoi
+    from atomai_amd import _lib as L
+    out = {}
+    for ws in ("1", "0"):
+        monkeypatch.setenv("AMX_CONV_WS", ws)
+        torch.manual_seed(5)
+        net, _ = aoi.nets.init_fcnn_model("Unet", 3, nb_filters=16)
+        net = net.to(device).train()
+        x = torch.randn(batch, 1, hw, hw, device=device)
+        n0 = L.load().amx_conv2d_ws_launches()
+        y = net(x)
+        y.backward(torch.ones_like(y) / y.numel())
+        assert (L.load().amx_conv2d_ws_launches() - n0 > 0) == (ws == "1")
+        out[ws] = [y.detach().cpu()] + [p.grad.cpu() for p in net.parameters()]
+    for a, b in zip(out["1"], out["0"]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), float((a - b).abs().max())

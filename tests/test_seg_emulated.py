@@ -168,3 +168,7 @@ def test_dilated_block_sum_in_the_last_conv_epilogue():
 def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
     """conv_ws.hip against the general kernel and fp64 autograd (32x32 images, 4 emulated CUs)."""
     C.check_wave_specialised_conv("cpu", cin, cout, monkeypatch)
+
+
+def test_wave_specialised_two_source_layer(monkeypatch):
+    C.check_wave_specialised_concat("cpu", monkeypatch)

@@ -263,3 +263,8 @@ def test_fit_with_compute_accuracy(tmp_path):
 def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
     """conv_ws.hip against the general kernel and fp64 autograd (128x128 images: 2 tiles per CU and more)."""
     C.check_wave_specialised_conv("cuda", cin, cout, monkeypatch, hw=128, batch=12)
+
+
+@pytest.mark.gpu
+def test_wave_specialised_two_source_layer(monkeypatch):
+    C.check_wave_specialised_concat("cuda", monkeypatch, hw=128, batch=12)
