@@ -108,6 +108,23 @@ struct ConvFwdArgs {
                                     // 4-way bank conflict of the scalar stores but measured SLOWER in the step (18.56 ->
                                     // 19.01 ms, profiles/r03_conv_epi_pad_ab.log): the b128 read-back then straddles rows
 #endif
+// AMX_CONV_PRIO_OUT / AMX_CONV_PRIO_MFMA: s_setprio of a wave outside / inside its MFMA phases (experiment switches; equal
+// values = no s_setprio at all).  The issue arbiter serves the oldest ready wave first, and a wave whose next MFMA waits for
+// the busy matrix pipe stands in front of the other waves' prologue / epilogue instructions (conv_ws.hip found its
+// producer waves starved that way).  Measured here (profiles/r03_conv_prio_ab.log): OUT = 3 18.54 -> 18.73 ms per U-Net
+// step and 1.312 -> 1.406 ms per dilnet frame, OUT = 1 the same, MFMA = 3 18.58 / 1.427: with four symmetric waves per
+// SIMD the default oldest-first order is the best one — off.
+#ifndef AMX_CONV_PRIO_OUT
+#define AMX_CONV_PRIO_OUT 0
+#endif
+#ifndef AMX_CONV_PRIO_MFMA
+#define AMX_CONV_PRIO_MFMA 0
+#endif
+#if !defined(AMX_EMU) && (AMX_CONV_PRIO_OUT != AMX_CONV_PRIO_MFMA)
+#define AMX_SETPRIO(v) __builtin_amdgcn_s_setprio(v)
+#else
+#define AMX_SETPRIO(v) do { } while (0)
+#endif
 #ifndef AMX_CONV_GLDS_WAVES
 #define AMX_CONV_GLDS_WAVES 5       // waves per SIMD requested for the 8-row thin classes when the weights go by LDS-DMA
 #endif
@@ -152,6 +169,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
+    AMX_SETPRIO(AMX_CONV_PRIO_OUT);
     AMX_TICK(0);
     // EXACT: the dilation equals MAXHALO (1, 2, 4, 6 — every dilation the reference's nets use) and the whole tile
     // geometry is compile-time: the slot index math of the loaders divides by constants instead of running a ~40
@@ -376,8 +394,10 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         if (chunk < 2) AMX_TICK(3 + 5 * chunk);
         if (chunk + 1 < a.nchunk) issue_loads(chunk + 1);
         if (chunk < 2) AMX_TICK(4 + 5 * chunk);
+        AMX_SETPRIO(AMX_CONV_PRIO_MFMA);
         if (TAIL && chunk + 1 == a.nchunk && a.tail_kg < KG) compute_tail(a.tail_kg);
         else compute_taps(0, 0, TAPS);
+        AMX_SETPRIO(AMX_CONV_PRIO_OUT);
         if (chunk < 2) AMX_TICK(5 + 5 * chunk);
         __syncthreads();
 #if AMX_CONV_GLDS
