@@ -430,8 +430,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
                                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic,
                                "traffic_source": tsrc,
-                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> (amx_conv2d_fwd: all forward + dgrad "
-                                         "launches of the step)",
+                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> + conv_ws_kernel<NCH,NT> (amx_conv2d_fwd / "
+                                         "amx_conv2d_dgrad: all forward + dgrad launches of the step)",
                                "launches_per_step": conv["calls"] // ksteps,
                                "ms_per_step": round(conv["total_ms"] / ksteps, 3),
                                "avg_launch_ms": round(conv["total_ms"] / conv["calls"], 4),

@@ -42,9 +42,9 @@ def kernel_stats(steps=7, sub="prof", outname="r01_unet_bs32_512_kernel_stats_fi
         side = sum(r[2] - r[1] for r in R if r[3] != 0) / 1e6
         out.append(f"\nSteady-state step (5th of the trace): wall {(e1 - s0) / 1e6:.2f} ms, GPU busy (union of kernel intervals) "
                    f"{busy / 1e6:.2f} ms, main-stream kernel time {main:.2f} ms, side-stream (weight gradients) {side:.2f} ms.\n")
-    fam = [(cl, td) for n, cl, td, av, pc in rows if short(n).startswith("conv_fwd_kernel")]
+    fam = [(cl, td) for n, cl, td, av, pc in rows if short(n).startswith(("conv_fwd_kernel", "conv_ws_kernel"))]
     if fam:
-        out.append(f"\nconv_fwd_kernel family (amx_conv2d_fwd + amx_conv2d_dgrad): {sum(c_ for c_, _ in fam)} launches, "
+        out.append(f"\nconv_fwd_kernel + conv_ws_kernel family (amx_conv2d_fwd + amx_conv2d_dgrad): {sum(c_ for c_, _ in fam)} launches, "
                    f"average {sum(t for _, t in fam) / sum(c_ for c_, _ in fam) / 1e3:.4f} ms per launch.\n")
     open(os.path.join(ROOT, "profiles", outname), "w").writelines(out)
 
@@ -71,7 +71,7 @@ def pmc_traffic(tag="r01", head="", sub_prefix="pmc_"):
         cnt = f[n][0]
         kern[n] = {"launches_per_step": cnt, "fetch_MB_per_launch": round(2 * f[n][1] * 1024 / 1e6 / cnt, 1),
                    "write_MB_per_launch": round(w[n][1] * 1024 / 1e6 / max(w[n][0], 1), 1)}
-    fam = [k for k in kern if k.startswith("conv_fwd_kernel")]
+    fam = [k for k in kern if k.startswith(("conv_fwd_kernel", "conv_ws_kernel"))]
     L = sum(kern[k]["launches_per_step"] for k in fam)
     fe = sum(kern[k]["fetch_MB_per_launch"] * kern[k]["launches_per_step"] for k in fam)
     wr = sum(kern[k]["write_MB_per_launch"] * kern[k]["launches_per_step"] for k in fam)
