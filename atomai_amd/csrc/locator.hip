@@ -7,39 +7,58 @@
 //   rem_edge_coord (predictor.py:621-639)       drop centres closer than dist_edge to the frame border
 // for every frame and every class channel except the last (background).
 //
-// Integer/byte work bound by HBM: no MFMA.  One linear element space e = ((b*nch + c)*H + h)*W + w.
-//   1. locate_init     L[e] = e for foreground pixels, -1 otherwise (reads the NHWC probabilities once)
-//   2. locate_merge    lock-free union-find (atomicMin on roots) over left / up neighbours
-//   3. locate_flatten  L[e] = root(e); per-root pixel count and row / column sums (integer atomics — exact,
-//                      order independent, so results are bit-reproducible)
-//   4. locate_count / locate_scan / locate_emit  order-preserving stream compaction of the surviving roots.
+// Integer/byte work bound by HBM: no MFMA.  One linear element space e = ((b*nch + c)*H + h)*W + w (a "plane" is
+// one (frame, class) map).  Round 3 — labelling happens in LDS, global memory only sees what crosses a tile:
+//   1. locate_tile     one workgroup per 32 x 64-pixel tile: reads the NHWC probabilities ONCE (8 consecutive pixels
+//                      per thread), thresholds, labels the tile's 4-connected components with a union-find over
+//                      horizontal RUNS in LDS (atomicMin on LDS parents; a run never needs more than one hook per
+//                      overlapping run of the row above), sums count / row / column per component with one packed
+//                      64-bit LDS atomic per run, and writes L[e] = element index of the pixel's tile-local root
+//                      (-1: background), the sums at the local roots only, and one BYTE of "is a local root" bits per
+//                      8 pixels.  Global traffic: 4 B read + 4.1 B written per pixel, everything 16/32-byte coalesced.
+//   2. locate_border   lock-free union-find (atomicMin on roots) over the pixel pairs that straddle a tile border —
+//                      1/32 + 1/64 of the pixels, and their parent chains start at a tile-local root;
+//   3. locate_fold     every local root that was hooked under another one adds its sums to its final root
+//                      (integer atomics — exact, order independent, so results are bit-reproducible);
+//   4. locate_count / locate_scan / locate_emit  order-preserving stream compaction of the surviving roots; these
+//                      passes walk the root BIT MAP (1/32 of the label volume), not the labels.
 // The root of a component is its smallest linear index = its first pixel in raster order, which is exactly
 // the order in which scipy.ndimage.label numbers components; centres are sums/count in fp64, the arithmetic
 // center_of_mass performs (integer-valued sums are exact in both).
+// (Round 1-2 labelled with ONE global union-find over all pixels: 0.57 ms per 32 frames of 1024^2 = 2.6 % of the HBM
+// roofline, parent chains chased through L2; profiles/r03_locator_tiles.md has the before / after.)
 #include "amx_device.h"
 
 typedef unsigned long long u64;
 
-#define LOC_STRIP 8                    // consecutive elements per thread
-#define LOC_CHUNK (256 * LOC_STRIP)    // elements per workgroup in the compaction passes
+#define LT_H 32                        // tile rows
+#define LT_W 64                        // tile columns (8 strips of 8 pixels: one thread each)
+#define LT_N (LT_H * LT_W)
+#define LOC_MB 8                       // root-map bytes (= 64 pixels) per thread in the fold / compaction passes
+#define LOC_CHUNK (256 * LOC_MB)       // root-map bytes per workgroup in the compaction passes
 
 struct LocWork {                       // views into the caller's workspace
-    int* L;
-    unsigned* cnt;
-    u64* sr;
-    u64* sc;
+    int* L;                            // [ne]   parent pointers (tile-local root after pass 1)
+    unsigned* cnt;                     // [ne]   valid at local roots only
+    u64* sr;                           // [ne]   "
+    u64* sc;                           // [ne]   "
+    unsigned char* rmap;               // [planes * H][WB] one bit per pixel: tile-local root
     int* chunk_off;                    // [nchunks + 1]
 };
 
-static __host__ __device__ inline long loc_nchunks(long ne) { return (ne + LOC_CHUNK - 1) / LOC_CHUNK; }
+static __host__ __device__ inline long loc_wb(int W) { return (W + 7) / 8; }
+static __host__ __device__ inline long loc_map_bytes(long rows, int W) { return (rows * loc_wb(W) + 7) / 8 * 8; }
+static __host__ __device__ inline long loc_nchunks(long map_bytes) { return (map_bytes + LOC_CHUNK - 1) / LOC_CHUNK; }
 
-static __host__ inline LocWork loc_views(void* work, long ne) {
+static __host__ inline LocWork loc_views(void* work, long ne, long map_bytes) {
     char* p = (char*)work;
     LocWork w;
     w.sr = (u64*)p;            p += ne * 8;
     w.sc = (u64*)p;            p += ne * 8;
     w.L = (int*)p;             p += ne * 4;
     w.cnt = (unsigned*)p;      p += ne * 4;
+    p += (8 - ((uintptr_t)p & 7)) & 7;
+    w.rmap = (unsigned char*)p; p += map_bytes;
     w.chunk_off = (int*)p;
     return w;
 }
@@ -67,60 +86,181 @@ static __device__ __forceinline__ void loc_unite(int* L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void locate_init_kernel(const float* __restrict__ prob, int* __restrict__ L,
+static __device__ __forceinline__ int loc_ctz(unsigned v) {
+#ifdef AMX_EMU
+    return __builtin_ctz(v);
+#else
+    return __ffs((int)v) - 1;
+#endif
+}
+
+// Pass 1.  Thread t owns the strip of 8 pixels at tile row t / 8, columns 8 * (t % 8) ...: local index t * 8 + j.
+__global__ __launch_bounds__(256) void locate_tile_kernel(const float* __restrict__ prob, int* __restrict__ L,
                                                           unsigned* __restrict__ cnt, u64* __restrict__ sr,
-                                                          u64* __restrict__ sc, long ne, int H, int W, int C,
-                                                          int nch, float thr) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ne) return;
-    const int w = (int)(e % W);
-    long t = e / W;
-    const int h = (int)(t % H);
-    t /= H;
-    const int c = (int)(t % nch);
-    const long b = t / nch;
-    const float p = prob[((b * H + h) * (long)W + w) * C + c];
-    const bool fg = p > thr;                        // cv2.THRESH_BINARY: strictly greater; NaN -> background
-    L[e] = fg ? (int)e : -1;
-    if (fg) { cnt[e] = 0u; sr[e] = 0ull; sc[e] = 0ull; }
-}
+                                                          u64* __restrict__ sc, unsigned char* __restrict__ rmap,
+                                                          int H, int W, int C, int nch, float thr, int ntx, int nty) {
+    __shared__ int s_lab[LT_N];                      // parent (local index); -1 background
+    __shared__ u64 s_acc[LT_N];                      // at run starts: count | row sum << 16 | column sum << 40 (tile-local)
+    __shared__ unsigned s_msk[256];                  // foreground bits of every strip
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tx = t % ntx; t /= ntx;
+    const int ty = t % nty;
+    const int fc = t / nty;                          // plane = b * nch + c
+    const int srow = tid >> 3, scol = tid & 7;
+    const int h = ty * LT_H + srow, w0 = tx * LT_W + scol * 8;
+    const int base = tid * 8;
+    const bool in_rows = h < H;
+    const int nvalid = !in_rows ? 0 : (W - w0 >= 8 ? 8 : (W - w0 > 0 ? W - w0 : 0));
 
-__global__ __launch_bounds__(256) void locate_merge_kernel(int* __restrict__ L, long ne, int H, int W) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ne) return;
-    if (loc_load(L + e) < 0) return;
-    const int w = (int)(e % W);
-    const int h = (int)((e / W) % H);
-    const bool left = w > 0 && loc_load(L + e - 1) >= 0;
-    const bool up = h > 0 && loc_load(L + e - W) >= 0;
-    if (left) loc_unite(L, (int)e, (int)e - 1);
-    // up is already connected through left + up-left when all three are foreground
-    if (up && !(left && loc_load(L + e - W - 1) >= 0)) loc_unite(L, (int)e, (int)e - W);
-}
-
-__global__ __launch_bounds__(256) void locate_flatten_kernel(int* __restrict__ L, unsigned* __restrict__ cnt,
-                                                             u64* __restrict__ sr, u64* __restrict__ sc,
-                                                             long ne, int H, int W) {
-    const long e0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * LOC_STRIP;
-    if (e0 >= ne) return;
-    int root = -1;
-    unsigned n = 0;
-    u64 ar = 0, ac = 0;
-    for (int j = 0; j < LOC_STRIP; ++j) {
-        const long e = e0 + j;
-        if (e >= ne) break;
-        int r = -1;
-        if (loc_load(L + e) >= 0) {
-            r = loc_find(L, (int)e);
-            L[e] = r;                                // every ancestor is valid for concurrent readers
+    unsigned m = 0;
+    if (nvalid) {
+        const long pix = ((long)(fc / nch) * H + h) * W + w0;
+        const float* src = prob + pix * C + (fc % nch);
+        if (C == 1 && nvalid == 8 && (pix & 3) == 0) {
+            const float4 a = amx_ld4(src), b = amx_ld4(src + 4);
+            m = (a.x > thr ? 1u : 0u) | (a.y > thr ? 2u : 0u) | (a.z > thr ? 4u : 0u) | (a.w > thr ? 8u : 0u) |
+                (b.x > thr ? 16u : 0u) | (b.y > thr ? 32u : 0u) | (b.z > thr ? 64u : 0u) | (b.w > thr ? 128u : 0u);
+        } else {
+            for (int j = 0; j < nvalid; ++j)
+                if (src[(long)j * C] > thr) m |= 1u << j;    // cv2.THRESH_BINARY: strictly greater; NaN -> background
         }
-        if (r != root) {                             // flush the run accumulated so far
-            if (root >= 0) { atomicAdd(cnt + root, n); atomicAdd(sr + root, ar); atomicAdd(sc + root, ac); }
-            root = r; n = 0; ar = 0; ac = 0;
-        }
-        if (r >= 0) { n += 1u; ar += (u64)((e / W) % H); ac += (u64)(e % W); }
     }
-    if (root >= 0) { atomicAdd(cnt + root, n); atomicAdd(sr + root, ar); atomicAdd(sc + root, ac); }
+    s_msk[tid] = m;
+    {
+        int cur = -1;
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (m & (1u << j)) {
+                if (cur < 0) { cur = base + j; s_acc[cur] = 0ull; }
+            } else cur = -1;
+            s_lab[base + j] = cur;                   // every pixel of a run points at the run's first pixel
+        }
+    }
+    __syncthreads();
+    if (m) {
+        if (scol > 0 && (m & 1u) && (s_msk[tid - 1] & 0x80u)) loc_unite(s_lab, base, base - 1);
+        if (srow > 0) {
+            const unsigned both = m & s_msk[tid - 8];
+            unsigned starts = both & ~(both << 1);   // one hook per run of vertically adjacent pairs
+            while (starts) {
+                const int j = loc_ctz(starts);
+                starts &= starts - 1;
+                loc_unite(s_lab, base + j, base - LT_W + j);
+            }
+        }
+    }
+    __syncthreads();
+    // flatten: the labels are read-only from here on; one LDS atomic per run
+    int lab[8];
+    {
+        int r = -1, n = 0, cs = 0;
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (m & (1u << j)) {
+                if (n == 0) r = loc_find(s_lab, base + j);
+                ++n; cs += scol * 8 + j;
+                lab[j] = r;
+            } else {
+                if (n) atomicAdd(&s_acc[r], (u64)n | ((u64)(n * srow) << 16) | ((u64)cs << 40));
+                n = 0; cs = 0;
+                lab[j] = -1;
+            }
+        }
+        if (n) atomicAdd(&s_acc[r], (u64)n | ((u64)(n * srow) << 16) | ((u64)cs << 40));
+    }
+    const long plane0 = (long)fc * H * W;
+    const long tile0 = plane0 + (long)(ty * LT_H) * W + tx * LT_W;       // element of the tile's first pixel
+    if (nvalid) {
+        int out[8];
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = lab[j] < 0 ? -1 : (int)(tile0 + (long)(lab[j] >> 6) * W + (lab[j] & 63));
+        const long e0 = tile0 + (long)srow * W + scol * 8;
+        if (nvalid == 8 && (e0 & 3) == 0) {
+            uint4 v0, v1;
+            v0.x = (unsigned)out[0]; v0.y = (unsigned)out[1]; v0.z = (unsigned)out[2]; v0.w = (unsigned)out[3];
+            v1.x = (unsigned)out[4]; v1.y = (unsigned)out[5]; v1.z = (unsigned)out[6]; v1.w = (unsigned)out[7];
+            *reinterpret_cast<uint4*>(L + e0) = v0;
+            *reinterpret_cast<uint4*>(L + e0 + 4) = v1;
+        } else {
+            for (int j = 0; j < nvalid; ++j) L[e0 + j] = out[j];
+        }
+    }
+    __syncthreads();                                 // the sums are complete
+    if (nvalid) {
+        unsigned roots = 0;
+        unsigned cand = m & ~(m << 1);               // run starts: the only pixels that can be roots
+        while (cand) {
+            const int j = loc_ctz(cand);
+            cand &= cand - 1;
+            if (s_lab[base + j] != base + j) continue;
+            roots |= 1u << j;
+            const u64 a = s_acc[base + j];
+            const u64 n = a & 0xFFFFull;
+            const long e = tile0 + (long)srow * W + scol * 8 + j;
+            cnt[e] = (unsigned)n;
+            sr[e] = ((a >> 16) & 0xFFFFFFull) + n * (u64)(ty * LT_H);
+            sc[e] = (a >> 40) + n * (u64)(tx * LT_W);
+        }
+        rmap[((long)fc * H + h) * loc_wb(W) + (w0 >> 3)] = (unsigned char)roots;
+    }
+}
+
+// Pass 2.  Item i of a plane: the (nty - 1) * W pixels of the first row of every tile row but the first (pair with
+// the pixel above), then the (ntx - 1) * H pixels of the first column of every tile column but the first (pair with
+// the pixel to the left).
+__global__ __launch_bounds__(256) void locate_border_kernel(int* __restrict__ L, int H, int W, int ntx, int nty,
+                                                            long per_plane, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long fc = i / per_plane;
+    long k = i - fc * per_plane;
+    const long plane0 = fc * H * W;
+    const long nrow_items = (long)(nty - 1) * W;
+    if (k < nrow_items) {
+        const int h = (int)(k / W + 1) * LT_H, w = (int)(k % W);
+        const long e = plane0 + (long)h * W + w;
+        if (loc_load(L + e) < 0 || loc_load(L + e - W) < 0) return;
+        // already connected through left + up-left when all four are foreground (that pair is handled by the thread
+        // of the pixel to the left, by the column items below, or inside the tiles)
+        if (w > 0 && loc_load(L + e - 1) >= 0 && loc_load(L + e - W - 1) >= 0) return;
+        loc_unite(L, (int)e, (int)(e - W));
+    } else {
+        k -= nrow_items;
+        const int w = (int)(k / H + 1) * LT_W, h = (int)(k % H);
+        const long e = plane0 + (long)h * W + w;
+        if (loc_load(L + e) < 0 || loc_load(L + e - 1) < 0) return;
+        loc_unite(L, (int)e, (int)(e - 1));
+    }
+}
+
+// Element index of bit `bit` of root-map byte `mb`.
+static __device__ __forceinline__ long loc_elem(long mb, int bit, int W) {
+    const long wb = loc_wb(W);
+    const long row = mb / wb;
+    return row * W + (mb - row * wb) * 8 + bit;
+}
+
+// Pass 3.  A tile-local root that is no longer a root hands its sums to the final root of its component.
+__global__ __launch_bounds__(256) void locate_fold_kernel(const int* __restrict__ L, unsigned* __restrict__ cnt,
+                                                          u64* __restrict__ sr, u64* __restrict__ sc,
+                                                          const unsigned char* __restrict__ rmap, long map_bytes,
+                                                          long live_bytes, int W) {
+    const long b0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * LOC_MB;
+    if (b0 >= map_bytes) return;
+    u64 bits = *reinterpret_cast<const u64*>(rmap + b0);
+    if (b0 + LOC_MB > live_bytes) bits &= b0 >= live_bytes ? 0ull : ((1ull << (8 * (live_bytes - b0))) - 1ull);
+    while (bits) {
+        const int q = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const long e = loc_elem(b0 + (q >> 3), q & 7, W);
+        const int p = L[e];
+        if (p == (int)e) continue;
+        const int g = loc_find(L, p);
+        atomicAdd(cnt + g, cnt[e]);
+        atomicAdd(sr + g, sr[e]);
+        atomicAdd(sc + g, sc[e]);
+    }
 }
 
 // A root survives when its centre is not within dist_edge of the border (predictor.py:625-633, fp64 compares).
@@ -134,18 +274,33 @@ static __device__ __forceinline__ bool loc_keep(const int* L, const unsigned* cn
              c < (double)dist_edge);
 }
 
+// The 64 root-map bits of thread `threadIdx.x` of chunk `blockIdx.x` (bytes past the live map read as zero).
+static __device__ __forceinline__ u64 loc_chunk_bits(const unsigned char* rmap, long map_bytes, long live_bytes, long* b0_out) {
+    const long b0 = (long)blockIdx.x * LOC_CHUNK + (long)threadIdx.x * LOC_MB;
+    *b0_out = b0;
+    if (b0 >= map_bytes) return 0ull;
+    u64 bits = *reinterpret_cast<const u64*>(rmap + b0);
+    if (b0 + LOC_MB > live_bytes) bits &= b0 >= live_bytes ? 0ull : ((1ull << (8 * (live_bytes - b0))) - 1ull);
+    return bits;
+}
+
 __global__ __launch_bounds__(256) void locate_count_kernel(const int* __restrict__ L, const unsigned* __restrict__ cnt,
                                                            const u64* __restrict__ sr, const u64* __restrict__ sc,
-                                                           int* __restrict__ chunk_cnt, long ne, int H, int W,
+                                                           const unsigned char* __restrict__ rmap, long map_bytes,
+                                                           long live_bytes, int* __restrict__ chunk_cnt, int H, int W,
                                                            int dist_edge) {
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
-    const long e0 = (long)blockIdx.x * LOC_CHUNK + (long)threadIdx.x * LOC_STRIP;
+    long b0;
+    u64 bits = loc_chunk_bits(rmap, map_bytes, live_bytes, &b0);
     int mine = 0;
     double r, c;
-    for (int j = 0; j < LOC_STRIP; ++j)
-        if (e0 + j < ne && loc_keep(L, cnt, sr, sc, e0 + j, H, W, dist_edge, &r, &c)) ++mine;
+    while (bits) {
+        const int q = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (loc_keep(L, cnt, sr, sc, loc_elem(b0 + (q >> 3), q & 7, W), H, W, dist_edge, &r, &c)) ++mine;
+    }
     if (mine) atomicAdd(&total, mine);
     __syncthreads();
     if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
@@ -180,16 +335,21 @@ __global__ __launch_bounds__(1024) void locate_scan_kernel(int* __restrict__ chu
 
 __global__ __launch_bounds__(256) void locate_emit_kernel(const int* __restrict__ L, const unsigned* __restrict__ cnt,
                                                           const u64* __restrict__ sr, const u64* __restrict__ sc,
-                                                          const int* __restrict__ chunk_off, double* __restrict__ coords,
-                                                          int* __restrict__ meta, long cap, long ne, int H, int W,
-                                                          int nch, int dist_edge) {
+                                                          const unsigned char* __restrict__ rmap, long map_bytes,
+                                                          long live_bytes, const int* __restrict__ chunk_off,
+                                                          double* __restrict__ coords, int* __restrict__ meta, long cap,
+                                                          int H, int W, int nch, int dist_edge) {
     __shared__ int pre[256];
-    const long e0 = (long)blockIdx.x * LOC_CHUNK + (long)threadIdx.x * LOC_STRIP;
-    double rr[LOC_STRIP], cc[LOC_STRIP];
-    unsigned mask = 0;
+    long b0;
+    const u64 all = loc_chunk_bits(rmap, map_bytes, live_bytes, &b0);
+    u64 keep = 0;
     int mine = 0;
-    for (int j = 0; j < LOC_STRIP; ++j)
-        if (e0 + j < ne && loc_keep(L, cnt, sr, sc, e0 + j, H, W, dist_edge, &rr[j], &cc[j])) { mask |= 1u << j; ++mine; }
+    double r, c;
+    for (u64 bits = all; bits;) {
+        const int q = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (loc_keep(L, cnt, sr, sc, loc_elem(b0 + (q >> 3), q & 7, W), H, W, dist_edge, &r, &c)) { keep |= 1ull << q; ++mine; }
+    }
     pre[threadIdx.x] = mine;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
@@ -199,13 +359,15 @@ __global__ __launch_bounds__(256) void locate_emit_kernel(const int* __restrict_
         __syncthreads();
     }
     long o = (long)chunk_off[blockIdx.x] + pre[threadIdx.x] - mine;
-    for (int j = 0; j < LOC_STRIP; ++j) {
-        if (!(mask & (1u << j))) continue;
+    while (keep) {
+        const int q = __builtin_ctzll(keep);
+        keep &= keep - 1;
         if (o < cap) {
-            const long e = e0 + j;
+            const long e = loc_elem(b0 + (q >> 3), q & 7, W);
+            loc_keep(L, cnt, sr, sc, e, H, W, dist_edge, &r, &c);
             const long fc = e / ((long)H * W);            // = b*nch + c
-            coords[2 * o] = rr[j];
-            coords[2 * o + 1] = cc[j];
+            coords[2 * o] = r;
+            coords[2 * o + 1] = c;
             meta[2 * o] = (int)(fc / nch);
             meta[2 * o + 1] = (int)(fc % nch);
         }
@@ -218,7 +380,8 @@ extern "C" long amx_locate_workspace_bytes(int B, int H, int W, int nch) {
     if (B <= 0 || H <= 0 || W <= 0 || nch <= 0) AMX_BADARG(1);
     const long ne = (long)B * nch * H * W;
     if (ne >= 2147483647L) AMX_BADARG(2);                // int32 labels: chunk the stack on the host
-    return ne * 24 + (loc_nchunks(ne) + 1) * 4 + 64;
+    const long mb = loc_map_bytes((long)B * nch * H, W);
+    return ne * 24 + 8 + mb + (loc_nchunks(mb) + 1) * 4 + 64;
 }
 
 extern "C" int amx_locate_label(const float* prob, int B, int H, int W, int C, int nch, float thr, int dist_edge,
@@ -228,15 +391,27 @@ extern "C" int amx_locate_label(const float* prob, int B, int H, int W, int C, i
     const long ne = (long)B * nch * H * W;
     if (ne >= 2147483647L) AMX_BADARG(3);
     if ((uintptr_t)work & 7) AMX_BADARG(4);
-    const LocWork w = loc_views(work, ne);
+    const long planes = (long)B * nch;
+    const long live = planes * H * loc_wb(W), mb = loc_map_bytes(planes * H, W);
+    const LocWork w = loc_views(work, ne, mb);
     hipStream_t s = (hipStream_t)stream;
-    const unsigned g1 = (unsigned)((ne + 255) / 256);
-    AMX_LAUNCH(locate_init_kernel, dim3(g1), dim3(256), 0, s, prob, w.L, w.cnt, w.sr, w.sc, ne, H, W, C, nch, thr);
-    AMX_LAUNCH(locate_merge_kernel, dim3(g1), dim3(256), 0, s, w.L, ne, H, W);
-    const long nchunks = loc_nchunks(ne);
-    AMX_LAUNCH(locate_flatten_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, w.L, w.cnt, w.sr, w.sc, ne, H, W);
+    const int ntx = amx_ceil_div(W, LT_W), nty = amx_ceil_div(H, LT_H);
+    const long tiles = planes * ntx * nty;
+    if (tiles >= 2147483647L) AMX_BADARG(5);
+    AMX_LAUNCH(locate_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, prob, w.L, w.cnt, w.sr, w.sc, w.rmap, H, W, C,
+               nch, thr, ntx, nty);
+    const long per_plane = (long)(nty - 1) * W + (long)(ntx - 1) * H;
+    if (per_plane > 0) {
+        const long total = per_plane * planes;
+        AMX_LAUNCH(locate_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w.L, H, W, ntx, nty,
+                   per_plane, total);
+        AMX_LAUNCH(locate_fold_kernel, dim3((unsigned)((mb / LOC_MB + 255) / 256)), dim3(256), 0, s, (const int*)w.L, w.cnt,
+                   w.sr, w.sc, (const unsigned char*)w.rmap, mb, live, W);
+    }
+    const long nchunks = loc_nchunks(mb);
     AMX_LAUNCH(locate_count_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, (const int*)w.L,
-               (const unsigned*)w.cnt, (const u64*)w.sr, (const u64*)w.sc, w.chunk_off, ne, H, W, dist_edge);
+               (const unsigned*)w.cnt, (const u64*)w.sr, (const u64*)w.sc, (const unsigned char*)w.rmap, mb, live,
+               w.chunk_off, H, W, dist_edge);
     AMX_LAUNCH(locate_scan_kernel, dim3(1), dim3(1024), 0, s, w.chunk_off, nchunks, count);
     AMX_CHECK_LAUNCH();
     return 0;
@@ -249,10 +424,12 @@ extern "C" int amx_locate_emit(const void* work, int B, int H, int W, int nch, i
     const long ne = (long)B * nch * H * W;
     if (ne >= 2147483647L) AMX_BADARG(3);
     if (cap == 0) return 0;
-    const LocWork w = loc_views(const_cast<void*>(work), ne);
-    AMX_LAUNCH(locate_emit_kernel, dim3((unsigned)loc_nchunks(ne)), dim3(256), 0, (hipStream_t)stream,
+    const long planes = (long)B * nch;
+    const long live = planes * H * loc_wb(W), mb = loc_map_bytes(planes * H, W);
+    const LocWork w = loc_views(const_cast<void*>(work), ne, mb);
+    AMX_LAUNCH(locate_emit_kernel, dim3((unsigned)loc_nchunks(mb)), dim3(256), 0, (hipStream_t)stream,
                (const int*)w.L, (const unsigned*)w.cnt, (const u64*)w.sr, (const u64*)w.sc,
-               (const int*)w.chunk_off, coords, meta, cap, ne, H, W, nch, dist_edge);
+               (const unsigned char*)w.rmap, mb, live, (const int*)w.chunk_off, coords, meta, cap, H, W, nch, dist_edge);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -48,6 +48,28 @@ def check_shapes(device, big=False):
     zeros = np.zeros((2, 24, 40, 2), dtype=np.float32)
     got = Locator(0.5, 2, device=device).run(zeros)
     assert all(v.shape == (0, 3) for v in got.values()) and len(got) == 2
+    # tile borders of the device labelling (32 x 64-pixel tiles, 8-pixel strips): everything foreground over several
+    # tiles (every border pair present -> the de-duplication rule at the four-tile corners), a checkerboard (the
+    # maximum number of components: every foreground pixel is a root), sides that are exact multiples of the tile,
+    # a comb and a serpentine whose teeth / turns cross the tile borders (components made of many tile-local parts)
+    ones_mt = np.ones((1, 70, 140, 2), dtype=np.float32)
+    _same(Locator(0.5, 3, device=device).run(ones_mt), lo.locate(ones_mt, 0.5, 3))
+    yy, xx = np.mgrid[0:40, 0:72]
+    cb = np.zeros((1, 40, 72, 2), dtype=np.float32)
+    cb[0, :, :, 0] = (yy + xx) % 2
+    _same(Locator(0.5, 0, device=device).run(cb), lo.locate(cb, 0.5, 0))
+    exact = (rs.rand(2, 64, 128, 2) > 0.42).astype(np.float32)
+    _same(Locator(0.5, 1, device=device).run(exact), lo.locate(exact, 0.5, 1))
+    comb = np.zeros((1, 100, 200, 3), dtype=np.float32)
+    comb[0, 97, 1:199, 0] = 1
+    comb[0, 3:98, 1:199:2, 0] = 1                      # teeth two pixels apart, joined only by the bottom row
+    comb[0, 2:99, 5, 1] = 1
+    for k, r in enumerate(range(2, 99, 2)):            # serpentine: rows joined alternately at the right / left end
+        comb[0, r, 5:195, 1] = 1
+        comb[0, r + 1, 194 if k % 2 == 0 else 5, 1] = 1
+    comb[0, 2:99, 5, 1] = 0
+    comb[0, 2:99:2, 5, 1] = 1
+    _same(Locator(0.5, 0, device=device).run(comb), lo.locate(comb, 0.5, 0))
     # spiral: one component whose first pixel is far from most of its mass
     sp = np.zeros((1, 41, 41, 2), dtype=np.float32)
     r0, r1, c0, c1 = 2, 38, 2, 38
