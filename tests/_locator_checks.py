@@ -58,6 +58,10 @@ def check_shapes(device, big=False):
     cb = np.zeros((1, 40, 72, 2), dtype=np.float32)
     cb[0, :, :, 0] = (yy + xx) % 2
     _same(Locator(0.5, 0, device=device).run(cb), lo.locate(cb, 0.5, 0))
+    many = (rs.rand(2, 100, 200, 3) > 0.43).astype(np.float32)     # more tiles than persistent workgroups (emulator)
+    _same(Locator(0.5, 2, device=device).run(many), lo.locate(many, 0.5, 2))
+    onech = (rs.rand(3, 72, 136, 1) > 0.45).astype(np.float32)      # 1-channel maps, W % 8 == 0: the vector-load path
+    _same(Locator(0.5, 2, device=device).run(onech), lo.locate(onech, 0.5, 2))
     exact = (rs.rand(2, 64, 128, 2) > 0.42).astype(np.float32)
     _same(Locator(0.5, 1, device=device).run(exact), lo.locate(exact, 0.5, 1))
     comb = np.zeros((1, 100, 200, 3), dtype=np.float32)
