@@ -6,6 +6,7 @@
 //   c1 = ConvBlock(2, nbl[0], 1, nb_filters): Conv2d(1, F, 3, padding=1) -> LeakyReLU -> BN stats
 //                                                   atomai/nets/fcnn.py:66-69, 186-189; blocks.py:61-76
 #include "amx_device.h"
+#include <cstdlib>
 #ifndef AMX_CONV1_UNROLL
 #define AMX_CONV1_UNROLL 4      // weight gradient: pixels of a thread in flight together (a thread walks rows_pix / PL
                                 // pixels, each a global-load round trip): 192 -> 160 us per launch at bs 32, 512^2
@@ -16,6 +17,11 @@
 #ifndef AMX_CONV1_FAST
 #define AMX_CONV1_FAST 1        // compile-time experiment switch: interior pixels skip the per-tap bounds arithmetic
 #endif
+
+#ifndef AMX_CONV1_LDS
+#define AMX_CONV1_LDS 1         // the block's pixel range + one halo row either side staged in LDS (see stage_image)
+#endif
+#define CONV1_STAGE_MAX 12288   // floats (48 KB): wider images fall back to direct global loads
 
 // Per-thread shifted sums for 4 channels: d = x - K with K = the first value the thread sees, so that
 // M2 = sum d^2 - (sum d)^2 / n is free of catastrophic cancellation; merged across the block with Chan's formula.
@@ -69,14 +75,44 @@ static __device__ __forceinline__ void load_3x3(const float* __restrict__ img, i
     }
 }
 
+// LDS staging of the single-channel input (round 3).  A block owns the LINEAR pixel range [p0, p1); every tap of every
+// pixel of that range lies in [p0 - halo, p1 + halo) with halo = dil * (W + 1), so the block copies that range once with
+// coalesced loads (positions outside the tensor read as 0; row / image borders are still masked per tap by the caller)
+// and the pixel loop reads its 9 taps from LDS.  The direct form issued 9 dependent global loads per pixel and thread
+// and ran at 2.6-2.8 TB/s of output, latency-bound.  Values and FMA order are unchanged.
+// Measured (profiles/r03_conv1_lds_ab.log, in-process): U-Net 32 x 512^2 x 16 forward 238 -> 174 us; dilnet predict
+// 16 x 1024^2 x 28 (no statistics, input normalisation on load) 818 -> 426 us = 4.4 TB/s of output.  The weight-gradient
+// kernel, which already keeps 4 pixels (36 loads) in flight per thread, got SLOWER with the same staging (158 -> 175 us)
+// and stays on direct loads.
+static __device__ __forceinline__ void stage_image(float* s_in, const float* __restrict__ x, long p0, long npix, int halo,
+                                                   int len, bool norm, float in_sub, float in_div) {
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const long q = p0 - halo + i;
+        float v = (q >= 0 && q < npix) ? x[q] : 0.f;
+        if (norm) { const float d = v - in_sub; v = d / in_div; }
+        s_in[i] = v;
+    }
+    __syncthreads();
+}
+static __device__ __forceinline__ void taps_lds(const float* s_in, int o, int yy, int xx, int H, int W, int dil, float v[9]) {
+    const bool oky[3] = {yy - dil >= 0, true, yy + dil < H}, okx[3] = {xx - dil >= 0, true, xx + dil < W};
+    #pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float u = s_in[o + (t / 3 - 1) * W * dil + (t % 3 - 1) * dil];
+        v[t] = (oky[t / 3] && okx[t % 3]) ? u : 0.f;
+    }
+}
+
 // x [N][H][W] (single channel), w OIHW [Cout][1][3][3], y NHWC [P][Cs].
 // Block b owns pixels [b*ppb, (b+1)*ppb); stats row b = (sum, M2 about the row mean) per channel.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, float* __restrict__ stats,
                                                         int N, int H, int W, int Cout, int Cs, int dil,
-                                                        float slope, int ppb, int cop, float in_sub, float in_div) {
+                                                        float slope, int ppb, int cop, float in_sub, float in_div,
+                                                        int stage_len) {
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
@@ -102,6 +138,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
     const bool norm = !(in_sub == 0.f && in_div == 1.f);     // uniform: training never normalises here
     Sh4 st; st.K = make_float4(0, 0, 0, 0); st.s1 = st.K; st.s2 = st.K; st.n = 0.f;
+    const int halo = dil * (W + 1);
+    if (STAGED) stage_image(s, x, p0, npix, halo, stage_len, norm, in_sub, in_div);      // (aliases the statistics rows)
     if (active)
     {
         PixCursor cur; cur.init(p0 + pl < npix ? p0 + pl : 0, H, W);
@@ -114,8 +152,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int u = 0; u < U; ++u) {
                 ok[u] = p + (long)u * PL < p1;
                 const long ni = ok[u] ? cur.nimg : 0;
-                load_3x3<true>(x + (size_t)ni * H * W, ok[u] ? cur.yy : 0, ok[u] ? cur.xx : 0, H, W, dil, xv[u], norm,
-                               in_sub, in_div);
+                if (STAGED) taps_lds(s, (int)((ok[u] ? p + (long)u * PL : p0) - p0) + halo, ok[u] ? cur.yy : 0, ok[u] ? cur.xx : 0, H, W, dil, xv[u]);
+                else load_3x3<true>(x + (size_t)ni * H * W, ok[u] ? cur.yy : 0, ok[u] ? cur.xx : 0, H, W, dil, xv[u], norm,
+                                    in_sub, in_div);
                 if (ok[u]) cur.advance(PL, H, W);
             }
             #pragma unroll
@@ -136,33 +175,58 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         }
     }
     if (!stats) return;
-    if (active) {
-        const float inv = st.n > 0.f ? 1.f / st.n : 0.f;
-        float4 mean, m2;
+    if (STAGED) __syncthreads();                  // every thread is done with the staged image: its LDS becomes the rows below
+    // Block statistics: Chan merges of the PL per-thread (mean, M2, n) triples of every channel group, as a binary
+    // tree over the pixel lanes (fixed order, 6-8 rounds on all lanes).  The round-1/2 form walked the PL rows serially
+    // on Cs threads while the other 240 waited: ~40 % of a training-mode block's life.
+    float4 mean = make_float4(0, 0, 0, 0), m2 = mean;
+    float n = 0.f;
+    if (active && st.n > 0.f) {
+        const float inv = 1.f / st.n;
+        n = st.n;
         mean.x = st.K.x + st.s1.x * inv; m2.x = st.s2.x - st.s1.x * st.s1.x * inv;
         mean.y = st.K.y + st.s1.y * inv; m2.y = st.s2.y - st.s1.y * st.s1.y * inv;
         mean.z = st.K.z + st.s1.z * inv; m2.z = st.s2.z - st.s1.z * st.s1.z * inv;
         mean.w = st.K.w + st.s1.w * inv; m2.w = st.s2.w - st.s1.w * st.s1.w * inv;
-        amx_st4(s + ((size_t)(pl * 3 + 0) * Cs + cg * 4), mean);
-        amx_st4(s + ((size_t)(pl * 3 + 1) * Cs + cg * 4), m2);
-        s[(size_t)(pl * 3 + 2) * Cs + cg * 4] = st.n;
     }
-    __syncthreads();
-    for (int c = tid; c < Cs; c += 256) {
-        const int cgc = c >> 2;
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int q = 0; q < PL; ++q) {
-            const float nq = s[(size_t)(q * 3 + 2) * Cs + cgc * 4];
-            if (nq == 0.f) continue;
-            const float mq = s[(size_t)(q * 3 + 0) * Cs + c], m2q = s[(size_t)(q * 3 + 1) * Cs + c];
-            const float nt = n + nq, d = mq - mean;
-            mean += d * (nq / nt);
-            m2 += m2q + d * d * (n * nq / nt);
-            n = nt;
+    int span = 1;
+    while (span < PL) span <<= 1;
+    for (int half = span >> 1; half >= 1; half >>= 1) {
+        if (active && pl >= half && pl < 2 * half) {       // rows [half, 2 half) hand over to rows [0, half)
+            amx_st4(s + ((size_t)(pl * 3 + 0) * Cs + cg * 4), mean);
+            amx_st4(s + ((size_t)(pl * 3 + 1) * Cs + cg * 4), m2);
+            s[(size_t)(pl * 3 + 2) * Cs + cg * 4] = n;
         }
-        stats[((size_t)blockIdx.x * 2 + 0) * cop + c] = mean * n;
-        stats[((size_t)blockIdx.x * 2 + 1) * cop + c] = m2;
+        __syncthreads();
+        if (active && pl < half && pl + half < PL) {
+            const int q = pl + half;
+            const float nq = s[(size_t)(q * 3 + 2) * Cs + cg * 4];
+            if (nq > 0.f) {
+                const float4 mq = amx_ld4(s + ((size_t)(q * 3 + 0) * Cs + cg * 4));
+                const float4 m2q = amx_ld4(s + ((size_t)(q * 3 + 1) * Cs + cg * 4));
+                const float nt = n + nq, f = nq / nt, g2 = n * nq / nt;
+                float d;
+                d = mq.x - mean.x; mean.x += d * f; m2.x += m2q.x + d * d * g2;
+                d = mq.y - mean.y; mean.y += d * f; m2.y += m2q.y + d * d * g2;
+                d = mq.z - mean.z; mean.z += d * f; m2.z += m2q.z + d * d * g2;
+                d = mq.w - mean.w; mean.w += d * f; m2.w += m2q.w + d * d * g2;
+                n = nt;
+            }
+        }
+        __syncthreads();
     }
+    if (active && pl == 0) {
+        amx_st4(stats + ((size_t)blockIdx.x * 2 + 0) * cop + cg * 4, make_float4(mean.x * n, mean.y * n, mean.z * n, mean.w * n));
+        amx_st4(stats + ((size_t)blockIdx.x * 2 + 1) * cop + cg * 4, m2);
+    }
+}
+
+// floats of the staged range of a block (0 = direct loads: switched off, or the range does not fit)
+static int conv1_stage_len(int ppb, int W, int dil) {
+    if (!AMX_CONV1_LDS) return 0;
+    if (const char* e = getenv("AMX_CONV1_LDS")) if (atoi(e) == 0) return 0;
+    const long len = (long)ppb + 2L * dil * (W + 1);
+    return len <= CONV1_STAGE_MAX ? (int)len : 0;
 }
 
 extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
@@ -173,9 +237,17 @@ extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, 
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
     const int PL = 256 / (Cs / 4);
-    AMX_LAUNCH(conv1_fwd_kernel, dim3(rows), dim3(256), (size_t)PL * 3 * Cs * sizeof(float),
-               (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
-               amx_round_up(Cout, 16), in_sub, in_div);
+    const int stage_len = conv1_stage_len(rows_pix, W, dil);
+    size_t lds = (size_t)PL * 3 * Cs * sizeof(float);
+    if ((size_t)stage_len * sizeof(float) > lds) lds = (size_t)stage_len * sizeof(float);
+    if (stage_len)
+        AMX_LAUNCH(conv1_fwd_kernel<true>, dim3(rows), dim3(256), lds,
+                   (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
+                   amx_round_up(Cout, 16), in_sub, in_div, stage_len);
+    else
+        AMX_LAUNCH(conv1_fwd_kernel<false>, dim3(rows), dim3(256), lds,
+                   (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
+                   amx_round_up(Cout, 16), in_sub, in_div, stage_len);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -194,7 +266,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
     const bool active = pl < PL;
-    AMX_DYN_SMEM(float, s);                       // [PL][Cs] (one tap at a time)
+    AMX_DYN_SMEM(float, s);                       // [nrow][PL][Cs]
     const long npix = (long)N * H * W;
     const long p0 = (long)blockIdx.x * ppb;
     const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
@@ -242,18 +314,19 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             }
         }
     }
+    // all tap rows (+ the bias row) of every pixel lane go to LDS at once, then nrow * Cs threads each sum one column
+    // over the PL lanes in lane order (the same order, hence the same bits, as the round-1/2 form, which did this one
+    // tap at a time on Cs threads with two barriers per tap: 10 serial rounds of a 64-step sum were longer than the
+    // block's pixel loop)
     #pragma unroll
-    for (int t = 0; t < 10; ++t) {
-        if (t < nrow) {                              // (uniform; no `break`, so that the loop unrolls and acc stays in registers)
-            if (active) amx_st4(s + ((size_t)pl * Cs + cg * 4), acc[t]);
-            __syncthreads();
-            for (int c = tid; c < Cs; c += 256) {
-                float a = 0.f;
-                for (int q = 0; q < PL; ++q) a += s[(size_t)q * Cs + c];
-                part[((size_t)blockIdx.x * nrow + t) * Cs + c] = a;
-            }
-            __syncthreads();
-        }
+    for (int t = 0; t < 10; ++t)
+        if (t < nrow && active) amx_st4(s + ((size_t)(t * PL + pl) * Cs + cg * 4), acc[t]);
+    __syncthreads();
+    for (int i = tid; i < nrow * Cs; i += 256) {
+        const int t = i / Cs, c = i - t * Cs;
+        float a = 0.f;
+        for (int q = 0; q < PL; ++q) a += s[(size_t)(t * PL + q) * Cs + c];
+        part[((size_t)blockIdx.x * nrow + t) * Cs + c] = a;
     }
 }
 
@@ -263,7 +336,7 @@ extern "C" int amx_conv1_wgrad(const float* x, const float* dpre, float* part, i
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
     const int PL = 256 / (Cs / 4);
-    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)PL * Cs * sizeof(float),
+    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)9 * PL * Cs * sizeof(float),
                (hipStream_t)stream, x, dpre, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                (const float*)nullptr, 1.f, part, N, H, W, Cs, dil, rows_pix, 9);
     AMX_CHECK_LAUNCH();
@@ -279,7 +352,7 @@ extern "C" int amx_conv1_wgrad_fused(const float* x, const float* dy, const floa
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(3);
     const int PL = 256 / (Cs / 4);
-    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)PL * Cs * sizeof(float),
+    AMX_LAUNCH(conv1_wgrad_kernel, dim3(rows), dim3(256), (size_t)10 * PL * Cs * sizeof(float),
                (hipStream_t)stream, x, dy, aux, k1, k2, k3, bslope, part, N, H, W, Cs, dil, rows_pix, 10);
     AMX_CHECK_LAUNCH();
     return 0;

@@ -34,6 +34,20 @@ def timed(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+# first-layer kernels with / without the LDS-staged neighbourhoods (AMX_CONV1_LDS is read per call), U-Net and dilnet shapes
+xd = torch.rand(16, 1, 1024, 1024, device=dev); wd = torch.randn(25, 1, 3, 3, device=dev); bd = torch.randn(25, device=dev)
+yd = torch.empty(16, 1024, 1024, 28, device=dev)
+rd, rpd = lib0.amx_rows_for(16 * 1024 * 1024), lib0.amx_rows_pix(16 * 1024 * 1024)
+for rep in range(2):
+    for mode in ("0", "1"):
+        os.environ["AMX_CONV1_LDS"] = mode
+        t = {}
+        t["conv1_fwd"] = timed(lambda: L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(y), L.ptr(stats), N, H, W, C, Cs, 1, 0.01, rows, rows_pix, 0.0, 1.0, sp))
+        t["conv1_wgrad"] = timed(lambda: L.call("amx_conv1_wgrad", L.ptr(x), L.ptr(dpre), L.ptr(part1), N, H, W, Cs, 1, rows, rows_pix, sp))
+        t["dilnet conv1_fwd eval 16x1024^2x28"] = timed(lambda: L.call("amx_conv1_fwd", L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(yd), None, 16, 1024, 1024, 25, 28, 1, 0.01, rd, rpd, 0.1, 0.8, sp))
+        print(f"AMX_CONV1_LDS={mode}: " + "  ".join(f"{k} {v:7.1f} us" for k, v in t.items()), flush=True)
+os.environ.pop("AMX_CONV1_LDS", None)
+
 libs = {"": lib0}
 for name in sys.argv[1:]:
     libs[name] = L._bind(ctypes.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), f"libatomai_amd_{name}.so")))
