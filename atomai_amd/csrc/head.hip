@@ -11,6 +11,10 @@
                                 // vs 149 us -> the division stays (a 32-bit division behind an `npix < 2^32` test: 461 us)
 #endif
 
+#ifndef AMX_PX_BWD_UNROLL
+#define AMX_PX_BWD_UNROLL 4     // pixels of a thread in flight in px_bwd (profiles/r03_px_bwd_ab.log: class-templated 307 -> 235 us, 4 in flight 226)
+#endif
+
 #define MAXCLS 8
 
 // ------------------------------------------------------------------ px forward
@@ -90,6 +94,9 @@ extern "C" int amx_px_fwd(const float* a, const float* scale, const float* shift
 
 // ------------------------------------------------------------------ px backward
 // dxn[p][c] = sum_k dl[n][k][hw] * W[k][c];  partial rows: part[blk][K][Cs] (dW) and partb[blk][K] (db)
+// KT: compile-time bound of the class loops (K itself for K <= 4 — the reference's nets have 1-3 classes — else MAXCLS):
+// with the loops bounded by MAXCLS the per-class registers of 8 classes were live (122 VGPRs at one pixel in flight).
+template <int KT>
 __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ dl,
                                                      const float* __restrict__ a,
                                                      const float* __restrict__ scale,
@@ -104,13 +111,13 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
     const bool active = pl < PL;
     AMX_DYN_SMEM(float, s);                       // [PL][K][Cs] + [PL][K] + [2][PL][Cs]
     float4 bs1 = make_float4(0, 0, 0, 0), bs2 = make_float4(0, 0, 0, 0);   // sum dxn, sum dxn * a (raw)
-    float4 dw[MAXCLS];
-    float db[MAXCLS];
+    float4 dw[KT];
+    float db[KT];
     #pragma unroll
-    for (int k = 0; k < MAXCLS; ++k) { dw[k] = make_float4(0, 0, 0, 0); db[k] = 0.f; }
-    float4 wk[MAXCLS];
+    for (int k = 0; k < KT; ++k) { dw[k] = make_float4(0, 0, 0, 0); db[k] = 0.f; }
+    float4 wk[KT];
     #pragma unroll
-    for (int k = 0; k < MAXCLS; ++k) {
+    for (int k = 0; k < KT; ++k) {
         wk[k] = make_float4(0, 0, 0, 0);
         if (k < K && active) {
             const int c = cg * 4;
@@ -123,37 +130,50 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
     if (active) {
         float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
         if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
-        // (image, pixel-in-image) of p, advanced with a carry: a 64-bit division per pixel was a third of this
-        // kernel's instructions
-        long n = (p0 + pl) / HW, hw = (p0 + pl) - n * HW;
-        for (long p = p0 + pl; p < p1; p += PL, hw += PL) {
-#if AMX_HEAD_DIV
-            n = p / HW; hw = p - n * HW;
-#else
-            while (hw >= HW) { hw -= HW; ++n; }
-#endif
-            float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
-            const float4 raw = v;
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-            float4 d = make_float4(0, 0, 0, 0);
+        // U pixels of this thread in flight: every load of the U pixels (a: 16 B, dl: K scalars) is issued before the
+        // first FMA; the sums are still formed in pixel order.  With one pixel per iteration the loop was a chain of
+        // ppb / PL global-load round trips per thread (3.7 TB/s).  Loads are unconditional (clamped to the thread's
+        // first pixel of the iteration), see conv1.hip.
+        constexpr int U = AMX_PX_BWD_UNROLL;
+        for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+            float4 av[U];
+            float gv[U][KT];
+            bool ok[U];
             #pragma unroll
-            for (int k = 0; k < MAXCLS; ++k) {
-                if (k >= K) break;
-                const float g = dl[((size_t)n * K + k) * HW + hw];
-                d.x = fmaf(g, wk[k].x, d.x); d.y = fmaf(g, wk[k].y, d.y);
-                d.z = fmaf(g, wk[k].z, d.z); d.w = fmaf(g, wk[k].w, d.w);
-                dw[k].x = fmaf(g, v.x, dw[k].x); dw[k].y = fmaf(g, v.y, dw[k].y);
-                dw[k].z = fmaf(g, v.z, dw[k].z); dw[k].w = fmaf(g, v.w, dw[k].w);
-                db[k] += g;
+            for (int u = 0; u < U; ++u) {
+                ok[u] = p + (long)u * PL < p1;
+                const long pu = ok[u] ? p + (long)u * PL : p;
+                const long n = pu / HW, hw = pu - n * HW;
+                av[u] = amx_ld4(a + (size_t)pu * Cs + cg * 4);
+                #pragma unroll
+                for (int k = 0; k < KT; ++k) gv[u][k] = k < K ? dl[((size_t)n * K + k) * HW + hw] : 0.f;
             }
-            amx_st4(dxn + (size_t)p * Cs + cg * 4, d);
-            bs1.x += d.x; bs1.y += d.y; bs1.z += d.z; bs1.w += d.w;
-            bs2.x = fmaf(d.x, raw.x, bs2.x); bs2.y = fmaf(d.y, raw.y, bs2.y);
-            bs2.z = fmaf(d.z, raw.z, bs2.z); bs2.w = fmaf(d.w, raw.w, bs2.w);
+            #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                float4 v = av[u];
+                const float4 raw = v;
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                float4 d = make_float4(0, 0, 0, 0);
+                #pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    if (k >= K) break;
+                    const float g = gv[u][k];
+                    d.x = fmaf(g, wk[k].x, d.x); d.y = fmaf(g, wk[k].y, d.y);
+                    d.z = fmaf(g, wk[k].z, d.z); d.w = fmaf(g, wk[k].w, d.w);
+                    dw[k].x = fmaf(g, v.x, dw[k].x); dw[k].y = fmaf(g, v.y, dw[k].y);
+                    dw[k].z = fmaf(g, v.z, dw[k].z); dw[k].w = fmaf(g, v.w, dw[k].w);
+                    db[k] += g;
+                }
+                amx_st4(dxn + (size_t)(p + (long)u * PL) * Cs + cg * 4, d);
+                bs1.x += d.x; bs1.y += d.y; bs1.z += d.z; bs1.w += d.w;
+                bs2.x = fmaf(d.x, raw.x, bs2.x); bs2.y = fmaf(d.y, raw.y, bs2.y);
+                bs2.z = fmaf(d.z, raw.z, bs2.z); bs2.w = fmaf(d.w, raw.w, bs2.w);
+            }
         }
         #pragma unroll
-        for (int k = 0; k < MAXCLS; ++k) {
+        for (int k = 0; k < KT; ++k) {
             if (k >= K) break;
             amx_st4(s + ((size_t)(pl * K + k) * Cs + cg * 4), dw[k]);
             if (cg == 0) s[(size_t)PL * K * Cs + pl * K + k] = db[k];
@@ -197,8 +217,17 @@ extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, c
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(4);
     const int PL = 256 / (Cs / 4);
     const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K + 4 + (size_t)2 * PL * Cs) * sizeof(float);
-    AMX_LAUNCH(px_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, dl, a, scale, shift, w, dxn,
-               part, partb, bstats, npix, (long)H * W, C, Cs, K, rows_pix);
+#define PX_BWD_LAUNCH(KT_)                                                                                              \
+    AMX_LAUNCH(px_bwd_kernel<KT_>, dim3(rows), dim3(256), lds, (hipStream_t)stream, dl, a, scale, shift, w, dxn, part, \
+               partb, bstats, npix, (long)H * W, C, Cs, K, rows_pix)
+    switch (K) {
+        case 1: PX_BWD_LAUNCH(1); break;
+        case 2: PX_BWD_LAUNCH(2); break;
+        case 3: PX_BWD_LAUNCH(3); break;
+        case 4: PX_BWD_LAUNCH(4); break;
+        default: PX_BWD_LAUNCH(MAXCLS); break;
+    }
+#undef PX_BWD_LAUNCH
     AMX_CHECK_LAUNCH();
     return 0;
 }
