@@ -158,14 +158,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     const long p0 = (long)blockIdx.x * ppb;
     const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
-    if (m.active)
-        for (long p = p0 + m.pl; p < p1; p += m.PL) {
-            const float4 g = amx_ld4(dy + (size_t)p * Cs + m.cg * 4);
-            const float4 v = amx_ld4(a + (size_t)p * Cs + m.cg * 4);
-            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-            s2.x = fmaf(g.x, v.x, s2.x); s2.y = fmaf(g.y, v.y, s2.y);
-            s2.z = fmaf(g.z, v.z, s2.z); s2.w = fmaf(g.w, v.w, s2.w);
+    if (m.active) {
+        // 4 pixels (8 loads) of a thread in flight; the sums are formed in pixel order as before.  Loads are unconditional
+        // (clamped to the iteration's first pixel) so that none of them is waited for where it is issued (conv1.hip).
+        constexpr int U = 4;
+        for (long p = p0 + m.pl; p < p1; p += (long)m.PL * U) {
+            float4 g[U], v[U];
+            bool ok[U];
+            #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = p + (long)u * m.PL < p1;
+                const size_t o = (size_t)(ok[u] ? p + (long)u * m.PL : p) * Cs + m.cg * 4;
+                g[u] = amx_ld4(dy + o);
+                v[u] = amx_ld4(a + o);
+            }
+            #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                s1.x += g[u].x; s1.y += g[u].y; s1.z += g[u].z; s1.w += g[u].w;
+                s2.x = fmaf(g[u].x, v[u].x, s2.x); s2.y = fmaf(g[u].y, v[u].y, s2.y);
+                s2.z = fmaf(g[u].z, v[u].z, s2.z); s2.w = fmaf(g[u].w, v[u].w, s2.w);
+            }
         }
+    }
     if (m.active) {
         amx_st4(s + ((size_t)m.pl * Cs + m.cg * 4), s1);
         amx_st4(s + ((size_t)(m.PL + m.pl) * Cs + m.cg * 4), s2);
