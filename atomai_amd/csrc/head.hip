@@ -322,6 +322,22 @@ extern "C" int amx_bce_fwd_bwd(const float* logits, const float* target, float* 
     return 0;
 }
 
+// ------------------------------------------------------------------ upstream gradient of the scalar loss
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(float* __restrict__ x, const float* __restrict__ g, long n) {
+    const float f = *g;
+    if (f == 1.0f) return;                       // (uniform) the usual case: nothing is read or written
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= f;
+}
+
+extern "C" int amx_scale_unless_one(float* x, const float* g, long n, void* stream) {
+    if (!x || !g || n <= 0) AMX_BADARG(1);
+    long nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    AMX_LAUNCH(scale_unless_one_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, g, n);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------ IoU confusion counts (SegTrainer.accuracy_fn)
 // The reference's IoU (losses_metrics/metrics.py:16-95) moves logits and labels to the host, thresholds the softmax /
 // sigmoid probabilities at `thresh` (cv2.threshold THRESH_BINARY: p > thresh -> 1), squeezes the channels into a class

@@ -16,6 +16,15 @@ from .. import _lib as L
 LOSS_BLOCKS = [int(os.environ.get("AMX_LOSS_BLOCKS", "4096"))]
 
 
+def _times_upstream(dl, g):
+    """dlogits * (upstream gradient of the scalar loss) without a pass over dlogits when the upstream gradient is 1
+    (``loss.backward()``): the factor is read on the device, nothing synchronises."""
+    if g.numel() == 1 and g.dtype == torch.float32 and g.device == dl.device:
+        L.call("amx_scale_unless_one", L.ptr(dl), L.ptr(g.contiguous()), dl.numel(), L.stream_ptr(dl))
+        return dl
+    return dl * g
+
+
 class _CEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
@@ -37,7 +46,7 @@ class _CEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dl, ctx.dl = ctx.dl, None
-        return dl * g, None
+        return _times_upstream(dl, g), None
 
 
 class _BCEFn(torch.autograd.Function):
@@ -59,7 +68,7 @@ class _BCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dl, ctx.dl = ctx.dl, None
-        return dl * g, None
+        return _times_upstream(dl, g), None
 
 
 class CrossEntropyLoss(nn.Module):

@@ -205,6 +205,10 @@ int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits,
                    int N, int K, long HW, void* stream);
 int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, float* part, int rows,
                     long numel, void* stream);
+/* loss.backward() hands the loss node an upstream gradient g (a device scalar, 1.0 unless the caller scaled the loss:
+ * trainers/trainer.py:203-206).  x *= *g in place — and no pass at all when *g == 1 (the multiplication by one was a
+ * 200 MB read + write of the logits gradient in every training step). */
+int amx_scale_unless_one(float* x, const float* g, long n, void* stream);
 /* IoU of SegTrainer.accuracy_fn (trainers/trainer.py:727-737 -> losses_metrics/metrics.py:16-95): per-image K x K
  * confusion counts of (label, thresholded softmax / sigmoid class map) in one pass over the NCHW logits, replacing the
  * reference's host round trip (cv2.threshold per image + squeeze_channels + torch.bincount).  Exactly one of truth_i64

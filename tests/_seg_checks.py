@@ -382,3 +382,25 @@ def check_wave_specialised_concat(device, monkeypatch, hw=32, batch=2):
         out[ws] = [y.detach().cpu()] + [p.grad.cpu() for p in net.parameters()]
     for a, b in zip(out["1"], out["0"]):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+
+
+def check_loss_upstream_gradient(device):
+    """loss.backward() multiplies the logits gradient by the upstream gradient of the scalar loss: 1.0 takes the
+    no-pass shortcut (amx_scale_unless_one), anything else scales in place — both against torch's own losses in fp64
+    (reference: trainers/trainer.py:203-206 calls loss.backward() on criterion(prob, y))."""
+    import torch.nn.functional as F
+    from atomai_amd.losses_metrics import select_loss
+    rs = np.random.RandomState(3)
+    for ncls in (3, 1):
+        x = torch.from_numpy(rs.randn(2, ncls, 12, 20).astype(np.float32))
+        if ncls == 1:
+            y = torch.from_numpy((rs.rand(2, 1, 12, 20) > 0.5).astype(np.float32))
+        else:
+            y = torch.from_numpy(rs.randint(0, ncls, (2, 12, 20)))
+        for factor in (1.0, 0.37, -2.0):
+            xd = x.clone().to(device).requires_grad_(True)
+            (select_loss("ce", ncls)(xd, y.to(device)) * factor).backward()
+            xr = x.double().requires_grad_(True)
+            ref = F.cross_entropy(xr, y) if ncls > 1 else F.binary_cross_entropy_with_logits(xr, y.double())
+            (ref * factor).backward()
+            assert relmax(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-6, (ncls, factor)

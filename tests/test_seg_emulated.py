@@ -172,3 +172,7 @@ def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
 
 def test_wave_specialised_two_source_layer(monkeypatch):
     C.check_wave_specialised_concat("cpu", monkeypatch)
+
+
+def test_loss_upstream_gradient_factor():
+    C.check_loss_upstream_gradient("cpu")

@@ -268,3 +268,8 @@ def test_wave_specialised_thin_conv(cin, cout, monkeypatch):
 @pytest.mark.gpu
 def test_wave_specialised_two_source_layer(monkeypatch):
     C.check_wave_specialised_concat("cuda", monkeypatch, hw=128, batch=12)
+
+
+@pytest.mark.gpu
+def test_loss_upstream_gradient_factor():
+    C.check_loss_upstream_gradient("cuda")
