@@ -25,7 +25,7 @@ def test_io_rvae(tmp_path):
 
 def test_ensemble_trainer_matches_reference(tmp_path):
     import _ensemble_checks as E
-    E.check_ensemble(tmp_path)
+    E.check_ensemble(tmp_path, tol=3e-2)
 
 
 def test_ensemble_predictor_matches_reference():
