@@ -32,7 +32,7 @@ def _close(sd, g, prefix, xt):
         with torch.no_grad():
             outs.append(net(xt.to(next(net.parameters()).device)).cpu().numpy())
     err = np.abs(outs[0] - outs[1]).max() / np.abs(outs[0]).max()
-    assert err < 5e-3, (prefix, err)
+    assert err < TOL[0], (prefix, err, TOL[0])
 
 
 def check_ensemble(tmp_path, tol=5e-3):
