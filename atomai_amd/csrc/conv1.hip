@@ -105,14 +105,15 @@ static __device__ __forceinline__ void taps_lds(const float* s_in, int o, int yy
 
 // x [N][H][W] (single channel), w OIHW [Cout][1][3][3], y NHWC [P][Cs].
 // Block b owns pixels [b*ppb, (b+1)*ppb); stats row b = (sum, M2 about the row mean) per channel.
-template <bool STAGED>
+template <bool STAGED, bool POOL>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, float* __restrict__ stats,
                                                         int N, int H, int W, int Cout, int Cs, int dil,
                                                         float slope, int ppb, int cop, float in_sub, float in_div,
-                                                        int stage_len) {
+                                                        int stage_len, float* __restrict__ pool_out,
+                                                        const float* __restrict__ pscale, const float* __restrict__ pshift) {
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
@@ -174,6 +175,45 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             }
         }
     }
+    // Eval mode, block followed by F.max_pool2d(x, 2, 2) (fcnn.py:123, 219): the pooled, NORMALISED tensor is produced here
+    // as well — the four convolution outputs of a window are recomputed from the staged image (16 LDS reads, 144 FMAs per
+    // 4 channels: the kernel is bound by its stores, not by the VALU), the BatchNorm affine is applied before the max and the
+    // maximum is taken in pool_fwd_kernel's order, so the result is bit-identical to amx_pool2x2_fwd of y.  Saves reading
+    // y back (the largest activation of the net) and a launch.  The launcher guarantees whole row pairs per block.
+    if (STAGED && POOL && active) {
+        const int Wo = W >> 1;
+        const long row0 = p0 / W;                            // global row (n * H + y) of the block's first row: even
+        const int npool = (int)((p1 - p0) / W >> 1) * Wo;
+        const float4 sc = amx_ld4(pscale + cg * 4), sh = amx_ld4(pshift + cg * 4);
+        for (int j = pl; j < npool; j += PL) {
+            const int pr = j / Wo, px = j - pr * Wo;
+            const long grow = row0 + 2 * pr;
+            const int yy = (int)(grow % H);
+            float4 best = make_float4(0, 0, 0, 0);
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float xv[9];
+                taps_lds(s, (2 * pr + (k >> 1)) * W + 2 * px + (k & 1) + halo, yy + (k >> 1), 2 * px + (k & 1), H, W, dil, xv);
+                float4 acc = b4;
+                #pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float v = xv[t];
+                    acc.x = fmaf(v, wt[t].x, acc.x); acc.y = fmaf(v, wt[t].y, acc.y);
+                    acc.z = fmaf(v, wt[t].z, acc.z); acc.w = fmaf(v, wt[t].w, acc.w);
+                }
+                acc.x = acc.x > 0.f ? acc.x : acc.x * slope; acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+                acc.z = acc.z > 0.f ? acc.z : acc.z * slope; acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+                acc.x = fmaf(acc.x, sc.x, sh.x); acc.y = fmaf(acc.y, sc.y, sh.y);
+                acc.z = fmaf(acc.z, sc.z, sh.z); acc.w = fmaf(acc.w, sc.w, sh.w);
+                if (k == 0) best = acc;
+                else {
+                    best.x = acc.x > best.x ? acc.x : best.x; best.y = acc.y > best.y ? acc.y : best.y;
+                    best.z = acc.z > best.z ? acc.z : best.z; best.w = acc.w > best.w ? acc.w : best.w;
+                }
+            }
+            amx_st4(pool_out + ((size_t)(grow >> 1) * Wo + px) * Cs + cg * 4, best);
+        }
+    }
     if (!stats) return;
     if (STAGED) __syncthreads();                  // every thread is done with the staged image: its LDS becomes the rows below
     // Block statistics: Chan merges of the PL per-thread (mean, M2, n) triples of every channel group, as a binary
@@ -229,27 +269,56 @@ static int conv1_stage_len(int ppb, int W, int dil) {
     return len <= CONV1_STAGE_MAX ? (int)len : 0;
 }
 
-extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
-                             int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows,
-                             int rows_pix, float in_sub, float in_div, void* stream) {
+static int conv1_fwd_common(const float* x, const float* w, const float* bias, float* y, float* stats,
+                            int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows,
+                            int rows_pix, float in_sub, float in_div, float* pool_out, const float* pscale,
+                            const float* pshift, void* stream) {
     if (!x || !w || !y || Cout <= 0 || Cs < Cout || (Cs & 3) || Cs > 256 || dil < 1) AMX_BADARG(1);
     if (!(in_div != 0.f)) AMX_BADARG(3);
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(2);
     const int PL = 256 / (Cs / 4);
     const int stage_len = conv1_stage_len(rows_pix, W, dil);
+    if (pool_out && (!stage_len || stats || !pscale || !pshift || (H & 1) || (W & 1) || rows_pix % (2 * W))) AMX_BADARG(4);
     size_t lds = (size_t)PL * 3 * Cs * sizeof(float);
     if ((size_t)stage_len * sizeof(float) > lds) lds = (size_t)stage_len * sizeof(float);
-    if (stage_len)
-        AMX_LAUNCH(conv1_fwd_kernel<true>, dim3(rows), dim3(256), lds,
+    if (stage_len && pool_out)
+        AMX_LAUNCH((conv1_fwd_kernel<true, true>), dim3(rows), dim3(256), lds,
                    (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
-                   amx_round_up(Cout, 16), in_sub, in_div, stage_len);
+                   amx_round_up(Cout, 16), in_sub, in_div, stage_len, pool_out, pscale, pshift);
+    else if (stage_len)
+        AMX_LAUNCH((conv1_fwd_kernel<true, false>), dim3(rows), dim3(256), lds,
+                   (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
+                   amx_round_up(Cout, 16), in_sub, in_div, stage_len, pool_out, pscale, pshift);
     else
-        AMX_LAUNCH(conv1_fwd_kernel<false>, dim3(rows), dim3(256), lds,
+        AMX_LAUNCH((conv1_fwd_kernel<false, false>), dim3(rows), dim3(256), lds,
                    (hipStream_t)stream, x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows_pix,
-                   amx_round_up(Cout, 16), in_sub, in_div, stage_len);
+                   amx_round_up(Cout, 16), in_sub, in_div, stage_len, (float*)nullptr, (const float*)nullptr,
+                   (const float*)nullptr);
     AMX_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
+                             int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows,
+                             int rows_pix, float in_sub, float in_div, void* stream) {
+    return conv1_fwd_common(x, w, bias, y, stats, N, H, W, Cout, Cs, dil, slope, rows, rows_pix, in_sub, in_div, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+// 1 when amx_conv1_fwd_pool can serve this shape (even H and W, whole row pairs per block, the block's range fits the LDS)
+extern "C" int amx_conv1_fwd_pool_supported(int H, int W, int dil, int rows_pix) {
+    return conv1_stage_len(rows_pix, W, dil) > 0 && !(H & 1) && !(W & 1) && rows_pix % (2 * W) == 0;
+}
+
+// Eval-mode first layer followed by a 2x2 max-pool: y as amx_conv1_fwd (no statistics) AND pooled =
+// max_pool2d(y * pscale + pshift) [N][H/2][W/2][Cs], bit-identical to amx_pool2x2_fwd(y, pscale, pshift).
+extern "C" int amx_conv1_fwd_pool(const float* x, const float* w, const float* bias, float* y, float* pooled,
+                                  const float* pscale, const float* pshift, int N, int H, int W, int Cout, int Cs,
+                                  int dil, float slope, int rows, int rows_pix, float in_sub, float in_div, void* stream) {
+    if (!pooled) AMX_BADARG(5);
+    return conv1_fwd_common(x, w, bias, y, nullptr, N, H, W, Cout, Cs, dil, slope, rows, rows_pix, in_sub, in_div, pooled,
+                            pscale, pshift, stream);
 }
 
 // dW[co][0][t] = sum_p dpre[p][co] * x[p + tap t];  partial rows part[blk][9][Cs] (+ row 9 = sum_p dpre when

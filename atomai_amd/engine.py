@@ -60,7 +60,7 @@ class Act:
     """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
     per-channel affine of the producing BatchNorm (None == identity)."""
     __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad", "producer",
-                 "first_consumer", "bstats", "post_slope", "unmasked")
+                 "first_consumer", "bstats", "post_slope", "unmasked", "pooled")
 
     def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
         self.t = t
@@ -72,6 +72,7 @@ class Act:
         self.grad: Optional[torch.Tensor] = None      # d loss / d (value the consumers see), NHWC
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
         self.unmasked: Optional[torch.Tensor] = None  # DilatedBlock + training Dropout: lrelu(conv) BEFORE the mask
+        self.pooled: Optional["Act"] = None           # eval mode: max_pool2d of this (normalised) activation, already computed
         self.needs_grad = needs_grad
         # No object references from an activation back to graph nodes: node <-> activation cycles would keep
         # gigabytes of device memory alive until the cyclic garbage collector happens to run (erratic step times).
@@ -239,8 +240,9 @@ class ConvNode(_Node):
     """conv (3x3 / dilated / 1x1) [+bias] [+LeakyReLU] [+BatchNorm statistics] over 1 or 2 sources."""
 
     def __init__(self, tape, srcs: Sequence[Act], conv, bn, slope: float, x_plain=None, post_slope: float = 1.0,
-                 drop_p: float = 0.0, keep_unmasked: bool = False):
+                 drop_p: float = 0.0, keep_unmasked: bool = False, pool_next: bool = False):
         self.srcs = list(srcs)
+        self.pool_next = pool_next                    # first layer whose output goes straight into a 2x2 max-pool
         self.keep_unmasked = keep_unmasked            # DilatedBlock sums the convolution output itself too
         self.conv, self.bn, self.slope = conv, bn, float(slope)
         # training-mode nn.Dropout between the convolution and its LeakyReLU (blocks.py:68-69): applied after the fused
@@ -290,9 +292,19 @@ class ConvNode(_Node):
             stats = _empty((self.rows, 2, cop), x) if training_bn else None
             norm = tape.input_norm if tape.input_norm is not None else (0.0, 1.0)
             tape.input_norm_used = tape.input_norm is not None
-            L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
-                   L.ptr(y), L.ptr(stats), N, H, W, self.cout, cos, self.dil, self.slope, self.rows,
-                   self.rows_pix, float(norm[0]), float(norm[1]), _sp(x))
+            self.pooled = None
+            if (self.pool_next and FUSE_POOL and self.bn is not None and not tape.training and not tape.need_grad
+                    and not drop and L.load().amx_conv1_fwd_pool_supported(H, W, self.dil, self.rows_pix)):
+                # eval mode: the 2x2 max-pool of the normalised output comes out of the same kernel (fcnn.py:123, 219)
+                psc, psh = bn_eval_affine(self.bn, self.cout, cos, y)
+                self.pooled = _empty((N, H // 2, W // 2, cos), x)
+                L.call("amx_conv1_fwd_pool", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
+                       L.ptr(y), L.ptr(self.pooled), L.ptr(psc), L.ptr(psh), N, H, W, self.cout, cos, self.dil,
+                       self.slope, self.rows, self.rows_pix, float(norm[0]), float(norm[1]), _sp(x))
+            else:
+                L.call("amx_conv1_fwd", L.ptr(x), L.ptr(w.detach()), L.ptr(b.detach() if b is not None else None),
+                       L.ptr(y), L.ptr(stats), N, H, W, self.cout, cos, self.dil, self.slope, self.rows,
+                       self.rows_pix, float(norm[0]), float(norm[1]), _sp(x))
             stat_mode, lat = 1, 0
         else:
             s0 = self.srcs[0]
@@ -364,6 +376,8 @@ class ConvNode(_Node):
                 scale, shift = bn_eval_affine(bn, self.cout, cos, y)
         needs = tape.need_grad
         act = Act(y, self.cout, scale, shift, needs_grad=needs)
+        if self.x_plain is not None and self.pooled is not None:
+            act.pooled = Act(self.pooled, self.cout, needs_grad=False)
         if drop and self.keep_unmasked:
             act.unmasked = unmasked
         return act
@@ -624,6 +638,10 @@ class PoolNode(_Node):
     def __init__(self, tape, src: Act):
         self.src = src
         src.consumed_by(self)
+        fused = src.pooled
+        if fused is not None:                        # eval mode: produced by the first-layer kernel itself
+            self.out = fused
+            return
         y = _empty((src.N, src.H // 2, src.W // 2, src.Cs), src.t)
         L.call("amx_pool2x2_fwd", L.ptr(src.t), L.ptr(src.scale), L.ptr(src.shift), L.ptr(y), src.N,
                src.H, src.W, src.Cs, _sp(y))
@@ -785,6 +803,9 @@ class OutputNode(_Node):
 
 # experiment switch for the eval-mode epilogue fusions (classification head, DilatedBlock sum); 0 = separate kernels
 FUSE_HEAD = _os.environ.get("AMX_FUSE_HEAD", "1") != "0"
+# Eval mode: the 2x2 max-pool that follows a one-layer first block (Unet / dilnet c1) is produced by the first-layer kernel
+# (amx_conv1_fwd_pool); AMX_FUSE_POOL=0 keeps the separate amx_pool2x2_fwd launch (A/B switch, tools/gpu_step_ab.py).
+FUSE_POOL = _os.environ.get("AMX_FUSE_POOL", "1") != "0"
 
 
 def head_fusable(tape, srcs: Sequence[Act], conv, px) -> bool:
@@ -1020,9 +1041,10 @@ class Tape:
     def res_out(self, t: Act, r: Act, slope: float) -> Act:
         return self._push(ResOutNode(self, t, r, slope)).out
 
-    def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0, drop_p: float = 0.0) -> Act:
+    def conv_first(self, x_plain: torch.Tensor, conv, bn=None, slope: float = 1.0, drop_p: float = 0.0,
+                   pool_next: bool = False) -> Act:
         return self._push(ConvNode(self, [], conv, bn, slope, x_plain=x_plain.detach().contiguous(),
-                                   drop_p=drop_p)).out
+                                   drop_p=drop_p, pool_next=pool_next)).out
 
     def pool(self, src: Act) -> Act:
         return self._push(PoolNode(self, src)).out

@@ -95,14 +95,17 @@ class ConvBlock(_HipBlock):
             srcs = [tape.conv(srcs, conv, bn, slope, drop_p=_drop_p(drop))]
         return srcs[0]
 
-    def _emit_input(self, tape, x):
+    def _emit_input(self, tape, x, pool_next: bool = False):
+        """pool_next: the caller max-pools this block's output next (lets a one-layer block's first-layer kernel
+        produce the pooled tensor too in eval mode)."""
         layers = _layers(self.block)
         conv0 = layers[0][0]
         fast = (x.shape[1] == 1 and conv0.in_channels == 1 and conv0.kernel_size == (3, 3)
                 and not (x.requires_grad and tape.need_grad))
         if not fast:
             return super()._emit_input(tape, x)
-        act = tape.conv_first(x, conv0, layers[0][2], layers[0][1], drop_p=_drop_p(layers[0][3]))
+        act = tape.conv_first(x, conv0, layers[0][2], layers[0][1], drop_p=_drop_p(layers[0][3]),
+                              pool_next=pool_next and len(layers) == 1)
         for conv, slope, bn, drop in layers[1:]:
             act = tape.conv([act], conv, bn, slope, drop_p=_drop_p(drop))
         return None, act

@@ -58,7 +58,7 @@ class Unet(_HipNet):
         if x.shape[2] % 8 or x.shape[3] % 8:
             raise AssertionError("Unet needs H and W divisible by 8 (three 2x2 poolings); "
                                  "SegPredictor pads inputs accordingly")
-        node, c1 = self.c1._emit_input(tape, x)
+        node, c1 = self.c1._emit_input(tape, x, pool_next=True)
         d1 = tape.pool(c1)
         c2 = self.c2._emit(tape, [d1])
         d2 = tape.pool(c2)
@@ -114,7 +114,7 @@ class dilnet(_HipNet):
     def _build(self, tape, x, px_mode: int = 0):
         if x.shape[2] % 2 or x.shape[3] % 2:
             raise AssertionError("dilnet needs even H and W (one 2x2 pooling)")
-        node, c1 = self.c1._emit_input(tape, x)
+        node, c1 = self.c1._emit_input(tape, x, pool_next=True)
         d1 = tape.pool(c1)
         at1 = self.at1._emit(tape, [d1])
         at2 = self.at2._emit(tape, [at1])

@@ -121,6 +121,14 @@ int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_p
 int amx_conv1_fwd(const float* x, const float* w, const float* bias, float* y, float* stats,
                   int N, int H, int W, int Cout, int Cs, int dil, float slope, int rows, int rows_pix,
                   float in_sub, float in_div, void* stream);
+/* Eval-mode first layer followed by F.max_pool2d(x, 2, 2) (nets/fcnn.py:123, 219 — Unet / dilnet pool c1 directly):
+ * y as amx_conv1_fwd without statistics AND pooled = max_pool2d(y * pscale + pshift) (N,H/2,W/2,Cs), bit-identical
+ * to amx_pool2x2_fwd(y, pscale, pshift); saves reading the net's largest activation back.  Only for shapes
+ * amx_conv1_fwd_pool_supported reports (even H, W; whole row pairs per block). */
+int amx_conv1_fwd_pool_supported(int H, int W, int dil, int rows_pix);
+int amx_conv1_fwd_pool(const float* x, const float* w, const float* bias, float* y, float* pooled,
+                       const float* pscale, const float* pshift, int N, int H, int W, int Cout, int Cs, int dil,
+                       float slope, int rows, int rows_pix, float in_sub, float in_div, void* stream);
 int amx_conv1_wgrad(const float* x, const float* dpre, float* part, int N, int H, int W, int Cs,
                     int dil, int rows, int rows_pix, void* stream);
 int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, const float* k1, const float* k2,

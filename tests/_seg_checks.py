@@ -292,6 +292,49 @@ def check_input_norm_fusion(device):
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
+def check_pool_fusion(device):
+    """Eval mode: the 2x2 max-pool behind a one-layer first block comes out of the first-layer kernel
+    (amx_conv1_fwd_pool) — bit-identical to the separate amx_pool2x2_fwd launch, with and without the predictor's input
+    normalisation, over several blocks of pixels; shapes the fused kernel does not serve fall back to the separate launch."""
+    import atomai_amd as aoi
+    from atomai_amd import engine, _lib as L
+    from atomai_amd.nets.fcnn import predict_proba
+    rs = np.random.RandomState(4)
+    calls = []
+    orig = L.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    for name, ncls, kw in (("Unet", 3, dict(nb_filters=4)), ("dilnet", 1, dict(nb_filters=5))):
+        torch.manual_seed(6)
+        net, _ = aoi.nets.init_fcnn_model(name, ncls, **kw)
+        net = net.to(device).eval()
+        with torch.no_grad():                                  # running statistics away from their (0, 1) initial values
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.add_(torch.from_numpy(rs.randn(m.num_features).astype(np.float32) * 0.1).to(device))
+                    m.running_var.mul_(torch.from_numpy((0.5 + rs.rand(m.num_features)).astype(np.float32)).to(device))
+                    m.weight.mul_(torch.from_numpy(np.where(rs.rand(m.num_features) > 0.5, 1.0, -1.0).astype(np.float32)).to(device))
+        for (B, H, W), served in (((3, 48, 32), True), ((2, 32, 64), True), ((1, 24, 40), False)):
+            x = torch.from_numpy((rs.rand(B, 1, H, W) * 9 - 2).astype(np.float32)).to(device)
+            for norm in (None, (np.float32(-2.0), np.float32(9.0))):
+                outs = []
+                for fuse in (True, False):
+                    engine.FUSE_POOL = fuse
+                    calls.clear()
+                    L.call = spy
+                    engine.L.call = spy
+                    try:
+                        outs.append(predict_proba(net, x, input_norm=norm) if norm else predict_proba(net, x))
+                    finally:
+                        L.call = orig
+                        engine.L.call = orig
+                        engine.FUSE_POOL = True
+                    assert ("amx_conv1_fwd_pool" in calls) == (fuse and served), (name, H, W, fuse, calls[:6])
+                assert torch.equal(outs[0], outs[1]), (name, H, W, float((outs[0] - outs[1]).abs().max()))
+
+
 def check_predict(device_is_gpu):
     import atomai_amd as aoi
     from atomai_amd.utils import img_pad, torch_format_image

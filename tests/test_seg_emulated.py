@@ -176,3 +176,7 @@ def test_wave_specialised_two_source_layer(monkeypatch):
 
 def test_loss_upstream_gradient_factor():
     C.check_loss_upstream_gradient("cpu")
+
+
+def test_eval_pool_inside_the_first_layer_kernel():
+    C.check_pool_fusion("cpu")

@@ -273,3 +273,8 @@ def test_wave_specialised_two_source_layer(monkeypatch):
 @pytest.mark.gpu
 def test_loss_upstream_gradient_factor():
     C.check_loss_upstream_gradient("cuda")
+
+
+@pytest.mark.gpu
+def test_eval_pool_inside_the_first_layer_kernel():
+    C.check_pool_fusion("cuda")
