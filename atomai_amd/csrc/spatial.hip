@@ -166,34 +166,55 @@ __device__ __forceinline__ void up_taps(int o, int n, int mode, int& i0, int& i1
     else { i0 = i > 0 ? i - 1 : 0; i1 = i; w0 = 0.25f; w1 = 0.75f; }
 }
 
-// One workgroup = 256 (x, channel group) slots of ONE output image row (blockIdx.x = n * H + y, blockIdx.y = slot chunk):
-// the only integer divisions are two 32-bit ones per thread (the flat 1-D mapping of round 1 ran three 64-bit div / mod
-// chains per 16-byte store — more instructions than the interpolation itself; 3.8 TB/s).
+// One workgroup = 256 (x, channel group) slots of UP_LR low-res rows = 2 * UP_LR output rows (blockIdx.x = n * ceil(h / UP_LR)
+// + row group, blockIdx.y = slot chunk): a thread keeps its two low-res columns of the UP_LR + 2 (clamped) low-res rows in
+// registers and writes 2 * UP_LR outputs.  The only integer divisions are two 32-bit ones per thread (the flat 1-D mapping
+// of round 1 ran three 64-bit div / mod chains per 16-byte store: 3.8 TB/s).  Round 3: one output row per workgroup meant
+// 4 loads and ONE 16-byte store per thread and 0.9 M workgroups per 16 frames of 1024^2 — dispatch-bound at 3.2-3.8 TB/s;
+// with two low-res rows per thread: 8 loads for 4 stores and a quarter of the workgroups.
+#ifndef UP_LR
+#define UP_LR 2
+#endif
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ v, float* __restrict__ u, int N,
-                                                           int h, int w, int G, int mode) {
-    const int H = 2 * h, W = 2 * w;
+                                                           int h, int w, int G, int mode, int groups) {
+    const int W = 2 * w;
     const unsigned slot = blockIdx.y * 256u + threadIdx.x;       // x * G + cg within the row
     if (slot >= (unsigned)(W * G)) return;
     const int x = (int)(slot / (unsigned)G), cg = (int)(slot - (unsigned)x * G);
-    const int n = (int)(blockIdx.x / (unsigned)H), y = (int)(blockIdx.x - (unsigned)n * H);
-    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-    up_taps(y, h, mode, y0, y1, wy0, wy1);
+    const int n = (int)(blockIdx.x / (unsigned)groups), k0 = (int)(blockIdx.x - (unsigned)n * groups) * UP_LR;
+    int x0, x1; float wx0, wx1;
     up_taps(x, w, mode, x0, x1, wx0, wx1);
     const float* base = v + (size_t)n * h * w * G * 4 + cg * 4;
-    const float4 a00 = amx_ld4(base + ((size_t)y0 * w + x0) * G * 4);
-    float4 o;
-    if (mode == 1) { o = a00; }
-    else {
-        const float4 a01 = amx_ld4(base + ((size_t)y0 * w + x1) * G * 4);
-        const float4 a10 = amx_ld4(base + ((size_t)y1 * w + x0) * G * 4);
-        const float4 a11 = amx_ld4(base + ((size_t)y1 * w + x1) * G * 4);
-        // same association order as ATen's upsample_bilinear2d: rows first, then columns
-        o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
-        o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
-        o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
-        o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+    // low-res rows k0 - 1 .. k0 + UP_LR, clamped into the image: out(2k) = .25 A[k-1] + .75 A[k], out(2k+1) = .75 A[k] +
+    // .25 A[k+1] — the (i0, i1, w0, w1) up_taps returns for these two output rows, with the same clamping
+    float4 A0[UP_LR + 2], A1[UP_LR + 2];
+    #pragma unroll
+    for (int r = 0; r < UP_LR + 2; ++r) {
+        int row = k0 - 1 + r;
+        row = row < 0 ? 0 : (row > h - 1 ? h - 1 : row);
+        A0[r] = amx_ld4(base + ((size_t)row * w + x0) * G * 4);
+        A1[r] = mode == 1 ? A0[r] : amx_ld4(base + ((size_t)row * w + x1) * G * 4);
     }
-    amx_st4(u + ((size_t)blockIdx.x * W * G + slot) * 4, o);
+    #pragma unroll
+    for (int j = 0; j < UP_LR; ++j) {
+        const int k = k0 + j;
+        if (k >= h) break;
+        #pragma unroll
+        for (int odd = 0; odd < 2; ++odd) {
+            const float4 a00 = A0[j + odd], a01 = A1[j + odd], a10 = A0[j + odd + 1], a11 = A1[j + odd + 1];
+            const float wy0 = odd ? 0.75f : 0.25f, wy1 = odd ? 0.25f : 0.75f;
+            float4 o;
+            if (mode == 1) { o = A0[j + 1]; }                 // nearest: floor(y / 2) = k
+            else {
+                // same association order as ATen's upsample_bilinear2d: rows first, then columns
+                o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+                o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+                o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+                o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+            }
+            amx_st4(u + (((size_t)n * 2 * h + 2 * k + odd) * W * G + slot) * 4, o);
+        }
+    }
 }
 
 extern "C" int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode,
@@ -202,8 +223,9 @@ extern "C" int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w,
     const int G = Cs / 4;
     if ((long)N * 2 * h >= 2147483647L || (long)2 * w * G >= 2147483647L) AMX_BADARG(2);
     if (amx_ceil_div(2 * w * G, 256) > 65535) AMX_BADARG(3);
-    AMX_LAUNCH(upsample_fwd_kernel, dim3((unsigned)(N * 2 * h), amx_ceil_div(2 * w * G, 256)), dim3(256), 0,
-               (hipStream_t)stream, v, u, N, h, w, G, mode);
+    const int groups = amx_ceil_div(h, UP_LR);
+    AMX_LAUNCH(upsample_fwd_kernel, dim3((unsigned)(N * groups), amx_ceil_div(2 * w * G, 256)), dim3(256), 0,
+               (hipStream_t)stream, v, u, N, h, w, G, mode, groups);
     AMX_CHECK_LAUNCH();
     return 0;
 }

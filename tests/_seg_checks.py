@@ -292,6 +292,39 @@ def check_input_norm_fusion(device):
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
 
 
+def check_upsample_exact(device):
+    """amx_upsample2x_fwd against a float32 numpy restatement of F.interpolate(scale_factor=2, align_corners=False)
+    (blocks.py:130-131) with ATen's association order — exact equality, odd and even low-res heights (a thread serves two
+    low-res rows), channel-group counts that do not divide 256, both modes."""
+    from atomai_amd import _lib as L
+    rs = np.random.RandomState(8)
+    f = np.float32
+
+    def taps(o, n, mode):
+        i = o >> 1
+        if mode == 1:
+            return i, i, f(1), f(0)
+        if o & 1:
+            return i, min(i + 1, n - 1), f(0.75), f(0.25)
+        return max(i - 1, 0), i, f(0.25), f(0.75)
+    for (N, h, w, Cs) in ((2, 5, 7, 28), (1, 8, 6, 16), (3, 1, 3, 4), (1, 3, 70, 12)):
+        v = rs.randn(N, h, w, Cs).astype(np.float32)
+        for mode in (0, 1):
+            want = np.empty((N, 2 * h, 2 * w, Cs), dtype=np.float32)
+            for y in range(2 * h):
+                y0, y1, wy0, wy1 = taps(y, h, mode)
+                for x in range(2 * w):
+                    x0, x1, wx0, wx1 = taps(x, w, mode)
+                    if mode == 1:
+                        want[:, y, x] = v[:, y0, x0]
+                    else:
+                        want[:, y, x] = wy0 * (wx0 * v[:, y0, x0] + wx1 * v[:, y0, x1]) + wy1 * (wx0 * v[:, y1, x0] + wx1 * v[:, y1, x1])
+            vt = torch.from_numpy(v).to(device)
+            u = torch.empty(N, 2 * h, 2 * w, Cs, device=device)
+            L.call("amx_upsample2x_fwd", L.ptr(vt), L.ptr(u), N, h, w, Cs, mode, L.stream_ptr(vt))
+            assert np.array_equal(u.cpu().numpy(), want), (N, h, w, Cs, mode, np.abs(u.cpu().numpy() - want).max())
+
+
 def check_pool_fusion(device):
     """Eval mode: the 2x2 max-pool behind a one-layer first block comes out of the first-layer kernel
     (amx_conv1_fwd_pool) — bit-identical to the separate amx_pool2x2_fwd launch, with and without the predictor's input

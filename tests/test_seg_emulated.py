@@ -180,3 +180,7 @@ def test_loss_upstream_gradient_factor():
 
 def test_eval_pool_inside_the_first_layer_kernel():
     C.check_pool_fusion("cpu")
+
+
+def test_upsample_forward_is_exact():
+    C.check_upsample_exact("cpu")

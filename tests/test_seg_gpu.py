@@ -278,3 +278,8 @@ def test_loss_upstream_gradient_factor():
 @pytest.mark.gpu
 def test_eval_pool_inside_the_first_layer_kernel():
     C.check_pool_fusion("cuda")
+
+
+@pytest.mark.gpu
+def test_upsample_forward_is_exact():
+    C.check_upsample_exact("cuda")
