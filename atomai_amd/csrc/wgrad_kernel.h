@@ -139,36 +139,38 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
         }
     }
 
+    // Every load is UNCONDITIONAL (conv_ws.hip found the same): a load under a bounds predicate whose destination was
+    // zeroed first makes the compiler merge old and new register values right behind the load — the wave then waits for
+    // the data where the load was issued, and with ONE wave per SIMD that latency is part of the "issue" phase (1728 -> 1541
+    // clocks per tile on the >= 32-channel classes, profiles/r03_wgrad_phases.log -> r03_wgrad_phases_uncond.log; U-Net
+    // step 18.19 -> 18.11 ms).  Slots outside the image (or without a
+    // source) read a safe address instead and are zeroed when the tile is staged.
+    const float* xsafe = xsrc ? xsrc + xc : a.x0;
     auto issue = [&](int n, int ty, int tx, int rr) {
         const int ry = LAT ? rr / LS : 0, rx = LAT ? rr - ry * LS : 0;     // residue class of this tile (lattice mode)
         const int gy0 = ry + (ty * TH - halo) * LS, gx0 = rx + (tx * TW - halo) * LS;   // image-space origin incl. halo
         const long xbase = ((long)(n * a.H + gy0) * a.W + gx0) * xCs;      // (may be negative: halo rows of image 0)
+        // (A wave-uniform fast path for tiles whose halo lies inside the image — no per-slot bounds arithmetic — was
+        // measured: the two code paths writing the same registers bring the wait-at-the-merge back, issue phase 1541 ->
+        // 2397 clocks per tile, step 18.11 -> 18.48 ms; profiles/r03_wgrad_phases_interior.log.)
         xvalid = 0;
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
-            xr[i] = make_float4(0, 0, 0, 0);
-            if (x_yx[i] >= 0) {
-                const int gy = gy0 + (x_yx[i] >> 8), gx = gx0 + (x_yx[i] & 255);
-                if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-                    xr[i] = amx_ld4(xsrc + (xbase + x_rel[i]));
-                    xvalid |= 1u << i;
-                }
-            }
+            const int gy = gy0 + (x_yx[i] >> 8), gx = gx0 + (x_yx[i] & 255);
+            const bool ok = x_yx[i] >= 0 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const float* src = ok ? xsrc + (xbase + x_rel[i]) : xsafe;
+            xr[i] = amx_ld4(src);
+            xvalid |= (ok ? 1u : 0u) << i;
         }
         const int dy0 = ry + ty * TH * LS, dx0 = rx + tx * TW * LS;
         const long dbase = ((long)(n * a.H + dy0) * a.W + dx0) * a.Dos;
         #pragma unroll
         for (int i = 0; i < DLD_MAX; ++i) {
-            dr[i] = make_float4(0, 0, 0, 0);
-            d_off[i] = -1;
-            if (d_yx[i] >= 0) {
-                const int gy = dy0 + (d_yx[i] >> 8), gx = dx0 + (d_yx[i] & 255);
-                if (gy < a.H && gx < a.W) {
-                    const long o = dbase + d_rel[i];
-                    dr[i] = amx_ld4(a.dpre + o);
-                    d_off[i] = o;
-                }
-            }
+            const int gy = dy0 + (d_yx[i] >> 8), gx = dx0 + (d_yx[i] & 255);
+            const bool ok = d_yx[i] >= 0 && gy < a.H && gx < a.W;
+            const long o = ok ? dbase + d_rel[i] : 0;
+            dr[i] = amx_ld4(a.dpre + o);
+            d_off[i] = ok ? o : -1;
         }
     };
     auto stage = [&]() {
@@ -177,14 +179,13 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
             const int pix = (tid + i * 256) / CG;
             if (pix < npix_x) {
                 float4 v = xr[i];
-                if (xvalid & (1u << i)) {
-                    v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
-                    v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
-                    if (r_islope != 1.f) {
-                        v.x = v.x > 0.f ? v.x : v.x * r_islope; v.y = v.y > 0.f ? v.y : v.y * r_islope;
-                        v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
-                    }
+                v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
+                v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
+                if (r_islope != 1.f) {
+                    v.x = v.x > 0.f ? v.x : v.x * r_islope; v.y = v.y > 0.f ? v.y : v.y * r_islope;
+                    v.z = v.z > 0.f ? v.z : v.z * r_islope; v.w = v.w > 0.f ? v.w : v.w * r_islope;
                 }
+                if (!(xvalid & (1u << i))) v = make_float4(0.f, 0.f, 0.f, 0.f);     // zero padding (AFTER the affine)
                 amx_st4(s_x + (size_t)pix * SX + xg * 4, v);
             }
         }
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, (TAPS == 9 && NT == 2 && WM == 4 && TH == 4) ?
             if (idx < nd4) {
                 const int pix = idx >> dg_shift, dg = idx & (DG - 1);
                 float4 v = dr[i];
+                if (d_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.aux) {
                     // dpre = lrelu'(a) * (k1*dy + k2*a + k3); a is fetched here rather than prefetched so that the
                     // register footprint (hence the number of co-resident workgroups) stays that of the plain kernel
