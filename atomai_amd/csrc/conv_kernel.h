@@ -42,6 +42,9 @@
 //     rows with Chan's formula in fp64: deterministic, no atomics), transpose through a wave-private LDS region,
 //     16-byte NHWC stores (+ optional residual addend).
 #pragma once
+#ifndef AMX_CONV_UNCOND_LOADS
+#define AMX_CONV_UNCOND_LOADS 1      // compile-time A/B switch (tools/build_variant_lib.sh), see issue_loads
+#endif
 #include "amx_device.h"
 #include <cstdlib>
 
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
     const int my_kg = tid & (KG - 1);
     const int nslots = IH * IW;
+    constexpr bool UNCOND = AMX_CONV_UNCOND_LOADS && NT <= 2;
     int x_off[XLD];                                              // pixel offset ((n*H+y)*W+x) or -1
     #pragma unroll
     for (int i = 0; i < XLD; ++i) {
@@ -230,10 +234,19 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         r_sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (src && sc) { r_sc = amx_ld4(sc + c); r_sh = amx_ld4(sh + c); }
         r_islope = src == a.x1 ? a.in_slope1 : a.in_slope0;
+        // The loads of a chunk are UNCONDITIONAL per slot (UNCOND; not on the 64-column classes, where the one extra register
+        // it costs halves the occupancy): a slot outside the image reads pixel 0 of
+        // its source and is zeroed when the chunk is staged.  The predicated form compiled to an exec-mask branch, four
+        // zero-initialising moves and a 64-bit multiply-add pair around every load (~12 instructions per load in a kernel
+        // that is issue-bound on the thin layers).
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
-            xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
+            if (UNCOND) {
+                xr[i] = src ? amx_ld4(src + (size_t)(x_off[i] >= 0 ? x_off[i] : 0) * Cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
+            }
         }
 #if !AMX_CONV_GLDS
         const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             const int pix = (tid + i * 256) >> 2;
             if (pix < nslots) {
                 float4 v = xr[i];
+                if (UNCOND && x_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (x_off[i] >= 0) {                             // padding stays exactly zero
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
                     v.z = fmaf(v.z, r_sc.z, r_sh.z); v.w = fmaf(v.w, r_sc.w, r_sh.w);
