@@ -325,16 +325,25 @@ static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
 // image sides in multiples of 16 and enough tiles for one persistent workgroup per CU; no fused head / block sum /
 // residual addend / post-affine activation.  `strip` is the statistics strip height the layer's plan reports.
 bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, float in_slope0, float in_slope1) {
-    // AMX_CONV_WS: 0 = off, 1 = forward and data-gradient launches, 2 (default) = forward only (a bias is present),
-    // 3 = data gradient only.  Stand-alone the kernel is 12-27 % faster than conv_kernel.h on every thin shape, forward
-    // and data gradient alike (profiles/r03_wave_specialised.md); inside the training step only the forward launches
-    // gain (18.67 -> 18.48 ms): a persistent 16-wave workgroup owns its CU's LDS and registers, so the weight-gradient
-    // kernels of the side stream cannot run next to the data gradients any more and the overlap that is lost cancels
-    // what the faster kernel wins.
-    int mode = 2;
+    // AMX_CONV_WS: 0 = off, 1 (default) = forward launches + the data-gradient classes of AMX_CONV_WS_DGRAD, 2 = forward
+    // only (a bias is present), 3 = data gradients only (every class).  AMX_CONV_WS_DGRAD is a mask of data-gradient
+    // classes: 1 = two-output launches at >= 512^2 (U-Net c6.0: 16 -> 16 + 16), 2 = 32 -> 32 channels (c5.3, c2.3),
+    // 4 = 32 -> 16 channels (c2.0); default 3.
+    // Stand-alone the kernel is 12-27 % faster than conv_kernel.h on every thin shape, forward and data gradient alike
+    // (profiles/r03_wave_specialised.md).  Inside the training step a persistent 16-wave workgroup owns its CU's LDS and
+    // registers, so the weight-gradient kernels of the side stream cannot run next to a wave-specialised data gradient
+    // and the lost overlap competes with what the faster kernel wins; measured per class in-process
+    // (profiles/r03_dgrad_first_ab.log): forward only 18.17 ms, + c6.0 18.03, + the two 32 -> 32 launches 17.99, while the
+    // 32 -> 16 launch costs 0.09 ms (all classes: 18.1-18.5, the round's earlier "no gain" result).
+    int mode = 1, dmask = 3;
     if (const char* e = getenv("AMX_CONV_WS")) mode = atoi(e);
+    if (const char* e = getenv("AMX_CONV_WS_DGRAD")) dmask = atoi(e);
     if (mode <= 0) return false;
     if ((mode == 2 && !a.bias) || (mode == 3 && a.bias)) return false;
+    if (mode == 1 && !a.bias) {
+        const int cls = (a.Y1s > 0 && (long)a.H * a.W >= 512L * 512L) ? 1 : ((a.C0s + a.C1s == 32 && a.cout == 32) ? 2 : 4);
+        if (!(dmask & cls)) return false;
+    }
     if (taps != 9 || dil != 1 || a.hout || a.nds || a.addend || in_slope0 != 1.f || in_slope1 != 1.f) return false;
     const int cin = a.C0s + a.C1s;
     if ((cin != 16 && cin != 32) || (a.C0s & 15) || (a.C1s & 15)) return false;

@@ -409,7 +409,8 @@ def check_wave_specialised_conv(device, cin, cout, monkeypatch, hw=32, batch=2):
     from atomai_amd.nets import ConvBlock
     out = {}
     for ws in ("1", "0"):
-        monkeypatch.setenv("AMX_CONV_WS", ws)            # 1: forward AND data-gradient launches (the default is forward only)
+        monkeypatch.setenv("AMX_CONV_WS", ws)            # 1 + every data-gradient class (the default mask leaves one out)
+        monkeypatch.setenv("AMX_CONV_WS_DGRAD", "7")
         torch.manual_seed(3)
         m = ConvBlock(2, 2, cin, cout, batch_norm=True).to(device)
         ref = nn.Sequential(*[copy.deepcopy(l) for l in m.block]).double()
@@ -447,6 +448,7 @@ def check_wave_specialised_concat(device, monkeypatch, hw=32, batch=2):
     out = {}
     for ws in ("1", "0"):
         monkeypatch.setenv("AMX_CONV_WS", ws)
+        monkeypatch.setenv("AMX_CONV_WS_DGRAD", "7")
         torch.manual_seed(5)
         net, _ = aoi.nets.init_fcnn_model("Unet", 3, nb_filters=16)
         net = net.to(device).train()

@@ -23,6 +23,7 @@ def run(tag, N, H, C0, C1, Cout, Y1=0, stats_on=True, iters=30):
     res = {}
     for ws in ("0", "1", "0", "1"):
         os.environ["AMX_CONV_WS"] = ws
+        os.environ["AMX_CONV_WS_DGRAD"] = "7"          # every data-gradient class (the product default leaves 32 -> 16 out)
         y = torch.zeros(N, H, H, Y0, device=dev)
         y1 = torch.zeros(N, H, H, Y1, device=dev) if Y1 else None
         stats = None
