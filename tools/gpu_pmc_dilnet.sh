@@ -16,4 +16,4 @@ PY
 cd /tmp
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d /root/repo/gpurun_out/pmc_dilnet -o pmc --output-format csv -- python /tmp/dil_pmc.py > /root/repo/gpurun_out/pmc_dilnet.log 2>&1
 cd /root/repo
-python tools/summarize_pmc_dilnet.py
+python tools/summarize_pmc_dilnet.py ${1:-r03}
