@@ -327,8 +327,9 @@ static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
 bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, float in_slope0, float in_slope1) {
     // AMX_CONV_WS: 0 = off, 1 (default) = forward launches + the data-gradient classes of AMX_CONV_WS_DGRAD, 2 = forward
     // only (a bias is present), 3 = data gradients only (every class).  AMX_CONV_WS_DGRAD is a mask of data-gradient
-    // classes: 1 = two-output launches at >= 512^2 (U-Net c6.0: 16 -> 16 + 16), 2 = 32 -> 32 channels (c5.3, c2.3),
-    // 4 = 32 -> 16 channels (c2.0); default 3.
+    // classes: 1 = two-output launches (the data gradient of a layer that read a concatenation — U-Net c6.0: 16 -> 16 + 16,
+    // the FIRST data gradient of the backward pass), 2 = 32 -> 32 channels (c5.3, c2.3), 4 = the rest (32 -> 16: c2.0, the
+    // last one, which finds the side stream's backlog of weight gradients in its way); default 3.
     // Stand-alone the kernel is 12-27 % faster than conv_kernel.h on every thin shape, forward and data gradient alike
     // (profiles/r03_wave_specialised.md).  Inside the training step a persistent 16-wave workgroup owns its CU's LDS and
     // registers, so the weight-gradient kernels of the side stream cannot run next to a wave-specialised data gradient
@@ -341,7 +342,7 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
     if (mode <= 0) return false;
     if ((mode == 2 && !a.bias) || (mode == 3 && a.bias)) return false;
     if (mode == 1 && !a.bias) {
-        const int cls = (a.Y1s > 0 && (long)a.H * a.W >= 512L * 512L) ? 1 : ((a.C0s + a.C1s == 32 && a.cout == 32) ? 2 : 4);
+        const int cls = a.Y1s > 0 ? 1 : ((a.C0s + a.C1s == 32 && a.cout == 32) ? 2 : 4);
         if (!(dmask & cls)) return false;
     }
     if (taps != 9 || dil != 1 || a.hout || a.nds || a.addend || in_slope0 != 1.f || in_slope1 != 1.f) return false;
