@@ -116,7 +116,8 @@ struct Geo {
 template <int HID, int MT>
 __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix0, const float* s_zc,
                                             float* dst, float* s_xy, const float* s_th, int tid,
-                                            float* gsave = nullptr) {
+                                            float* gsave = nullptr, const float* wc = nullptr) {
+    if (!wc) wc = a.Wc;                          // (the kernels pass their LDS copy: s_wc)
     using G = Geo<HID, MT>;
     #pragma unroll
     for (int i = 0; i < G::SPT; ++i) {
@@ -136,10 +137,11 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
             }
             if (s_xy && kg == 0) { s_xy[2 * p] = xx; s_xy[2 * p + 1] = yy; }
             const int f = kg * 4;
-            h.x = fmaf(a.Wc[2 * f + 0], xx, fmaf(a.Wc[2 * f + 1], yy, s_zc[f + 0]));
-            h.y = fmaf(a.Wc[2 * f + 2], xx, fmaf(a.Wc[2 * f + 3], yy, s_zc[f + 1]));
-            h.z = fmaf(a.Wc[2 * f + 4], xx, fmaf(a.Wc[2 * f + 5], yy, s_zc[f + 2]));
-            h.w = fmaf(a.Wc[2 * f + 6], xx, fmaf(a.Wc[2 * f + 7], yy, s_zc[f + 3]));
+            const float4 w0 = amx_ld4(wc + 2 * f), w1 = amx_ld4(wc + 2 * f + 4);       // Wc[f..f+3][0..1]
+            h.x = fmaf(w0.x, xx, fmaf(w0.y, yy, s_zc[f + 0]));
+            h.y = fmaf(w0.z, xx, fmaf(w0.w, yy, s_zc[f + 1]));
+            h.z = fmaf(w1.x, xx, fmaf(w1.y, yy, s_zc[f + 2]));
+            h.w = fmaf(w1.z, xx, fmaf(w1.w, yy, s_zc[f + 3]));
             if (!a.skip) { h.x = rd_tanh(h.x); h.y = rd_tanh(h.y); h.z = rd_tanh(h.z); h.w = rd_tanh(h.w); }
         }
         amx_st4(dst + ((size_t)kg * G::PS + p) * 4, h);
@@ -214,14 +216,15 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
 // out[p][c] = Wo[c] . h[p] + bo[c] for the tile; result left in s_out[c * MT + p]
 template <int HID, int MT>
 __device__ __forceinline__ void output_layer(const RDecArgs& a, const float* h, float* s_part, float* s_out,
-                                             int tid) {
+                                             int tid, const float* wo = nullptr) {
     using G = Geo<HID, MT>;
+    if (!wo) wo = a.Wo;                          // (the kernels pass their LDS copy: s_wo)
     const int p = tid % MT, part = tid / MT;
     for (int c = 0; c < a.C; ++c) {
         float acc = 0.f;
         for (int kg = part; kg < G::KG; kg += G::TPP) {
             const float4 v = amx_ld4(h + ((size_t)kg * G::PS + p) * 4);
-            const float4 w = amx_ld4(a.Wo + (size_t)c * HID + kg * 4);
+            const float4 w = amx_ld4(wo + (size_t)c * HID + kg * 4);
             acc = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, acc))));
         }
         s_part[part * MT + p] = acc;
@@ -239,7 +242,11 @@ __device__ __forceinline__ void output_layer(const RDecArgs& a, const float* h, 
 // zc[f] = bc[f] + sum_l Wz[f][l] z[l]
 template <int HID>
 __device__ __forceinline__ void latent_bias(const RDecArgs& a, int bidx, float* s_zc, float* s_z, float* s_th,
-                                            int tid) {
+                                            int tid, float* s_wc = nullptr, float* s_wo = nullptr) {
+    // the coordinate layer's and the output layer's weights (HID x 2, C x HID) are read by every thread in every tile:
+    // one LDS copy per workgroup instead of global loads in the tile loop (round 3, profiles/r03_rdecoder_phases.log)
+    if (s_wc) for (int i = tid; i < 2 * HID; i += 4 * HID) s_wc[i] = a.Wc[i];
+    if (s_wo) for (int i = tid; i < a.C * HID; i += 4 * HID) s_wo[i] = a.Wo[i];
     if (tid < a.L) s_z[tid] = a.z[(size_t)bidx * a.L + tid];
     if (a.theta && tid == 0) {                   // (cos phi, sin phi, dx, dy) of this sample
         const float phi = a.theta[(size_t)bidx * 3];
@@ -268,14 +275,17 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     float* s_part = s_z + MAXL;
     float* s_out = s_part + G::TPP * MT;              // [MAXC][MT]
     float* s_th = s_out + MAXC * MT;                  // [4]
+    float* s_wc = s_th + 4;                           // [HID][2]  (16-byte aligned: every size above is a multiple of 4 floats)
+    float* s_wo = s_wc + 2 * HID;                     // [MAXC][HID]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bidx = blockIdx.x;
-    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid);
+    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid, s_wc, s_wo);
     const float* th = a.theta ? s_th : nullptr;
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         float* h0 = a.skip ? buf2 : buf0;
         coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid,
-                             (RD_SAVE_H0 && a.hsave) ? a.hsave + ((size_t)bidx * RD_PLANES(a.NL) * G::KG * a.npad + pix0) * 4 : nullptr);
+                             (RD_SAVE_H0 && a.hsave) ? a.hsave + ((size_t)bidx * RD_PLANES(a.NL) * G::KG * a.npad + pix0) * 4 : nullptr,
+                             s_wc);
         __syncthreads();
         const float* src = h0;
         for (int l = 0; l < a.NL; ++l) {
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
             __syncthreads();
             src = dst;
         }
-        output_layer<HID, MT>(a, src, s_part, s_out, tid);
+        output_layer<HID, MT>(a, src, s_part, s_out, tid, s_wo);
         for (int e = tid; e < MT * a.C; e += G::NT) {                 // xrec[b][pixel][channel]
             const int pp = e / a.C, c = e - pp * a.C;
             if (pix0 + pp < a.n) a.xrec[((size_t)bidx * a.n + pix0 + pp) * a.C + c] = s_out[c * MT + pp];
@@ -312,10 +322,12 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     float* s_xy = s_out + MAXC * MT;               // [MT][2]
     float* s_red = s_xy + 2 * MT;                  // [NT] float4 scratch for the final reductions
     float* s_th = s_red + 4 * G::NT;               // [4]
+    float* s_wc = s_th + 4;                        // [HID][2]
+    float* s_wo = s_wc + 2 * HID;                  // [MAXC][HID]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 15, g = lane >> 4;
     const int bidx = blockIdx.x;
-    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid);
+    latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid, s_wc, s_wo);
     const float* th = a.theta ? s_th : nullptr;
     float a_phi = 0.f, a_tr = 0.f;                 // theta mode: thread (pixel slot, component) partial sums
 
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
         if (SAVED && RD_SAVE_H0) coord_xy<MT>(a, bidx, pix0, s_xy, th, tid);
-        else coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid);
+        else coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid, nullptr, s_wc);
         if (SAVED) {
             #pragma unroll
             for (int l = 0; l < NPL; ++l)
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             float4 gh = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int c = 0; c < a.C; ++c) {
                 const float d = s_out[c * MT + pp];
-                const float4 w = amx_ld4(a.Wo + (size_t)c * HID + kg * 4);
+                const float4 w = amx_ld4(s_wo + (size_t)c * HID + kg * 4);
                 gh.x = fmaf(d, w.x, gh.x); gh.y = fmaf(d, w.y, gh.y); gh.z = fmaf(d, w.z, gh.z); gh.w = fmaf(d, w.w, gh.w);
             }
             if (a.skip) {
@@ -513,8 +525,9 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             const float4 ga0 = amx_ld4(H[0] + ((size_t)kg * G::PS + pp) * 4);
             const bool ok = pix0 + pp < a.n;
             const int f = kg * 4;
-            float gx = ga0.x * a.Wc[2 * f + 0] + ga0.y * a.Wc[2 * f + 2] + ga0.z * a.Wc[2 * f + 4] + ga0.w * a.Wc[2 * f + 6];
-            float gy = ga0.x * a.Wc[2 * f + 1] + ga0.y * a.Wc[2 * f + 3] + ga0.z * a.Wc[2 * f + 5] + ga0.w * a.Wc[2 * f + 7];
+            const float4 w0 = amx_ld4(s_wc + 2 * f), w1 = amx_ld4(s_wc + 2 * f + 4);   // Wc[f..f+3][0..1]
+            float gx = ga0.x * w0.x + ga0.y * w0.z + ga0.z * w1.x + ga0.w * w1.z;
+            float gy = ga0.x * w0.y + ga0.y * w0.w + ga0.z * w1.y + ga0.w * w1.w;
             s_g[((size_t)kg * MT + pp) * 2 + 0] = ok ? gx : 0.f;
             s_g[((size_t)kg * MT + pp) * 2 + 1] = ok ? gy : 0.f;
         }
@@ -530,10 +543,28 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             }
         }
         __syncthreads();
+        // (d x', d y') of a pixel = sum over the feature groups: every thread sums KG / NQ groups of one (pixel, component),
+        // then 2 MT threads add the NQ partial sums in order (the round-1/2 form let 2 MT threads walk all KG groups while
+        // the others waited: ~2 k clocks of a 64 k-clock tile)
+        constexpr int NQ = G::NT / (2 * MT) >= 1 ? G::NT / (2 * MT) : 1;
+        if (NQ > 1) {
+            const int idx = tid % (2 * MT), q = tid / (2 * MT);
+            const int pp = idx >> 1, comp = idx & 1;
+            float t = 0.f;
+            #pragma unroll
+            for (int kg = q * (G::KG / NQ); kg < (q + 1) * (G::KG / NQ); ++kg) t += s_g[((size_t)kg * MT + pp) * 2 + comp];
+            s_red[q * 2 * MT + idx] = t;
+            __syncthreads();
+        }
         if (tid < 2 * MT) {
             const int pp = tid >> 1, comp = tid & 1;
             float t = 0.f;
-            for (int kg = 0; kg < G::KG; ++kg) t += s_g[((size_t)kg * MT + pp) * 2 + comp];
+            if (NQ > 1) {
+                #pragma unroll
+                for (int q = 0; q < NQ; ++q) t += s_red[q * 2 * MT + tid];
+            } else {
+                for (int kg = 0; kg < G::KG; ++kg) t += s_g[((size_t)kg * MT + pp) * 2 + comp];
+            }
             if (pix0 + pp < a.n) {
                 if (th) {
                     // d/dphi of (x', y') = (-(y' - dy), x' - dx);  d/d(dx, dy) = identity
@@ -626,12 +657,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
 template <int HID, int MT>
 static size_t fwd_lds(int skip) {
     using G = Geo<HID, MT>;
-    return ((size_t)G::BUF * (skip ? 3 : 2) + HID + MAXL + G::TPP * MT + MAXC * MT + 4) * sizeof(float);
+    return ((size_t)G::BUF * (skip ? 3 : 2) + HID + MAXL + G::TPP * MT + MAXC * MT + 4 + 2 * HID + MAXC * HID) * sizeof(float);
 }
 template <int HID, int MT, int NL>
 static size_t bwd_lds(int skip) {
     using G = Geo<HID, MT>;
-    return ((size_t)G::BUF * (NL + 1 + (skip ? 1 : 0)) + HID + MAXL + G::TPP * MT + MAXC * MT + 2 * MT + 4 * G::NT + 4) * sizeof(float);
+    return ((size_t)G::BUF * (NL + 1 + (skip ? 1 : 0)) + HID + MAXL + G::TPP * MT + MAXC * MT + 2 * MT + 4 * G::NT + 4 + 2 * HID +
+            MAXC * HID) * sizeof(float);
 }
 
 template <int HID, int MT>
