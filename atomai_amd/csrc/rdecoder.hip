@@ -119,29 +119,33 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
                                             float* gsave = nullptr, const float* wc = nullptr) {
     if (!wc) wc = a.Wc;                          // (the kernels pass their LDS copy: s_wc)
     using G = Geo<HID, MT>;
+    static_assert(G::NT % MT == 0, "a thread's slots share one pixel");
+    // every slot of a thread is the same pixel (NT is a multiple of MT): its transformed coordinates once per tile
+    const int p = tid % MT, q = pix0 + p;
+    float xx = 0.f, yy = 0.f;
+    if (q < a.n) {
+        if (s_th) {                                        // rotate + translate the shared grid point
+            const float gx = a.coords[(size_t)q * 2 + 0], gy = a.coords[(size_t)q * 2 + 1];
+            xx = gx * s_th[0] - gy * s_th[1] + s_th[2];
+            yy = gx * s_th[1] + gy * s_th[0] + s_th[3];
+        } else {
+            xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
+            yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+        }
+    }
     #pragma unroll
     for (int i = 0; i < G::SPT; ++i) {
-        const int s = tid + i * G::NT;
-        const int kg = s / MT, p = s - kg * MT;
-        const int q = pix0 + p;
+        const int kg = tid / MT + i * (G::NT / MT);
         float4 h = make_float4(0, 0, 0, 0);
         if (q < a.n) {
-            float xx, yy;
-            if (s_th) {                                    // rotate + translate the shared grid point
-                const float gx = a.coords[(size_t)q * 2 + 0], gy = a.coords[(size_t)q * 2 + 1];
-                xx = gx * s_th[0] - gy * s_th[1] + s_th[2];
-                yy = gx * s_th[1] + gy * s_th[0] + s_th[3];
-            } else {
-                xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
-                yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
-            }
             if (s_xy && kg == 0) { s_xy[2 * p] = xx; s_xy[2 * p + 1] = yy; }
             const int f = kg * 4;
             const float4 w0 = amx_ld4(wc + 2 * f), w1 = amx_ld4(wc + 2 * f + 4);       // Wc[f..f+3][0..1]
-            h.x = fmaf(w0.x, xx, fmaf(w0.y, yy, s_zc[f + 0]));
-            h.y = fmaf(w0.z, xx, fmaf(w0.w, yy, s_zc[f + 1]));
-            h.z = fmaf(w1.x, xx, fmaf(w1.y, yy, s_zc[f + 2]));
-            h.w = fmaf(w1.z, xx, fmaf(w1.w, yy, s_zc[f + 3]));
+            const float4 zc = amx_ld4(s_zc + f);
+            h.x = fmaf(w0.x, xx, fmaf(w0.y, yy, zc.x));
+            h.y = fmaf(w0.z, xx, fmaf(w0.w, yy, zc.y));
+            h.z = fmaf(w1.x, xx, fmaf(w1.y, yy, zc.z));
+            h.w = fmaf(w1.z, xx, fmaf(w1.w, yy, zc.w));
             if (!a.skip) { h.x = rd_tanh(h.x); h.y = rd_tanh(h.y); h.z = rd_tanh(h.z); h.w = rd_tanh(h.w); }
         }
         amx_st4(dst + ((size_t)kg * G::PS + p) * 4, h);
@@ -359,16 +363,16 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     constexpr int P0 = RD_SAVE_H0 ? 0 : 1;                       // H[] image the first plane belongs to
     float4 pre[NPL][G::SPT];
     const float* hs = SAVED ? a.hsaved + (size_t)bidx * RD_PLANES(NL) * G::KG * a.npad * 4 : nullptr;
+    // a thread's slots are (kg0 + i * NT / MT, pp0): one per-thread base per tile, wave-uniform strides between its loads
+    const int kg0 = tid / MT, pp0 = tid - kg0 * MT;
     auto fetch = [&](int pix0) {
         if (!SAVED) return;
+        const float* hb = hs + ((size_t)kg0 * a.npad + pix0 + pp0) * 4;
         #pragma unroll
         for (int l = 0; l < NPL; ++l)
             #pragma unroll
-            for (int i = 0; i < G::SPT; ++i) {
-                const int s = tid + i * G::NT;
-                const int kg = s / MT, pp = s - kg * MT;
-                pre[l][i] = amx_ld4(hs + (((size_t)l * G::KG + kg) * a.npad + pix0 + pp) * 4);
-            }
+            for (int i = 0; i < G::SPT; ++i)
+                pre[l][i] = amx_ld4(hb + (size_t)(l * G::KG + i * (G::NT / MT)) * a.npad * 4);
     };
     if (SAVED) fetch(0);
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
