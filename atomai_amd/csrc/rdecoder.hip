@@ -388,6 +388,12 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
                     const int kg = s / MT, pp = s - kg * MT;
                     amx_st4(H[l + P0] + ((size_t)kg * G::PS + pp) * 4, pre[l][i]);
                 }
+            // the tile's upstream gradient goes to LDS under the same barrier (it had one of its own)
+            for (int e = tid; e < MT * a.C; e += G::NT) {
+                const int pp = e / a.C, c = e - pp * a.C;
+                const int q = pix0 + pp;
+                s_out[c * MT + pp] = q < a.n ? a.dxrec[((size_t)bidx * a.n + q) * a.C + c] : 0.f;
+            }
             __syncthreads();
             RD_TICK(0);
         } else {
@@ -402,12 +408,14 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         }
         RD_TICK(1);
         // ---- output layer backward: dout, dWo, dbo, ga_NL (in place over H[NL])
-        for (int e = tid; e < MT * a.C; e += G::NT) {
-            const int pp = e / a.C, c = e - pp * a.C;
-            const int q = pix0 + pp;
-            s_out[c * MT + pp] = q < a.n ? a.dxrec[((size_t)bidx * a.n + q) * a.C + c] : 0.f;
+        if (!SAVED) {
+            for (int e = tid; e < MT * a.C; e += G::NT) {
+                const int pp = e / a.C, c = e - pp * a.C;
+                const int q = pix0 + pp;
+                s_out[c * MT + pp] = q < a.n ? a.dxrec[((size_t)bidx * a.n + q) * a.C + c] : 0.f;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
             if (c >= a.C) break;
