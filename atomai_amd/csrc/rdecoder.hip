@@ -758,7 +758,8 @@ extern "C" int amx_rdecoder_fwd_save(const float* coords, const float* theta, co
     if (rc) return rc;
     if (!xrec) AMX_BADARG(4);
     hipStream_t s = (hipStream_t)stream;
-    int mt = 64;      // 64-pixel tiles: 66 KB of LDS -> two workgroups per CU (58.8 % vs 53.4 % of MFMA peak measured)
+    int mt = 64;      // 64-pixel tiles: 66 KB of LDS -> two workgroups per CU (58.8 % vs 53.4 % of MFMA peak measured; round 3:
+                      // 32-pixel tiles, three workgroups per CU: rVAE step 4.99 -> 5.13 ms, not instantiated)
     if (const char* e = getenv("AMX_RDEC_FWD_MT")) mt = atoi(e);
     if (hid == 32) return launch_fwd<32, 128>(a, s);
     if (hid == 64) return launch_fwd<64, 128>(a, s);
