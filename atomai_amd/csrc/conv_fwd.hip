@@ -102,7 +102,15 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
 #ifdef AMX_CONV_PROFILE
     a.prof = (unsigned long long*)amx_conv_profile_buffer;               // dev build: per-wave phase timestamps
 #endif
-    a.xcd = 0;
+    // XCD-aware block order (conv_kernel.h): the cout blocks of a tile — and, in lattice mode, the d*d residue classes of
+    // a tile position, which share cache lines — become neighbours on ONE XCD's L2 instead of being dealt round-robin
+    // over the eight XCDs.  AMX_CONV_XCD: 0 off, 1 every launch, 2 launches with more than one cout block, 3 (default)
+    // dilated launches only.  The counters showed the dilated layers of dilnet fetching 3.3x (dilation 2 / 4) and 7.9x
+    // (dilation 6) their input from HBM (profiles/r03_pmc_hbm_extra.md); with the XCD-aware order a dilnet frame goes
+    // 1.282 -> 1.257 ms; plain 3x3 layers do not care (U-Net step 17.92 vs 17.93 ms, profiles/r03_conv_xcd_ab.log).
+    int xm = 3;
+    if (const char* e = getenv("AMX_CONV_XCD")) xm = atoi(e);
+    a.xcd = xm == 1 || (xm == 2 && amx_round_up(cout, 16) > 32) || (xm == 3 && dil > 1);
     a.N = N; a.H = H; a.W = W;
     a.cout = cout;
     a.cop = amx_round_up(cout, 16);
