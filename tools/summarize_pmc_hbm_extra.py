@@ -42,5 +42,9 @@ out = [f"# HBM traffic of the dominant kernels of the other workloads, MI355X, {
        "| kernel | launches seen | fetched MB / launch | written MB / launch | algorithmic |", "|---|---|---|---|---|"]
 for k, n, fm, wm, alg in rows:
     out.append(f"| `{k[:60]}` | {n} | {fm:.0f} | {wm:.0f} | {alg} |")
+out += ["", "Caveat: the doubling of FETCH_SIZE was calibrated on wide sequential streams (pool_fwd: 313 MB algorithmic).  The 1x1 "
+        "convolution above streams its 872 MB input once and reads 1440 MB by this accounting, so for narrower access patterns "
+        "the factor may over-count by up to 2x; the WRITE_SIZE column and the RATIOS between kernels of one pattern are reliable "
+        "(dilation 6 fetches 2.4x what dilations 2 / 4 fetch for the same tensor)."]
 open(f"profiles/{RND}_pmc_hbm_extra.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
