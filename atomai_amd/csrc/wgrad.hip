@@ -42,7 +42,7 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     const int ntiles = amx_ceil_div(amx_ceil_div(W, ls), TW) * amx_ceil_div(amx_ceil_div(H, ls), pl.th) * N * ls * ls;
     // split-K workgroups: one per CU (256: 20.98 ms/step, 512: 21.5, 1024: 21.6, 128: 25.2)
     int target = light ? light_wgs : 256;
-    if (const char* e = getenv("AMX_WGRAD_WGS")) { const int v = atoi(e); if (v >= 64) target = v; }
+    if (const char* e = getenv("AMX_WGRAD_WGS")) { const int v = atoi(e); if (v >= 1) target = v; }   // (tests: few workgroups, many tiles each)
     int ks = amx_ceil_div(target, blocks);
     if (ks > ntiles) ks = ntiles;
     if (ks < 1) ks = 1;
@@ -138,6 +138,7 @@ static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int
         if (pl.WM == 2) return launch_wgrad<T, 2, 2, H_, TH_>(a, s);                \
         return launch_wgrad<T, 2, 4, H_, TH_>(a, s);                                \
     }
+    if (amx_wgrad_ws_supported(a, taps, dil, pl.lat, pl.NT, pl.WM, pl.th)) return amx_wgrad_launch_ws(a, pl.NT, pl.WM, s);
     if (pl.lat == 2) return amx_wgrad_launch_lat2(a, pl.NT, pl.WM, s);
     if (pl.lat == 4) return amx_wgrad_launch_lat4(a, pl.NT, pl.WM, s);
     if (pl.lat == 6) return amx_wgrad_launch_lat6(a, pl.NT, pl.WM, s);

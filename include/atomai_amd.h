@@ -112,6 +112,10 @@ int amx_resize_cat_bwd(const float* ddst, int N, int H, int W, int Cd, int coff,
                        int Cs, int mode, void* stream);
 int amx_conv2d_wgrad_rows(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
 int amx_conv2d_wgrad_ksplit(int N, int H, int W, int Cin_s, int cout, int taps, int dil);
+/* Diagnostic: launches of amx_conv2d_wgrad* that the wave-specialised kernel of the plain 3x3 classes (wgrad_ws.hip:
+ * consumer waves issue MFMAs only, producer waves load / transform / stage the next tile) has taken since the library
+ * was loaded (AMX_WGRAD_WS=0 routes them to wgrad_kernel.h; the partial rows are bit-identical either way). */
+long amx_conv2d_wgrad_ws_launches(void);
 int amx_wgrad_reduce(const float* part, int rows, int taps, int ci_pad, int co_pad, int C0, int C0s,
                      int C1, int Cout, float* dw, void* stream);
 

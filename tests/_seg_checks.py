@@ -482,3 +482,55 @@ def check_loss_upstream_gradient(device):
             ref = F.cross_entropy(xr, y) if ncls > 1 else F.binary_cross_entropy_with_logits(xr, y.double())
             (ref * factor).backward()
             assert relmax(xd.grad.cpu().numpy(), xr.grad.numpy()) < 2e-6, (ncls, factor)
+
+
+def check_wgrad_ws_bit_identical(device, cin, cout, H, N, monkeypatch, W=None, two_sources=None):
+    """wgrad_ws.hip against wgrad_kernel.h through the C ABI (amx_conv2d_wgrad_fused): partial rows and bias partials
+    bit-identical; the summed rows against torch's conv2d_weight in fp64."""
+    from atomai_amd import _lib as L
+    W = W or H + 7
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    two = (cin >= 32) if two_sources is None else two_sources
+    c0 = cin // 2 if two else cin
+    c1 = cin - c0
+    x0 = torch.randn(N, H, W, c0, generator=g).to(device)
+    x1 = torch.randn(N, H, W, c1, generator=g).to(device) if two else None
+    sc0, sh0 = (torch.rand(c0, generator=g) + 0.5).to(device), torch.randn(c0, generator=g).to(device)
+    sc1, sh1 = ((torch.rand(c1, generator=g) + 0.5).to(device), torch.randn(c1, generator=g).to(device)) if two else (None, None)
+    cos = -(-cout // 4) * 4
+    dy = torch.randn(N, H, W, cos, generator=g).to(device)
+    aux = torch.randn(N, H, W, cos, generator=g).to(device)
+    k1, k2, k3 = ((torch.randn(cos, generator=g) * s).to(device) for s in (1.0, 0.1, 0.05))
+    slope = 0.01
+    lib = L.load()
+    rows = lib.amx_conv2d_wgrad_rows(N, H, W, cin, cout, 9, 1)
+    ks = lib.amx_conv2d_wgrad_ksplit(N, H, W, cin, cout, 9, 1)
+    ci_pad, co_pad = -(-cin // 16) * 16, -(-cout // 16) * 16
+    res = {}
+    for ws in ("0", "1"):
+        monkeypatch.setenv("AMX_WGRAD_WS", ws)
+        part = torch.full((rows, 9, ci_pad, co_pad), float("nan"), device=device)
+        bpart = torch.full((ks, co_pad), float("nan"), device=device)
+        n0 = lib.amx_conv2d_wgrad_ws_launches()
+        L.call("amx_conv2d_wgrad_fused", L.ptr(x0), L.ptr(sc0), L.ptr(sh0), c0, L.ptr(x1), L.ptr(sc1), L.ptr(sh1), c1,
+               L.ptr(dy), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), slope, cos, L.ptr(part), L.ptr(bpart),
+               N, H, W, cout, 9, 1, L.stream_ptr(x0))
+        if device != "cpu":
+            torch.cuda.synchronize()
+        assert (lib.amx_conv2d_wgrad_ws_launches() - n0 == 1) == (ws == "1")
+        res[ws] = (part.cpu(), bpart.cpu())
+    assert not torch.isnan(res["1"][0]).any() and not torch.isnan(res["1"][1][:, :cout]).any()
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][1][:, :cout], res["1"][1][:, :cout])
+    # against fp64 autograd of the convolution
+    xin = x0.double().cpu() * sc0.double().cpu() + sh0.double().cpu()
+    if two:
+        xin = torch.cat([xin, x1.double().cpu() * sc1.double().cpu() + sh1.double().cpu()], -1)
+    a64, d64 = aux.double().cpu(), dy.double().cpu()
+    dpre = torch.where(a64 > 0, 1.0, slope) * (k1.double().cpu() * d64 + k2.double().cpu() * a64 + k3.double().cpu())
+    dw = torch.nn.grad.conv2d_weight(xin.permute(0, 3, 1, 2), (cout, cin, 3, 3), dpre[..., :cout].permute(0, 3, 1, 2),
+                                     padding=1)                                            # [co][ci][3][3]
+    got = res["1"][0].double().sum(0)[:, :cin, :cout].permute(2, 1, 0).reshape(cout, cin, 3, 3)
+    assert float((got - dw).abs().max() / dw.abs().max()) < 2e-5
+    db = dpre[..., :cout].sum((0, 1, 2))
+    assert float((res["1"][1].double().sum(0)[:cout] - db).abs().max() / db.abs().max()) < 2e-5

@@ -44,7 +44,8 @@ def test_plain_command_self_launches_two_ranks():
     assert out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["headline"] is False                       # a shape override is never a headline number
     assert out["sustained"]["steps"] >= 2
-    assert abs(out["value"] - 2 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 1e-3
+    # (`value` is printed with two decimals: on a loaded CPU host it is ~2 img/s, so allow the rounding step)
+    assert abs(out["value"] - 2 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-3 * out["value"] + 0.006
 
 
 @pytest.mark.timeout(600)

@@ -99,6 +99,18 @@ def test_wgrad_4_row_tiles(cin, cout, H, monkeypatch):
     test_conv_layer_wide_channels(cin, cout, H, 1)
 
 
+@pytest.mark.parametrize("cin,cout,H,N", [(16, 16, 36, 1), (32, 16, 24, 2), (64, 16, 16, 1), (16, 32, 20, 1),
+                                          (16, 64, 16, 1), (32, 32, 24, 1), (32, 80, 16, 1), (64, 64, 20, 1)])
+def test_wave_specialised_wgrad_is_bit_identical(cin, cout, H, N, monkeypatch):
+    """wgrad_ws.hip (producer / consumer waves, double-buffered LDS images) against wgrad_kernel.h on every wave layout
+    of plan_wgrad's plain 3x3 classes — ragged image sides, several tiles per workgroup, bias partials, the fused
+    BatchNorm / LeakyReLU backward of the dy loader: the same MFMA order, so the partial rows are bit-identical."""
+    import _seg_checks as S
+    S.check_wgrad_ws_bit_identical("cpu", cin, cout, H, N, monkeypatch)
+    monkeypatch.setenv("AMX_WGRAD_WGS", "3")          # 1-3 workgroups: every one walks several tiles (both LDS images,
+    S.check_wgrad_ws_bit_identical("cpu", cin, cout, H, N, monkeypatch)     # the two-tiles-ahead load issue)
+
+
 def test_adam_flat_kernel_vs_torch_adam_fp64():
     import _adam_checks as A
     A.check_adam_flat_kernel("cpu")

@@ -271,6 +271,15 @@ def test_wave_specialised_two_source_layer(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,N", [(32, 16, 200, 6), (16, 32, 131, 5), (32, 32, 128, 8), (64, 32, 77, 7),
+                                          (32, 64, 96, 4), (64, 64, 64, 9), (128, 128, 40, 8), (64, 16, 90, 3)])
+def test_wave_specialised_wgrad_is_bit_identical(cin, cout, H, N, monkeypatch):
+    """wgrad_ws.hip (producer / consumer waves) against wgrad_kernel.h: many tiles per persistent workgroup, ragged
+    image sides; partial rows bit-identical, their sum against fp64 autograd."""
+    C.check_wgrad_ws_bit_identical("cuda", cin, cout, H, N, monkeypatch)
+
+
+@pytest.mark.gpu
 def test_loss_upstream_gradient_factor():
     C.check_loss_upstream_gradient("cuda")
 
