@@ -35,6 +35,11 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     if (const char* e = getenv("AMX_WGRAD_LIGHT")) { const int v = atoi(e); if (v >= 64) { light = pl.ci_pad <= 32; light_wgs = v; } }
     pl.th = (taps == 9 && dil == 1 && (light || pl.NT == 2)) ? 4 : 8;
     if (const char* e = getenv("AMX_WGRAD_TH")) { const int v = atoi(e); if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }
+    // 16 -> 32 channels (U-Net c2.0) on the wave-specialised kernel: with 4-row tiles a consumer wave has ONE row (72 MFMAs,
+    // ~1 us) per tile and the producers' loads of tile k+2 are not back when tile k+1 must be staged; 8-row tiles double the
+    // prefetch distance and cut the halo re-read from 1.69x to 1.41x (profiles/r04_wgrad_ws.md)
+    if (taps == 9 && dil == 1 && !lat && pl.NT == 2 && pl.WM == 1 && pl.WN == 1 && amx_wgrad_ws_mask() & 1 && !getenv("AMX_WGRAD_TH"))
+        pl.th = 8;
     if (lat) pl.th = pl.NT == 2 ? 4 : 8;                    // the instantiated lattice classes
     if (pl.WK > pl.th) pl.WK = pl.th;
     pl.lat = lat ? odil : 0;
@@ -138,7 +143,7 @@ static int wgrad_common(const float* x0, const float* sc0, const float* sh0, int
         if (pl.WM == 2) return launch_wgrad<T, 2, 2, H_, TH_>(a, s);                \
         return launch_wgrad<T, 2, 4, H_, TH_>(a, s);                                \
     }
-    if (amx_wgrad_ws_supported(a, taps, dil, pl.lat, pl.NT, pl.WM, pl.th)) return amx_wgrad_launch_ws(a, pl.NT, pl.WM, s);
+    if (amx_wgrad_ws_supported(a, taps, dil, pl.lat, pl.NT, pl.WM, pl.th)) return amx_wgrad_launch_ws(a, pl.NT, pl.WM, pl.th, s);
     if (pl.lat == 2) return amx_wgrad_launch_lat2(a, pl.NT, pl.WM, s);
     if (pl.lat == 4) return amx_wgrad_launch_lat4(a, pl.NT, pl.WM, s);
     if (pl.lat == 6) return amx_wgrad_launch_lat6(a, pl.NT, pl.WM, s);

@@ -343,8 +343,9 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
 
 
 // wave-specialised (producer / consumer) kernel for the plain 3x3 classes: wgrad_ws.hip
+int amx_wgrad_ws_mask();            // 0 = off; else the AMX_WGRAD_WS_MASK bits (1 = WM 1, 2 = WM 2, 4 = WM 4)
 bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int nt, int wm, int th);
-int amx_wgrad_launch_ws(const WgradArgs& a, int nt, int wm, hipStream_t s);
+int amx_wgrad_launch_ws(const WgradArgs& a, int nt, int wm, int th, hipStream_t s);
 
 // lattice-mode instantiation units (one per dilation: compiled in parallel); nt in {1, 2} with th = 8 / 4 as planned
 int amx_wgrad_launch_lat2(const WgradArgs& a, int nt, int wm, hipStream_t s);

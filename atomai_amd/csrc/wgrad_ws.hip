@@ -40,6 +40,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int XLD = (NPIX_X * CG + 255) / 256;
     constexpr int COB = 16 * NT * WN;                             // the wave grid is compile-time here: WM x WN x WK = 4
     constexpr int WK = 4 / (WM * WN);
+    constexpr int NSTEP = (TH / WK) * (TW / 4);                  // k-steps (4 pixels) of a consumer wave per tile
     constexpr int DG = COB / 4;
     constexpr int dg_shift = DG == 4 ? 2 : (DG == 8 ? 3 : 4);
     constexpr int SD = (COB % 32 == 16) ? COB : COB + 16;
@@ -82,23 +83,43 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
         for (int tile = blockIdx.x; tile < ntiles; tile += a.ksplit, ++k) {
             const float* s_x = smem + (size_t)(k & 1) * BUF;
             const float* s_d = s_x + XF;
-            #pragma unroll 1
-            for (int r = wk; r < TH; r += WK) {
+            // Software-pipelined sweep: the 9 + NT operand values of k-step s + 1 are fetched into a second register
+            // set while the 9 * NT MFMAs of step s issue (left to itself the compiler re-uses two operand registers and
+            // waits for every ds_read right behind it — an LDS round trip exposed per 2-3 MFMAs, with ONE wave per SIMD).
+            // Same (row, k-step, tap) order as wgrad_kernel.h -> bit-identical accumulators.
+            float af[2][TAPS], bf[2][NT];
+            // one lane base per image and tile; every operand address is that base + a compile-time offset (the top-left
+            // halo pixel of the wave's first row, so that all offsets are >= 0: the ds_read immediate is unsigned)
+            const float* xl = s_x + (size_t)(wk * IW + g) * SX + wm * 16 + p;
+            const float* dl = s_d + (size_t)(wk * TW + g) * SD + wn * NT * 16 + p;
+            auto fetch = [&](int st, float (&fa)[TAPS], float (&fb)[NT]) {
+                const int rr = (st / (TW / 4)) * WK, kx = st % (TW / 4);     // row relative to the wave's first, k-step
                 #pragma unroll
-                for (int kx = 0; kx < TW / 4; ++kx) {
-                    float bf[NT];
+                for (int q = 0; q < NT; ++q)
+                    fb[q] = dl[(rr * TW + kx * 4) * SD + q * 16];
+                #pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int dy = t / 3 - 1, dx = t % 3 - 1;
+                    fa[t] = xl[((rr + 1 + dy) * IW + kx * 4 + 1 + dx) * SX];
+                }
+            };
+            fetch(0, af[0], bf[0]);
+            #pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 1 < NSTEP) fetch(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+                #pragma unroll
+                for (int t = 0; t < TAPS; ++t)
                     #pragma unroll
                     for (int q = 0; q < NT; ++q)
-                        bf[q] = s_d[(size_t)(r * TW + kx * 4 + g) * SD + (wn * NT + q) * 16 + p];
-                    #pragma unroll
-                    for (int t = 0; t < TAPS; ++t) {
-                        const int dy = t / 3 - 1, dx = t % 3 - 1;
-                        const float af = s_x[(size_t)((r + 1 + dy) * IW + kx * 4 + g + 1 + dx) * SX + wm * 16 + p];
-                        #pragma unroll
-                        for (int q = 0; q < NT; ++q)
-                            acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[q], acc[t][q], 0, 0, 0);
-                    }
+                        acc[t][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st & 1][t], bf[st & 1][q], acc[t][q], 0, 0, 0);
+#ifndef AMX_EMU
+                // issue order: one operand fetch of the NEXT step behind every NT MFMAs of this one
+                #pragma unroll
+                for (int t = 0; t < TAPS + NT; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);     // NT MFMA
                 }
+#endif
             }
             WG_TICK(0);
             __syncthreads();
@@ -315,27 +336,31 @@ static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
 // Which launches the wave-specialised kernel takes: the plain 3x3 classes of plan_wgrad (lattice-mode dilated layers and
 // the 1x1 / halo classes stay on wgrad_kernel.h).  AMX_WGRAD_WS: 0 = off, 1 (default) = the classes of AMX_WGRAD_WS_MASK,
 // a bit mask over the wave layouts: 1 = WM 1 (16 input channels), 2 = WM 2 (32), 4 = WM 4 (>= 64).
-bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int nt, int wm, int th) {
+int amx_wgrad_ws_mask() {
     int mode = 1, mask = 7;
     if (const char* e = getenv("AMX_WGRAD_WS")) mode = atoi(e);
     if (const char* e = getenv("AMX_WGRAD_WS_MASK")) mask = atoi(e);
-    if (mode <= 0 || taps != 9 || dil != 1 || lat) return false;
-    if (!(mask & wm)) return false;
-    if (!((nt == 1 && th == 8) || (nt == 2 && th == 4))) return false;
-    (void)a;
-    return true;
+    return mode <= 0 ? 0 : (mask & 7);
+}
+
+bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int nt, int wm, int th) {
+    if (taps != 9 || dil != 1 || lat) return false;
+    if (!(amx_wgrad_ws_mask() & wm)) return false;
+    if (nt == 1) return th == 8;
+    return th == 4 || (th == 8 && wm == 1 && a.WN == 1);
 }
 
 static long wgrad_ws_launches = 0;
 extern "C" long amx_conv2d_wgrad_ws_launches(void) { return wgrad_ws_launches; }
 
-int amx_wgrad_launch_ws(const WgradArgs& a, int nt, int wm, hipStream_t s) {
+int amx_wgrad_launch_ws(const WgradArgs& a, int nt, int wm, int th, hipStream_t s) {
     ++wgrad_ws_launches;
     if (nt == 1) {                                                // 16 output channels: one cout tile, WN = 1
         if (wm == 1) return launch_wgrad_ws<1, 1, 1, 8, 0>(a, s);
         if (wm == 2) return launch_wgrad_ws<1, 2, 1, 8, 0>(a, s);
         return launch_wgrad_ws<1, 4, 1, 8, 0>(a, s);
     }
+    if (wm == 1 && th == 8) return launch_wgrad_ws<2, 1, 1, 8, 0>(a, s);
     if (wm == 1) return a.WN == 2 ? launch_wgrad_ws<2, 1, 2, 4, 0>(a, s) : launch_wgrad_ws<2, 1, 1, 4, 0>(a, s);
     if (wm == 2) return a.WN == 2 ? launch_wgrad_ws<2, 2, 2, 4, 0>(a, s) : launch_wgrad_ws<2, 2, 1, 4, 0>(a, s);
     return launch_wgrad_ws<2, 4, 1, 4, 0>(a, s);

@@ -474,8 +474,10 @@ class ConvNode(_Node):
         # The weight gradient (MFMA-bound) has no consumer inside backward: side stream.
         w_in = (dpre, aux, kptr)
         d_in = (dpre, aux, kptr) if dpre_mat is None else (dpre_mat, None, (None, None, None))
-        with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
-            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
+        order = _wgrad_order()
+        if order == 0 or self.x_plain is not None:
+            with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
+                self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         if self.x_plain is not None:
             return
         s0 = self.srcs[0]
@@ -484,6 +486,13 @@ class ConvNode(_Node):
         C0, C0s = s0.C, s0.Cs
         C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
         self._dgrad(tape, d_in[0], d_in[1], d_in[2], s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp)
+        if order == 1:
+            # the weight gradient starts when this layer's DATA gradient has finished and runs next to the HBM-bound
+            # BatchNorm-backward / pooling passes of the layer below instead of next to the data gradient
+            with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
+                self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
+        elif order == 2:
+            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)       # experiment: everything on one stream
 
     def _wgrad(self, tape, dpre, aux, kptr, dw, a, want_bias) -> None:
         w = self.conv.weight
@@ -967,6 +976,16 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     with a fresh stream per step every 4th one landed on the main stream's queue and that step lost the
     weight-gradient overlap (+2.6 ms, visible as a period-4 pattern in the per-step times)."""
     return aux_stream(dev, 0)
+
+
+def _wgrad_order() -> int:
+    """AMX_WGRAD_ORDER (read per backward, so an in-process A/B can flip it): 0 = the weight gradient of a layer is
+    enqueued on the side stream BEFORE the layer's data gradient (both MFMA kernels share the CUs), 1 = after it (the side
+    stream waits for the data gradient), 2 = on the main stream after it (no overlap at all)."""
+    return int(_os.environ.get("AMX_WGRAD_ORDER", _WGRAD_ORDER_DEFAULT))
+
+
+_WGRAD_ORDER_DEFAULT = "0"
 
 
 class _SideCtx:

@@ -51,18 +51,23 @@ def step():
     X = rs.rand(64, 512, 512).astype(np.float32); y = rs.randint(0, 3, (64, 512, 512))
     m = aoi.models.Segmentor("Unet", nb_classes=3, seed=1)
     m.compile_trainer((X, y, X[:32], y[:32]), training_cycles=10, batch_size=32)
-    cfgs = [("0", "7"), ("1", "7"), ("1", "3"), ("1", "4"), ("1", "2"), ("1", "1")]
+    # (AMX_WGRAD_WS, AMX_WGRAD_WS_MASK, AMX_WGRAD_ORDER, AMX_CONV_WS_DGRAD)
+    cfgs = [("0", "7", "0", "3"), ("1", "7", "0", "3"), ("1", "7", "1", "3"), ("0", "7", "1", "3"), ("1", "7", "1", "7"),
+            ("1", "7", "2", "7"), ("1", "3", "1", "3"), ("1", "3", "0", "3")]
+    if len(sys.argv) > 2:
+        cfgs = [tuple(c.split(",")) for c in sys.argv[2:]]
     res = {c: [] for c in cfgs}
     for rep in range(3):
         for c in cfgs:
-            os.environ["AMX_WGRAD_WS"], os.environ["AMX_WGRAD_WS_MASK"] = c
+            (os.environ["AMX_WGRAD_WS"], os.environ["AMX_WGRAD_WS_MASK"], os.environ["AMX_WGRAD_ORDER"],
+             os.environ["AMX_CONV_WS_DGRAD"]) = c
             for i in range(3): m.train_step(m.X_train[i % 2], m.y_train[i % 2])
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for i in range(10): m.train_step(m.X_train[i % 2], m.y_train[i % 2])
             torch.cuda.synchronize()
             res[c].append((time.perf_counter() - t0) / 10 * 1e3)
     for k, v in res.items():
-        print(f"AMX_WGRAD_WS={k[0]} MASK={k[1]}: step ms {['%.3f' % t for t in v]}  min {min(v):.3f}", flush=True)
+        print(f"WGRAD_WS={k[0]} MASK={k[1]} ORDER={k[2]} CONV_WS_DGRAD={k[3]}: step ms {['%.3f' % t for t in v]}  min {min(v):.3f}", flush=True)
 
 
 if what in ("standalone", "all"):
