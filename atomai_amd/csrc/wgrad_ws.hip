@@ -5,13 +5,13 @@
 // "stage tile k -> barrier -> issue loads of tile k+1 -> MFMA sweep -> barrier".  With one wave per SIMD nothing hides the
 // loader: the matrix pipe idles through staging, the barriers and the load issue (profiles/r03_pmc_sq.md: MFMA pipe busy
 // 0.47-0.49 on the 16 / 32-channel classes, 0.66 on the 64-channel class; tools/gpu_wgrad_phases.py: 23 % of a tile
-// outside the sweep).  Here the two kinds of work run in DIFFERENT waves of one persistent 8-wave workgroup per CU — the
+// outside the sweep).  Here the two kinds of work run in DIFFERENT waves of one persistent 8- or 12-wave workgroup per CU — the
 // recipe conv_ws.hip proved on the same layers' forward / data-gradient launches:
 //
 //   waves 0..3 (consumers, one per SIMD): ds_read_b32 operand fetches + v_mfma_f32_16x16x4_f32 only — the sweep of
 //                          wgrad_kernel.h, same (wm, wn, wk) wave grid, same row / k-step / tap order -> the partial rows
 //                          are BIT-IDENTICAL to the one-kind-of-wave kernel's (tests compare them);
-//   waves 4..7 (producers, s_setprio 3): global loads of tile k+2 into registers; BatchNorm affine (+ LeakyReLU of a
+//   waves 4..7 / 4..11 (producers, s_setprio 3): global loads of tile k+2 into registers; BatchNorm affine (+ LeakyReLU of a
 //                          ResBlock input) + zero padding of x, the fused BN / LeakyReLU backward of dy and the bias-gradient
 //                          partial sums while staging tile k+1 into the OTHER LDS image (double-buffered).
 //
@@ -26,10 +26,10 @@
 #define AMX_WGRAD_WS_PRIO 3
 #endif
 
-// AMX_WGRAD_PROFILE (dev builds, tools/gpu_wgrad_phases.py): [workgroup][wave][8] shader-clock totals — consumers:
+// AMX_WGRAD_PROFILE (dev builds, tools/gpu_wgrad_ws_phases.py): [workgroup][12 wave slots][8] shader-clock totals — consumers:
 // 0 sweep, 1 barrier wait; producers: 2 stage, 3 issue, 4 barrier wait; 6 tiles, 7 lifetime.
-template <int NT, int WM, int WN, int TH, int LAT>
-__global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
+template <int NT, int WM, int WN, int TH, int LAT, int NP>
+__global__ __launch_bounds__(256 + NP) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int TAPS = 9;
     constexpr int LS = LAT ? LAT : 1;
     constexpr int CIB = 16 * WM;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;         // == 16 mod 32
     constexpr int IW = TW + 2, IH = TH + 2;
     constexpr int NPIX_X = IH * IW;
-    constexpr int XLD = (NPIX_X * CG + 255) / 256;
+    constexpr int XLD = (NPIX_X * CG + NP - 1) / NP;              // NP = producer threads (4 or 8 waves)
     constexpr int COB = 16 * NT * WN;                             // the wave grid is compile-time here: WM x WN x WK = 4
     constexpr int WK = 4 / (WM * WN);
     constexpr int NSTEP = (TH / WK) * (TW / 4);                  // k-steps (4 pixels) of a consumer wave per tile
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int dg_shift = DG == 4 ? 2 : (DG == 8 ? 3 : 4);
     constexpr int SD = (COB % 32 == 16) ? COB : COB + 16;
     constexpr int nd4 = TH * TW * DG;
-    constexpr int DLD_MAX = (nd4 + 255) / 256;
+    constexpr int DLD_MAX = (nd4 + NP - 1) / NP;
     constexpr int XF = NPIX_X * SX;                               // floats of one x image
     constexpr int BUF = XF + TH * TW * SD;                        // floats of one (x, dpre) image pair
     AMX_DYN_SMEM(float, smem);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
         int x_rel[XLD], x_yx[XLD];
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
-            const int pix = (ptid + i * 256) / CG;
+            const int pix = (ptid + i * NP) / CG;
             x_yx[i] = -1; x_rel[i] = 0;
             if (pix < NPIX_X && xsrc) {
                 const int iy = pix / IW, ix = pix - iy * IW;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
         int d_rel[DLD_MAX], d_yx[DLD_MAX];
         #pragma unroll
         for (int i = 0; i < DLD_MAX; ++i) {
-            const int idx = ptid + i * 256;
+            const int idx = ptid + i * NP;
             d_yx[i] = -1; d_rel[i] = 0;
             if (idx < nd4) {
                 const int pix = idx >> dg_shift, dg = idx & (DG - 1);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
             float* s_d = s_x + XF;
             #pragma unroll
             for (int i = 0; i < XLD; ++i) {
-                const int pix = (ptid + i * 256) / CG;
+                const int pix = (ptid + i * NP) / CG;
                 if (pix < NPIX_X) {
                     float4 v = xr[i];
                     v.x = fmaf(v.x, r_sc.x, r_sh.x); v.y = fmaf(v.y, r_sc.y, r_sh.y);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
             }
             #pragma unroll
             for (int i = 0; i < DLD_MAX; ++i) {
-                const int idx = ptid + i * 256;
+                const int idx = ptid + i * NP;
                 if (idx < nd4) {
                     const int pix = idx >> dg_shift, dg = idx & (DG - 1);
                     float4 v = dr[i];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
         __syncthreads();
         if (tid < DG) {
             float4 t = make_float4(0, 0, 0, 0);
-            for (int q = tid; q < 256; q += DG) { const float4 u = red[q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+            for (int q = tid; q < NP; q += DG) { const float4 u = red[q]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
             const int c = co0 + tid * 4;
             const float tv[4] = {t.x, t.y, t.z, t.w};
             for (int e = 0; e < 4; ++e) if (c + e < a.co_pad) a.bpart[(size_t)blockIdx.x * a.co_pad + c + e] = tv[e];
@@ -306,12 +306,12 @@ __global__ __launch_bounds__(512) void wgrad_ws_kernel(WgradArgs a) {
 #ifdef AMX_WGRAD_PROFILE
     pt[7] = __builtin_amdgcn_s_memtime() - pstart;
     if (a.prof && lane == 0)
-        for (int i = 0; i < 8; ++i) a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + i] = pt[i];
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 12 + wave) * 8 + i] = pt[i];
 #endif
 }
 
-template <int NT, int WM, int WN, int TH, int LAT>
-static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
+template <int NT, int WM, int WN, int TH, int LAT, int NP>
+static int launch_wgrad_ws_np(const WgradArgs& a, hipStream_t stream) {
     constexpr int CIB = 16 * WM;
     constexpr int SX = (CIB % 32 == 16) ? CIB : CIB + 16;
     constexpr int COB = 16 * NT * WN;
@@ -322,15 +322,26 @@ static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_ws_kernel<NT, WM, WN, TH, LAT>,
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_ws_kernel<NT, WM, WN, TH, LAT, NP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((wgrad_ws_kernel<NT, WM, WN, TH, LAT>), grid, dim3(512), lds, stream, a);
+    AMX_LAUNCH((wgrad_ws_kernel<NT, WM, WN, TH, LAT, NP>), grid, dim3(256 + NP), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
+}
+
+// Producer waves: 8 on the <= 32-input-channel classes (with 4 the producers' stage + issue phases fill the whole tile time
+// there and the consumers wait 13-24 % of their life at the barrier; with 8 they wait 2-9 %: 0.66 -> 0.68, 0.60 -> 0.66,
+// 0.74 -> 0.77 of peak stand-alone), 4 on the 64-channel class (no difference: 0.81-0.83 either way);
+// profiles/r04_logs/r04_wgrad_ws_phases2.log, r04_wgrad_ws_np_ab.log.  AMX_WGRAD_WS_PRODUCERS = 4 | 8 overrides (A/B).
+template <int NT, int WM, int WN, int TH, int LAT>
+static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
+    int np = WM < 4 ? 8 : 4;
+    if (const char* e = getenv("AMX_WGRAD_WS_PRODUCERS")) np = atoi(e) == 4 ? 4 : 8;
+    return np == 4 ? launch_wgrad_ws_np<NT, WM, WN, TH, LAT, 256>(a, stream) : launch_wgrad_ws_np<NT, WM, WN, TH, LAT, 512>(a, stream);
 }
 
 // Which launches the wave-specialised kernel takes: the plain 3x3 classes of plan_wgrad (lattice-mode dilated layers and

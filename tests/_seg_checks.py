@@ -527,7 +527,8 @@ def check_wgrad_ws_bit_identical(device, cin, cout, H, N, monkeypatch, W=None, t
     # (16 -> 32..48 channels: the plan picks 8-row tiles for wgrad_ws.hip and 4-row tiles otherwise unless AMX_WGRAD_TH says)
     if force_th is not None or not (cin <= 16 and 32 <= cout <= 48):
         assert torch.equal(res["0"][0], res["1"][0])
-        assert torch.equal(res["0"][1][:, :cout], res["1"][1][:, :cout])
+        # (bias partials: the 8 producer waves of wgrad_ws.hip split a tile's pixels differently from the 4 waves of
+        #  wgrad_kernel.h — another fixed summation order; they are compared with fp64 below)
     # against fp64 autograd of the convolution
     xin = x0.double().cpu() * sc0.double().cpu() + sh0.double().cpu()
     if two:

@@ -22,7 +22,7 @@ def run(N, H, C0, C1, Cout):
     rows = lib.amx_conv2d_wgrad_rows(N, H, H, C0 + C1, Cout, 9, 1)
     ks = lib.amx_conv2d_wgrad_ksplit(N, H, H, C0 + C1, Cout, 9, 1)
     part = torch.empty(rows, 9, r16(C0 + C1), r16(Cout), device=dev)
-    prof = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device=dev)
+    prof = torch.zeros(8192 * 12 * 8, dtype=torch.int64, device=dev)
     lib.amx_wgrad_set_profile_buffer(ctypes.c_void_p(prof.data_ptr()))
 
     def go():
@@ -36,9 +36,11 @@ def run(N, H, C0, C1, Cout):
     e0.record(); go(); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     lib.amx_wgrad_set_profile_buffer(None)
-    t = prof.cpu().numpy().reshape(-1, 8, 8).astype(np.float64)
+    t = prof.cpu().numpy().reshape(-1, 12, 8).astype(np.float64)
     t = t[t[:, 0, 7] > 0]
     cons, prod = t[:, :4].reshape(-1, 8), t[:, 4:].reshape(-1, 8)
+    prod = prod[prod[:, 7] > 0]                     # 4 or 8 producer waves
+    print(f"   ({prod.shape[0] // t.shape[0]} producer waves per workgroup)")
     tiles = cons[:, 6].sum()
     tf = 2.0 * N * H * H * (C0 + C1) * Cout * 9 / ms / 1e9
     print(f"== wgrad_ws {C0}+{C1}->{Cout} @{H} B={N}: {ms*1e3:.1f} us = {tf:.1f} TFLOP/s ({tf/157.3:.3f}); split-K {ks}, "
@@ -46,7 +48,8 @@ def run(N, H, C0, C1, Cout):
     for who, arr, idx in (("consumer", cons, ((0, "MFMA sweep"), (1, "barrier wait"))),
                           ("producer", prod, ((2, "stage (+ wait for loads)"), (3, "issue loads"), (4, "barrier wait")))):
         for i, name in idx:
-            print(f"   {who} {name:28s} {100 * arr[:, i].sum() / arr[:, 7].sum():5.1f} % of lifetime   {arr[:, i].sum() / tiles:9.0f} clocks per tile")
+            per = arr[:, i].sum() / tiles / (arr.shape[0] / cons.shape[0])
+            print(f"   {who} {name:28s} {100 * arr[:, i].sum() / arr[:, 7].sum():5.1f} % of lifetime   {per:9.0f} clocks per tile")
 
 
 for shape in [(512, 16, 16, 16), (256, 16, 0, 32), (256, 32, 0, 32), (256, 32, 32, 32), (128, 64, 0, 64), (64, 128, 0, 128)]:
