@@ -21,6 +21,9 @@ class IoU:
                                       "path: the trainers always pass logits (trainers/trainer.py:727-737)")
         if pred.ndim != 4:
             raise AssertionError("expected predictions of shape (N, K, H, W)")
+        if pred.shape[1] > 8:
+            raise NotImplementedError(f"IoU on the device supports up to 8 classes (got {pred.shape[1]}): the per-frame "
+                                      "confusion histogram of amx_iou_hist is K x K <= 8 x 8, like the CE loss kernel")
         self.thresh = thresh
         N, K = pred.shape[0], pred.shape[1]
         HW = pred.shape[2] * pred.shape[3]

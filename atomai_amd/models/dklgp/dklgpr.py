@@ -10,8 +10,21 @@ from ...trainers.gptrainer import dklGPTrainer
 class dklGPR(dklGPTrainer):
     """``dklGPR(indim, embedim=2, shared_embedding_space=True, precision='double', ...)``"""
 
+    _noted_exact_gp = False
+
     def __init__(self, indim: int, embedim: int = 2, shared_embedding_space: bool = True, **kwargs) -> None:
         super().__init__(indim, embedim, shared_embedding_space, **kwargs)
+        if not dklGPR._noted_exact_gp:
+            dklGPR._noted_exact_gp = True
+            # Stated once per process (SURVEY.md section 8 rows C2-C4, "parity unpinned"): the GP on top of the feature
+            # extractor is NOT the reference's model.
+            import warnings
+            warnings.warn("atomai_amd.dklGPR evaluates an EXACT dense GP (tiled RBF / Matern covariance on the MI355X, "
+                          "Cholesky solve) on the embedded points; the reference wraps the same base kernel in gpytorch's "
+                          "KISS-GP approximation (GridInterpolationKernel, grid_size=50 — atomai/nets/gp.py:41-46) and "
+                          "trains through gpytorch's CG / Lanczos estimators, so posteriors and hyper-parameter "
+                          "trajectories agree with the reference only up to that approximation; there is no gpytorch in "
+                          "this build to pin them against (oracle/gp_oracle.py)", UserWarning, stacklevel=2)
 
     def fit(self, X, y, training_cycles: int = 1, **kwargs) -> None:
         _ = self.run(X, y, training_cycles, **kwargs)
@@ -88,4 +101,5 @@ class dklGPR(dklGPTrainer):
         x_new, _ = self.set_data(x_new, device='cpu')
         bs = kwargs.get("batch_size", len(x_new))
         out = [self._embed(x_new[i:i + bs]) for i in range(0, len(x_new), bs)]
-        return torch.cat(out).numpy()
+        # independent per-output networks (GPModelList) embed to (q, n, embedim): the chunks join along the SAMPLE axis
+        return torch.cat(out, dim=-2).numpy()

@@ -8,6 +8,9 @@ from .blocks import ConvBlock, DilatedBlock, ResModule, UpsampleBlock
 from ._function import run_tape
 
 
+_warned_modular = False
+
+
 class _HipNet(nn.Module):
     def _build(self, tape, x):
         raise NotImplementedError
@@ -19,6 +22,13 @@ class _HipNet(nn.Module):
         # Utilities such as get_downsample_factor hook every top-level child and need it invoked via
         # __call__ (atomai/utils/nn.py:215-228): honour that with the block-by-block path.
         if any(len(m._forward_hooks) or len(m._forward_pre_hooks) for m in self.children()):
+            global _warned_modular
+            if not _warned_modular:
+                _warned_modular = True
+                import warnings
+                warnings.warn("a forward hook is attached to a block of this network: the forward pass runs block by block "
+                              "(each block on its HIP kernels, pooling / concatenation through ATen) instead of the fused "
+                              "single-tape path, so that the hook sees its block's input and output", RuntimeWarning)
             return self._modular(x)
         return run_tape(self._build, x, list(self.parameters()), self.training)
 

@@ -21,6 +21,8 @@ class DataParallelGrads:
         self.optimizer = optimizer
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.timing = False                                   # bench.py: time every gradient all-reduce
+        self._timings = []
         optimizer.prepare()
         optimizer.grad_scale = 1.0 / self.world
         # identical initial weights on every rank (buffers too: BN running stats)
@@ -31,6 +33,11 @@ class DataParallelGrads:
         if net is not None:
             for b in net.buffers():
                 dist.broadcast(b, src=0)
+        # parameters (views of the flat buffer) and BatchNorm buffers were just rewritten behind their version counters:
+        # invalidate the packed-weight images and the cached eval-mode affines / folded heads keyed on them
+        from . import engine
+        engine.bump_weight_generation()
+        engine._bn_generation[0] += 1
 
     def allreduce_grads(self) -> None:
         opt = self.optimizer
@@ -40,7 +47,29 @@ class DataParallelGrads:
             if p.grad is not None and p.grad.data_ptr() != gbase + 4 * off:
                 f["g"][off:off + p.numel()].copy_(p.grad.reshape(-1))
                 p.grad = f["g"][off:off + p.numel()].view(p.shape)
-        dist.all_reduce(f["g"], op=dist.ReduceOp.SUM)
+        g = f["g"]
+        if not self.timing:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return
+        # Events on the launch stream around the collective: the first one sits behind backward's last kernel, the
+        # second behind the stream-level wait torch inserts for the (R)CCL stream, so the pair holds the all-reduce only.
+        if g.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            e1.record()
+            self._timings.append((e0, e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            self._timings.append((time.perf_counter() - t0) * 1e3)
+
+    def allreduce_ms(self):
+        """Milliseconds of every timed gradient all-reduce so far (``timing = True``); synchronises the device."""
+        if any(isinstance(t, tuple) for t in self._timings):
+            torch.cuda.synchronize()
+        return [t[0].elapsed_time(t[1]) if isinstance(t, tuple) else t for t in self._timings]
 
 
 def shard_range(n: int, rank: int, world: int):

@@ -327,11 +327,13 @@ class BaseTrainer:
         if self.criterion is None:
             self.criterion = self.get_loss_fn(loss, self.nb_classes)
         if not self.full_epoch:
-            seed = kwargs.get("batch_seed", 1) + rank
-            for name, data in (("batch_idx_train", self.X_train), ("batch_idx_test", self.X_test)):
+            seed = kwargs.get("batch_seed", 1)
+            # the TRAINING schedule differs per rank (each rank walks its own shard); test data is not sharded, so its
+            # schedule keeps the un-offset seed and every rank reports the test losses of a single-process run
+            for name, data, sd in (("batch_idx_train", self.X_train, seed + rank), ("batch_idx_test", self.X_test, seed)):
                 reps = self.training_cycles // len(data) + 1
                 idx = np.arange(len(data)).repeat(reps)[:self.training_cycles]
-                setattr(self, name, _shuffle(idx, seed))
+                setattr(self, name, _shuffle(idx, sd))
         self.print_loss = kwargs.get("print_loss") or (1 if self.full_epoch else 100)
         self.accuracy_metrics = kwargs.get("accuracy_metrics")
         self.filename = kwargs.get("filename", "./model")

@@ -283,9 +283,14 @@ class datatransform:
         if keep is not None and not keep.all():
             idx = torch.from_numpy(np.nonzero(keep)[0]).to(x.device)
             x, targets = x.index_select(0, idx).contiguous(), targets.index_select(0, idx).contiguous()
-        if x.shape[0]:
-            mm = _minmax(x)                                   # kept referenced until the launch is enqueued
-            L.call("amx_aug_renorm", L.ptr(x), x.numel(), L.ptr(mm), L.stream_ptr(x))
+        if not x.shape[0]:
+            # the reference's squeeze_channels drops a pair as soon as one class is absent after the transform; it then
+            # fails inside the next conv with a shape error — say what happened instead
+            raise RuntimeError("data augmentation dropped every image of the batch: after the geometric transform at least "
+                               "one label class is missing from each frame (the reference's squeeze_channels rule, "
+                               "transforms/imaug.py:361-393); use larger frames / zoom windows or fewer classes")
+        mm = _minmax(x)                                       # kept referenced until the launch is enqueued
+        L.call("amx_aug_renorm", L.ptr(x), x.numel(), L.ptr(mm), L.stream_ptr(x))
         return x[:, None], targets
 
 

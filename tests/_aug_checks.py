@@ -128,8 +128,10 @@ def check_class_drop_and_trainer_hook(device):
     Xn = rs.rand(8, 16, 16).astype(np.float32)
     yn = rs.randint(0, 3, (8, 16, 16))
     m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, seed=1)
-    m.fit(Xn, yn, Xn[:4], yn[:4], training_cycles=3, batch_size=4, rotation=True, gauss_noise=[20, 40], contrast=True,
-          background=True, plot_training_history=False)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:               # fit() writes <filename>_metadict_final.tar
+        m.fit(Xn, yn, Xn[:4], yn[:4], training_cycles=3, batch_size=4, rotation=True, gauss_noise=[20, 40], contrast=True,
+              background=True, plot_training_history=False, filename=os.path.join(tmp, "model"))
     assert len(m.loss_acc["train_loss"]) == 3 and all(np.isfinite(m.loss_acc["train_loss"]))
 
 

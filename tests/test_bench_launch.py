@@ -1,4 +1,5 @@
-"""bench.py's launch contract, end to end on CPU (gloo + the kernel emulator, tiny shape override):
+"""bench.py's launch contract, end to end on CPU (bench.main() driven by tests/emu/bench_emu.py: gloo + the kernel
+emulator, tiny shape override):
   * `python bench.py --gpus 2` with NO launcher spawns its two ranks itself and prints ONE JSON line (n_gpus 2);
   * the same command under `python -m torch.distributed.run` (the driver's N>1 command) works too;
   * the line carries the fields the driver's contract names."""
@@ -12,7 +13,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TINY = ["--test-backend", "emu", "--hw", "16", "--bs", "2", "--nb-filters", "4", "--steps", "2", "--warmup", "1",
+BENCH = os.path.join(ROOT, "tests", "emu", "bench_emu.py")     # bench.main() on the CPU emulator + gloo (test helper)
+TINY = ["--hw", "16", "--bs", "2", "--nb-filters", "4", "--steps", "2", "--warmup", "1",
         "--sustain-seconds", "0.01"]
 REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config"]
@@ -32,7 +34,7 @@ def _clean_env():
 def test_plain_command_self_launches_two_ranks():
     if torch.cuda.is_available():
         pytest.skip("CPU/gloo tier")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY, env=_clean_env(),
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + TINY, env=_clean_env(),
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
@@ -48,6 +50,28 @@ def test_plain_command_self_launches_two_ranks():
     assert abs(out["value"] - 2 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-3 * out["value"] + 0.006
 
 
+@pytest.mark.timeout(900)
+def test_plain_command_self_launches_eight_ranks():
+    """The driver's widest shape (`--gpus 8`): eight ranks, one JSON line, and the diagnosis fields a first real 8-GPU
+    run will be read by — every rank's own step time and the time of its gradient all-reduces."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"] + TINY, env=_clean_env(),
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 8 and out["config"]["world_size_seen"] == 8 and out["config"]["global_batch"] == 16
+    assert out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert len(out["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in out["per_rank_ms_per_step"])
+    assert len(out["allreduce_ms_per_rank_mean"]) == 8 and out["allreduce_ms"] > 0
+    assert out["allreduce_bytes"] > 0
+    # whole-job value = 8 ranks x bs 2 x steps / the slowest rank's region
+    assert abs(out["value"] - 8 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-3 * out["value"] + 0.006
+    assert max(out["per_rank_ms_per_step"]) <= out["ms_per_step"] * 1.001 + 1e-3
+
+
 @pytest.mark.timeout(600)
 def test_torchrun_launch_two_ranks():
     if torch.cuda.is_available():
@@ -56,7 +80,7 @@ def test_torchrun_launch_two_ranks():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY
+           "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2"] + TINY
     r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
@@ -66,6 +90,6 @@ def test_torchrun_launch_two_ranks():
 
 def test_gpus_flag_must_match_world_size():
     env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY, env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY, env=env,     # the product script
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -200,7 +200,7 @@ def test_two_rank_rvae_step_matches_averaged_gradient_oracle():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # fit(..., distributed=True): the training ENTRY POINT of the data-parallel path
-def _fit_worker(rank, world, port, q, tmp):
+def _fit_worker(rank, world, port, q, tmp, n_samples=8, cycles=3):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(HERE, "emu"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -209,11 +209,11 @@ def _fit_worker(rank, world, port, q, tmp):
     emu_backend.use_emulator()
     import atomai_amd as aoi
     rs = np.random.RandomState(30)
-    X = rs.rand(8, 16, 16).astype(np.float32)                  # the WHOLE training set on every rank: fit() shards it
-    y = rs.randint(0, 3, (8, 16, 16))
+    X = rs.rand(n_samples, 16, 16).astype(np.float32)          # the WHOLE training set on every rank: fit() shards it
+    y = rs.randint(0, 3, (n_samples, 16, 16))
     Xt, yt = X[:2], y[:2]
     m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, seed=1 + rank)   # different init, broadcast by fit
-    m.fit(X, y, Xt, yt, training_cycles=3, batch_size=2, distributed=True, plot_training_history=False,
+    m.fit(X, y, Xt, yt, training_cycles=cycles, batch_size=2, distributed=True, plot_training_history=False,
           filename=os.path.join(tmp, "seg"))
     q.put((rank, list(m.loss_acc["train_loss"]), list(m.loss_acc["test_loss"]), list(m.batch_idx_train),
            [t.numpy().copy() for t in m.X_train],
@@ -222,46 +222,46 @@ def _fit_worker(rank, world, port, q, tmp):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_segmentor_fit_distributed_matches_averaged_gradient_oracle(tmp_path):
-    if torch.cuda.is_available():
-        pytest.skip("CPU/gloo tier")
+def _check_fit_distributed(world, n_samples, cycles, tmp_path):
     from oracle import seg_oracle as so
     from sklearn.utils import shuffle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, q, str(tmp_path), n_samples, cycles)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict()
-    for _ in range(2):
-        r, *rest = q.get(timeout=500)
+    for _ in range(world):
+        r, *rest = q.get(timeout=800)
         got[r] = rest
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
     assert os.path.exists(tmp_path / "seg_metadict_final.tar")          # rank 0 saved (and only rank 0 writes)
     rs = np.random.RandomState(30)
-    X = rs.rand(8, 16, 16).astype(np.float32)
-    y = rs.randint(0, 3, (8, 16, 16))
-    # shards: rank r owns samples [4r, 4r+4) = 2 mini-batches; schedule = the reference's shuffle with batch_seed + rank
-    for r in range(2):
-        sched = shuffle(np.arange(2).repeat(3 // 2 + 1)[:3], random_state=1 + r)
+    X = rs.rand(n_samples, 16, 16).astype(np.float32)
+    y = rs.randint(0, 3, (n_samples, 16, 16))
+    per = n_samples // world                                            # equal shards; the n % world tail is dropped
+    nb = per // 2                                                       # mini-batches of 2 per rank
+    # shards: rank r owns samples [per*r, per*(r+1)); schedule = the reference's shuffle with batch_seed + rank
+    for r in range(world):
+        sched = shuffle(np.arange(nb).repeat(cycles // nb + 1)[:cycles], random_state=1 + r)
         assert got[r][2] == list(sched), (r, got[r][2])
-        for b in range(2):
-            np.testing.assert_array_equal(got[r][3][b][:, 0], X[4 * r + 2 * b:4 * r + 2 * b + 2])
-    # oracle: 2 replicas from rank 0's weights (seed 1), each on its own scheduled mini-batch, gradients averaged
+        assert len(got[r][3]) == nb
+        for b in range(nb):
+            np.testing.assert_array_equal(got[r][3][b][:, 0], X[per * r + 2 * b:per * r + 2 * b + 2])
+    # oracle: `world` replicas from rank 0's weights (seed 1), each on its own scheduled mini-batch, gradients averaged
     sd = so.cast(so.init_unet(3, 4, seed=1), torch.float64)
-    bn = [OrderedDict(sd), OrderedDict(sd)]
+    bn = [OrderedDict(sd) for _ in range(world)]
     opt = so.AdamState(lr=1e-3)
-    ref_losses = [[], []]
-    for step in range(3):
+    ref_losses = [[] for _ in range(world)]
+    for step in range(cycles):
         grads = []
-        for r in range(2):
+        for r in range(world):
             b = got[r][2][step]
-            xb = torch.from_numpy(X[4 * r + 2 * b:4 * r + 2 * b + 2][:, None]).double()
-            yb = torch.from_numpy(y[4 * r + 2 * b:4 * r + 2 * b + 2])
+            xb = torch.from_numpy(X[per * r + 2 * b:per * r + 2 * b + 2][:, None]).double()
+            yb = torch.from_numpy(y[per * r + 2 * b:per * r + 2 * b + 2])
             rep = OrderedDict((k, (sd[k] if k in so.param_keys(sd) else bn[r][k].clone())) for k in sd)
             loss, _, g = so.loss_and_grads("Unet", rep, xb, yb, 3)
             ref_losses[r].append(float(loss))
@@ -269,13 +269,30 @@ def test_segmentor_fit_distributed_matches_averaged_gradient_oracle(tmp_path):
                 if k not in g:
                     bn[r][k] = rep[k]
             grads.append(g)
-        opt.step(sd, {k: 0.5 * (grads[0][k] + grads[1][k]) for k in grads[0]})
-    for r in range(2):
+        opt.step(sd, {k: sum(g[k] for g in grads) / world for k in grads[0]})
+    for r in range(world):
         np.testing.assert_allclose(got[r][0], ref_losses[r], rtol=1e-4)
     for k in so.param_keys(sd):
-        assert np.array_equal(got[0][4][k], got[1][4][k]), k
+        for r in range(1, world):
+            assert np.array_equal(got[0][4][k], got[r][4][k]), (k, r)       # replicas stay bit-identical
         a = torch.from_numpy(got[0][4][k]).double()
         assert float((a - sd[k]).abs().max()) < 3e-3 * max(1.0, float(sd[k].abs().max())), k
+
+
+@pytest.mark.timeout(600)
+def test_segmentor_fit_distributed_matches_averaged_gradient_oracle(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    _check_fit_distributed(2, 8, 3, tmp_path)
+
+
+@pytest.mark.timeout(900)
+def test_segmentor_fit_distributed_eight_ranks_ragged_shard(tmp_path):
+    """The driver's 8-GPU shape on CPU: world size 8, 19 samples (not divisible by 8: 2 per rank, the tail of 3 is
+    dropped so that every rank holds the same number of collectives), against the 8-replica averaged-gradient oracle."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    _check_fit_distributed(8, 19, 2, tmp_path)
 
 
 def _rvae_fit_worker(rank, world, port, q, tmp):

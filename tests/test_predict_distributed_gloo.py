@@ -104,6 +104,61 @@ def test_two_rank_predict_is_bit_identical_to_single_process():
     assert np.array_equal(got[1]["nogather"][1], dec1[2:5])
 
 
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    from atomai_amd.parallel import init_distributed
+    init_distributed("gloo")
+    p = aoi.predictors.SegPredictor(_model(), use_gpu=False, nb_classes=1, downsampling=2, verbose=False)
+    dec, coords = p.run(_stack(), compute_coords=True, distributed=True, thresh=0.5)     # 5 frames over 8 ranks
+    lo, part = p.predict(_stack(), distributed=True, gather=False)
+    q.put((rank, dec if rank == 0 else dec.shape, coords if rank == 0 else None, lo, part.shape))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_predict_with_more_ranks_than_frames():
+    """The driver's 8-GPU shape on CPU: 5 frames over 8 ranks — three ranks own an EMPTY frame range, the global
+    min / max all-reduce still has 8 participants; rank 0's gathered output is bit-identical to a single process."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import emu_backend
+    emu_backend.use_emulator()
+    import atomai_amd as aoi
+    from atomai_amd.predictors import SegPredictor
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(8):
+        r, *rest = q.get(timeout=800)
+        got[r] = rest
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sp = aoi.predictors.SegPredictor(_model(), use_gpu=False, nb_classes=1, downsampling=2, verbose=False)
+    dec1, c1 = sp.run(_stack(), compute_coords=True, thresh=0.5)
+    assert np.array_equal(got[0][0], dec1) and sorted(got[0][1]) == list(range(5))
+    for i in c1:
+        assert np.array_equal(got[0][1][i], c1[i])
+    sizes = []
+    for r in range(8):
+        lo, hi = SegPredictor.frame_range(5, r, 8)
+        assert got[r][2] == lo and got[r][3][0] == hi - lo
+        sizes.append(hi - lo)
+    assert sum(sizes) == 5 and sizes.count(0) == 3
+
+
 def test_frame_ranges_partition_the_stack():
     from atomai_amd.predictors import SegPredictor
     for n in (0, 1, 5, 8, 4096, 4099):
