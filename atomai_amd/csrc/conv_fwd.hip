@@ -69,13 +69,17 @@ struct ConvEpi {
     int nds = 0; float ds_inv_slope = 1.f;
 };
 
+// loader extras of the data gradient that forms dpre from (dy, a) on the fly (conv_kernel.h: ConvFwdArgs::bw_*)
+struct ConvBwdLoad { const float* aux; const float* k1; const float* k2; const float* k3; float slope; };
+
 // C ABI — see include/atomai_amd.h for the contract.
 static int conv2d_common(const float* x0, const float* sc0, const float* sh0, int C0s,
                          const float* x1, const float* sc1, const float* sh1, int C1s,
                          const float* wpk, const float* bias, const float* addend,
                          float* y, int Y0s, float* y1, int Y1s, float* stats,
                          int N, int H, int W, int cout, int taps, int dil, float slope, void* stream,
-                         float in_slope0 = 1.f, float in_slope1 = 1.f, const ConvEpi* epi = nullptr) {
+                         float in_slope0 = 1.f, float in_slope1 = 1.f, const ConvEpi* epi = nullptr,
+                         const ConvBwdLoad* bw = nullptr) {
     const float* hw = epi ? epi->hw : nullptr; const float* hb = epi ? epi->hb : nullptr;
     float* hout = epi ? epi->hout : nullptr; const int hK = epi ? epi->hK : 0, hmode = epi ? epi->hmode : 0;
     const int nds = epi ? epi->nds : 0;
@@ -98,6 +102,8 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.nds = nds; a.ds_inv_slope = epi ? epi->ds_inv_slope : 1.f;         // fused DilatedBlock sum (eval) or 0
     for (int l = 0; l < 3; ++l) a.ds_a[l] = (epi && l < nds) ? epi->ds_a[l] : nullptr;
     for (int l = 0; l < 4; ++l) { a.ds_sc[l] = (epi && l <= nds) ? epi->ds_sc[l] : nullptr; a.ds_sh[l] = (epi && l <= nds) ? epi->ds_sh[l] : nullptr; }
+    a.bw_aux = bw ? bw->aux : nullptr; a.bw_k1 = bw ? bw->k1 : nullptr; a.bw_k2 = bw ? bw->k2 : nullptr;
+    a.bw_k3 = bw ? bw->k3 : nullptr; a.bw_slope = bw ? bw->slope : 1.f;
     a.prof = nullptr;
 #ifdef AMX_CONV_PROFILE
     a.prof = (unsigned long long*)amx_conv_profile_buffer;               // dev build: per-wave phase timestamps
@@ -124,6 +130,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     const bool tail = a.tail_kg < KG;                       // partial last chunk: cheaper tail path
     if (amx_conv_ws_supported(a, taps, dil, pl.th / 4, in_slope0, in_slope1)) return amx_conv_launch_ws(a, s);
+    if (a.bw_aux) AMX_BADARG(14);                           // the on-load BatchNorm backward exists in conv_ws.hip only
     if (amx_lattice_mode(taps, dil)) {                          // tiles of the (largest) residue-class sub-image
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);
@@ -216,6 +223,27 @@ extern "C" int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, con
                                 void* stream) {
     return conv2d_common(dpre, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, addend, y, Y0s, y1,
                          Y1s, nullptr, N, H, W, Y0s + Y1s, taps, dil, 1.f, stream);
+}
+
+// Data gradient with the layer's BatchNorm / LeakyReLU backward formed by the loader (no materialised dpre): only for
+// launches the wave-specialised kernel takes (amx_conv2d_dgrad_fused_supported), whose producer waves have the
+// registers and issue slots for the second tensor.  Replaces amx_bn_bwd_apply + amx_conv2d_dgrad for those layers.
+extern "C" int amx_conv2d_dgrad_fused(const float* dy, const float* aux, const float* k1, const float* k2,
+                                      const float* k3, float bslope, int Cs, const float* wpk, float* y, int Y0s,
+                                      float* y1, int Y1s, int N, int H, int W, int taps, int dil, void* stream) {
+    if (!aux) AMX_BADARG(14);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(15);
+    ConvBwdLoad bw{aux, k1, k2, k3, bslope};
+    return conv2d_common(dy, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, nullptr, y, Y0s, y1,
+                         Y1s, nullptr, N, H, W, Y0s + Y1s, taps, dil, 1.f, stream, 1.f, 1.f, nullptr, &bw);
+}
+extern "C" int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil) {
+    if (Cs <= 0 || Y0s <= 0 || (taps != 1 && taps != 9)) return 0;
+    if (const char* e = getenv("AMX_BWD_FUSE")) if (atoi(e) == 0) return 0;
+    ConvFwdArgs a = {};
+    a.C0s = Cs; a.Y0s = Y0s; a.Y1s = Y1s; a.cout = Y0s + Y1s; a.N = N; a.H = H; a.W = W;
+    a.bw_aux = reinterpret_cast<const float*>(&a);          // (any non-null value: the query dereferences nothing)
+    return amx_conv_ws_supported(a, taps, dil, plan_conv(Cs, Y0s + Y1s, taps, dil, H).th / 4, 1.f, 1.f) ? 1 : 0;
 }
 
 // Height (in image rows) of the 16-pixel-wide strip one partial-statistics row of amx_conv2d_fwd covers for this

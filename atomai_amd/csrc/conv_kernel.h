@@ -75,6 +75,12 @@ struct ConvFwdArgs {
     const float* ds_a[3];
     const float* ds_sc[4]; const float* ds_sh[4];
     int nds; float ds_inv_slope;
+    // ---- data gradient with the producing layer's BatchNorm / LeakyReLU backward formed while loading (conv_ws.hip,
+    // round 4): x0 = dy, the gradient w.r.t. the layer's OUTPUT; the convolution input is
+    //   dpre = lrelu'(a) * (k1 * dy + k2 * a + k3)       (amx_bn_bwd_apply's arithmetic, never written to HBM)
+    const float* bw_aux;                   // the layer's saved activation a (shape of x0), or nullptr
+    const float* bw_k1; const float* bw_k2; const float* bw_k3;      // per-channel constants (all three or none)
+    float bw_slope;
     unsigned long long* prof;   // AMX_CONV_PROFILE builds: per-wave phase clocks (or nullptr)
     int N, H, W;
     int cout;            // real number of output channels

@@ -65,7 +65,12 @@ static __device__ __forceinline__ int amx_wave_uniform(int v) {
 // floats; the consumers' fragment reads are contiguous within a plane and do not care
 template <int NCH> struct WsPlane { static constexpr int value = NCH == 2 ? 338 : 340; };
 
-template <int NCH, int NT>
+// BWD (round 4): the data-gradient launch of a layer with BatchNorm — x0 is dy, the gradient w.r.t. the layer's output, and
+// the producers form  dpre = lrelu'(a) * (k1 * dy + k2 * a + k3)  from (dy, a) while staging (ConvFwdArgs::bw_*; the
+// arithmetic of amx_bn_bwd_apply, so the input image — and hence the result — is bit-identical to the two-pass form).
+// The separate amx_bn_bwd_apply pass (read dy, read a, write dpre: 0.16-0.32 ms per thin layer, on the critical path of
+// the backward pass) disappears; the producers' second load stream costs registers only they need.
+template <int NCH, int NT, bool BWD>
 __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
     constexpr int COP = 16 * NT;
     constexpr int G = KG * NCH;                                   // 4-channel groups of the concatenated input
@@ -166,6 +171,10 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
             src = (const char*)(a.x1 + (ch - a.C0s)); cs_bytes = (unsigned)a.C1s * 4u;
             if (a.sc1) { r_sc = amx_ld4(a.sc1 + (ch - a.C0s)); r_sh = amx_ld4(a.sh1 + (ch - a.C0s)); }
         }
+        // (the three per-channel constants of the on-load backward are re-read from L1 when a tile is staged: holding them
+        //  next to two 6-slot register images pushed the 32-channel class over the 128 registers a 16-wave workgroup has)
+        const long aux_delta = BWD ? (const char*)a.bw_aux - (const char*)a.x0 : 0;      // bytes from dy to the saved activation
+        const float bslope = a.bw_slope;
         int yx[XLD];                                              // (iy << 8) | ix of the thread's slots (the last may be past the image: -1)
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
             yx[i] = slot < WS_SLOTS ? ((iy << 8) | ix) : -1;
         }
         float4 xr[XLD];
+        float4 ar[BWD ? XLD : 1];
         unsigned xvalid = 0;
         auto tile_of = [&](int k, int& n, int& ty, int& tx) {
             int t = first + k * step;
@@ -197,17 +207,30 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
                 const int iy = yx[i] >> 8, ix = yx[i] & 255;      // (-1 -> row -1, column 255: clamped like any other)
                 const int cy = min(max(iy, ylo), yhi), cx = min(max(ix, xlo), xhi);
                 if (cy == iy && cx == ix) xvalid |= 1u << i;
-                xr[i] = *reinterpret_cast<const float4*>(base + (unsigned)(cy * a.W + cx) * cs_bytes);
+                const char* pa = base + (unsigned)(cy * a.W + cx) * cs_bytes;
+                xr[i] = *reinterpret_cast<const float4*>(pa);
+                if (BWD) ar[i] = *reinterpret_cast<const float4*>(pa + aux_delta);
             }
         };
         auto stage = [&](int buf) {
             float* dst = s_in + (size_t)buf * IN_FLOATS + (size_t)c8 * PLANE * 4 + (size_t)slot0 * 4;
+            float4 c1 = make_float4(1.f, 1.f, 1.f, 1.f), c2 = make_float4(0.f, 0.f, 0.f, 0.f), c3 = c2;
+            if (BWD && a.bw_k1) { c1 = amx_ld4(a.bw_k1 + ch); c2 = amx_ld4(a.bw_k2 + ch); c3 = amx_ld4(a.bw_k3 + ch); }
             #pragma unroll
             for (int i = 0; i < XLD; ++i) {
                 if (i + 1 == XLD && yx[i] < 0) continue;          // (only the last load of a thread can fall off the image)
                 const float4 v = xr[i];
-                float4 w = make_float4(fmaf(v.x, r_sc.x, r_sh.x), fmaf(v.y, r_sc.y, r_sh.y),
-                                       fmaf(v.z, r_sc.z, r_sh.z), fmaf(v.w, r_sc.w, r_sh.w));
+                float4 w;
+                if (BWD) {
+                    const float4 t = ar[i];
+                    w.x = (t.x > 0.f ? 1.f : bslope) * fmaf(c1.x, v.x, fmaf(c2.x, t.x, c3.x));
+                    w.y = (t.y > 0.f ? 1.f : bslope) * fmaf(c1.y, v.y, fmaf(c2.y, t.y, c3.y));
+                    w.z = (t.z > 0.f ? 1.f : bslope) * fmaf(c1.z, v.z, fmaf(c2.z, t.z, c3.z));
+                    w.w = (t.w > 0.f ? 1.f : bslope) * fmaf(c1.w, v.w, fmaf(c2.w, t.w, c3.w));
+                } else {
+                    w = make_float4(fmaf(v.x, r_sc.x, r_sh.x), fmaf(v.y, r_sc.y, r_sh.y),
+                                    fmaf(v.z, r_sc.z, r_sh.z), fmaf(v.w, r_sc.w, r_sh.w));
+                }
                 if (!(xvalid & (1u << i))) w = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding (AFTER the affine)
                 amx_st4(dst + (size_t)i * (512 / G) * 4, w);
             }
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
 #endif
 }
 
-template <int NCH, int NT>
+template <int NCH, int NT, bool BWD>
 static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
     constexpr int COP = 16 * NT;
     const size_t lds = ((size_t)NCH * 9 * KG * COP * 4 + 2 * (size_t)KG * NCH * WsPlane<NCH>::value * 4 + (size_t)COP * WS_PS) * sizeof(float);
@@ -310,12 +333,12 @@ static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_ws_kernel<NCH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_ws_kernel<NCH, NT, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_ws_kernel<NCH, NT>), dim3(wgs), dim3(1024), lds, stream, a);
+    AMX_LAUNCH((conv_ws_kernel<NCH, NT, BWD>), dim3(wgs), dim3(1024), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -329,14 +352,16 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
     // only (a bias is present), 3 = data gradients only (every class).  AMX_CONV_WS_DGRAD is a mask of data-gradient
     // classes: 1 = two-output launches (the data gradient of a layer that read a concatenation — U-Net c6.0: 16 -> 16 + 16,
     // the FIRST data gradient of the backward pass), 2 = 32 -> 32 channels (c5.3, c2.3), 4 = the rest (32 -> 16: c2.0, the
-    // last one, which finds the side stream's backlog of weight gradients in its way); default 3.
+    // last one, which finds the side stream's backlog of weight gradients in its way); default 7 since round 4: with the
+    // layer's BatchNorm backward formed by this kernel's loader (BWD) every class saves its amx_bn_bwd_apply pass, and the
+    // 32 -> 16 launch, a 0.09 ms loss in round 3, becomes a gain (17.95 -> 17.80 ms, profiles/r04_logs/r04_bwd_fuse_ab.log).
     // Stand-alone the kernel is 12-27 % faster than conv_kernel.h on every thin shape, forward and data gradient alike
     // (profiles/r03_wave_specialised.md).  Inside the training step a persistent 16-wave workgroup owns its CU's LDS and
     // registers, so the weight-gradient kernels of the side stream cannot run next to a wave-specialised data gradient
     // and the lost overlap competes with what the faster kernel wins; measured per class in-process
     // (profiles/r03_dgrad_first_ab.log): forward only 18.17 ms, + c6.0 18.03, + the two 32 -> 32 launches 17.99, while the
     // 32 -> 16 launch costs 0.09 ms (all classes: 18.1-18.5, the round's earlier "no gain" result).
-    int mode = 1, dmask = 3;
+    int mode = 1, dmask = 7;
     if (const char* e = getenv("AMX_CONV_WS")) mode = atoi(e);
     if (const char* e = getenv("AMX_CONV_WS_DGRAD")) dmask = atoi(e);
     if (mode <= 0) return false;
@@ -345,6 +370,7 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
         const int cls = a.Y1s > 0 ? 1 : ((a.C0s + a.C1s == 32 && a.cout == 32) ? 2 : 4);
         if (!(dmask & cls)) return false;
     }
+    if (a.bw_aux && (a.bias || a.C1s || a.sc0 || a.stats)) return false;      // the on-load backward: one plain dy source
     if (taps != 9 || dil != 1 || a.hout || a.nds || a.addend || in_slope0 != 1.f || in_slope1 != 1.f) return false;
     const int cin = a.C0s + a.C1s;
     if ((cin != 16 && cin != 32) || (a.C0s & 15) || (a.C1s & 15)) return false;
@@ -362,6 +388,10 @@ int amx_conv_launch_ws(ConvFwdArgs& a, hipStream_t s) {
     ++ws_launches;
     a.tiles_x = a.W / TILE; a.tiles_y = a.H / TILE;
     const int nch = (a.C0s + a.C1s) / 16;
-    if (nch == 1) return a.cout == 16 ? launch_conv_ws<1, 1>(a, s) : launch_conv_ws<1, 2>(a, s);
-    return a.cout == 16 ? launch_conv_ws<2, 1>(a, s) : launch_conv_ws<2, 2>(a, s);
+    if (a.bw_aux) {
+        if (nch == 1) return a.cout == 16 ? launch_conv_ws<1, 1, true>(a, s) : launch_conv_ws<1, 2, true>(a, s);
+        return a.cout == 16 ? launch_conv_ws<2, 1, true>(a, s) : launch_conv_ws<2, 2, true>(a, s);
+    }
+    if (nch == 1) return a.cout == 16 ? launch_conv_ws<1, 1, false>(a, s) : launch_conv_ws<1, 2, false>(a, s);
+    return a.cout == 16 ? launch_conv_ws<2, 1, false>(a, s) : launch_conv_ws<2, 2, false>(a, s);
 }

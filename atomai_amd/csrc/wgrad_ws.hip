@@ -347,8 +347,13 @@ static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
 // Which launches the wave-specialised kernel takes: the plain 3x3 classes of plan_wgrad (lattice-mode dilated layers and
 // the 1x1 / halo classes stay on wgrad_kernel.h).  AMX_WGRAD_WS: 0 = off, 1 (default) = the classes of AMX_WGRAD_WS_MASK,
 // a bit mask over the wave layouts: 1 = WM 1 (16 input channels), 2 = WM 2 (32), 4 = WM 4 (>= 64).
+// Default mask 3: stand-alone the kernel wins on every class (+20 % on the 64-channel one), but inside the training step a
+// persistent 8-wave / 109 KB workgroup of that class keeps the main stream's convolution workgroups off its CU while the
+// one-wave-per-SIMD kernel of wgrad_kernel.h lets them in: U-Net step 17.40 ms with mask 7, 17.25 with mask 3, 18.04 with
+// mask 4 (profiles/r04_logs/r04_step_ab5.log; the thin classes are where the loaders' fused BatchNorm backward needs the
+// producer waves: 18.24 ms without the wave-specialised kernel at all).
 int amx_wgrad_ws_mask() {
-    int mode = 1, mask = 7;
+    int mode = 1, mask = 3;
     if (const char* e = getenv("AMX_WGRAD_WS")) mode = atoi(e);
     if (const char* e = getenv("AMX_WGRAD_WS_MASK")) mask = atoi(e);
     return mode <= 0 ? 0 : (mask & 7);

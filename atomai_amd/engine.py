@@ -406,6 +406,10 @@ class ConvNode(_Node):
                    npix, cos, L.ptr(masked), None, sp)
             dy = masked
         fused = out.gx is None and bool(FUSE & 4) and self.mask is None
+        # Round 4: layers whose data gradient runs on the wave-specialised kernel form dpre inside BOTH consumers' loaders
+        # (amx_conv2d_dgrad_fused / amx_conv2d_wgrad_fused) — no amx_bn_bwd_apply pass, dpre never exists in HBM.
+        fused_ws = (not fused and self._bwd_fusable(out)) if self.bn is not None else False
+        fused = fused or fused_ws
         k = None
         aux = None
         bias_part = None
@@ -428,7 +432,7 @@ class ConvNode(_Node):
             tape.add_param_grad(bn.bias, dbeta)
         needs_transform = self.bn is not None or self.slope != 1.0 or out.gx is not None
         dpre_mat = None
-        if needs_transform and fused:
+        if needs_transform and fused and not fused_ws:
             # experiment mode: one of the two consumers still wants a materialised dpre
             arows = L.load().amx_rows_for(npix)
             bias_part = _empty((arows, cos), a) if has_bias else None
@@ -493,6 +497,24 @@ class ConvNode(_Node):
                 self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         elif order == 2:
             self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)       # experiment: everything on one stream
+
+    def _bwd_fusable(self, out) -> bool:
+        """True when this layer's BatchNorm / LeakyReLU backward can be formed inside the loaders of its two consumers
+        (round 4): the data gradient must be a launch of the wave-specialised kernel writing fresh gradients (no
+        accumulation into an existing one), nothing else may be folded into dpre (dropout mask, DilatedBlock sum)."""
+        if self.x_plain is not None or self.mask is not None or out.gx is not None or self.post_slope != 1.0:
+            return False
+        if not self.srcs or len(self.srcs) > 2:
+            return False
+        s0 = self.srcs[0]
+        s1 = self.srcs[1] if len(self.srcs) > 1 else None
+        if not (s0.needs_grad or (s1 is not None and s1.needs_grad)):
+            return False
+        for s in (s0, s1):
+            if s is not None and (not s.needs_grad or s.grad is not None or s.gx is not None):
+                return False
+        return bool(L.load().amx_conv2d_dgrad_fused_supported(out.Cs, s0.Cs, s1.Cs if s1 else 0, s0.N, s0.H, s0.W,
+                                                              self.taps, self.dil))
 
     def _wgrad(self, tape, dpre, aux, kptr, dw, a, want_bias) -> None:
         w = self.conv.weight
@@ -603,7 +625,12 @@ class ConvNode(_Node):
             y1 = scratch
         else:
             scratch, y1 = None, tgt[1][0]
-        assert aux is None, "the data-gradient kernel takes a materialised dpre"
+        if aux is not None:
+            # dpre is formed by the loader of the wave-specialised kernel from (dy, a) (_bwd_fusable guarantees support)
+            assert add0 is None and scratch is None
+            L.call("amx_conv2d_dgrad_fused", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope, cos,
+                   L.ptr(wpk), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, N, H, W, self.taps, self.dil, sp)
+            return
         L.call("amx_conv2d_dgrad", L.ptr(dpre), cos, L.ptr(wpk), L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s,
                N, H, W, self.taps, self.dil, sp)
         if scratch is not None:

@@ -62,6 +62,16 @@ int amx_conv2d_fwd_dsum(const float* x0, const float* sc0, const float* sh0, int
                         int n, float* y, int N, int H, int W, int cout, int dil, float slope, void* stream);
 int amx_conv2d_dgrad(const float* dpre, int Cs, const float* wpk, const float* addend, float* y, int Y0s, float* y1,
                      int Y1s, int N, int H, int W, int taps, int dil, void* stream);
+/* Data gradient of a conv -> LeakyReLU -> BatchNorm layer with the BatchNorm / LeakyReLU backward formed by the loader:
+ * the convolution input is dpre = lrelu'(a) * (k1*dy + k2*a + k3) (amx_bn_bwd_apply's arithmetic, bit-identical), read
+ * from dy (gradient w.r.t. the layer output) and the saved activation a, never written to HBM.  Only for launches the
+ * wave-specialised kernel takes (amx_conv2d_dgrad_fused_supported == 1: plain 3x3, 16 / 32 channels either side, image
+ * sides in multiples of 16, no addend); together with amx_conv2d_wgrad_fused it replaces the amx_bn_bwd_apply pass of
+ * those layers (autograd of blocks.py:61-76 through nn.BatchNorm2d / nn.LeakyReLU). */
+int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil);
+int amx_conv2d_dgrad_fused(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
+                           float bslope, int Cs, const float* wpk, float* y, int Y0s, float* y1, int Y1s,
+                           int N, int H, int W, int taps, int dil, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
 /* Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images x[ry::d, rx::d]; their

@@ -542,3 +542,55 @@ def check_wgrad_ws_bit_identical(device, cin, cout, H, N, monkeypatch, W=None, t
         got = res[ws][0].double().sum(0)[:, :cin, :cout].permute(2, 1, 0).reshape(cout, cin, 3, 3)
         assert float((got - dw).abs().max() / dw.abs().max()) < 2e-5
         assert float((res[ws][1].double().sum(0)[:cout] - db).abs().max() / db.abs().max()) < 2e-5
+
+
+def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, unet=False):
+    """Round 4: BatchNorm / LeakyReLU backward formed inside the loaders of the wave-specialised data-gradient and
+    weight-gradient kernels (amx_conv2d_dgrad_fused / amx_conv2d_wgrad_fused) against the two-pass form (amx_bn_bwd_apply
+    materialises dpre): the loaders use amx_bn_bwd_apply's arithmetic, so input and weight gradients are BIT-IDENTICAL;
+    the conv bias gradient is summed in another (fixed) order.  Also checks that the fused launches happen and that
+    amx_bn_bwd_apply is skipped for exactly those layers."""
+    import atomai_amd as aoi
+    from atomai_amd import _lib as L
+    from atomai_amd.nets import ConvBlock
+    monkeypatch.setenv("AMX_CONV_WS", "1")
+    monkeypatch.setenv("AMX_CONV_WS_DGRAD", "7")
+    out, calls = {}, {}
+    real_call = L.call
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AMX_BWD_FUSE", mode)
+        cnt = {}
+
+        def counting(name, *a, _c=cnt):
+            _c[name] = _c.get(name, 0) + 1
+            return real_call(name, *a)
+        monkeypatch.setattr(L, "call", counting)
+        if unet:
+            torch.manual_seed(5)
+            net, _ = aoi.nets.init_fcnn_model("Unet", 3, nb_filters=16)
+            net = net.to(device).train()
+            x = torch.randn(batch, 1, hw, hw, device=device)
+            y = net(x)
+            y.backward(torch.ones_like(y) / y.numel())
+            grads = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+        else:
+            torch.manual_seed(3)
+            m = ConvBlock(2, 2, cin, cout, batch_norm=True).to(device)
+            x = torch.randn(batch, cin, hw, hw, device=device).requires_grad_(True)
+            y = m(x)
+            torch.manual_seed(4)
+            y.backward(torch.randn_like(y))
+            grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+            grads["x"] = x.grad.detach().cpu()
+        monkeypatch.setattr(L, "call", real_call)
+        out[mode], calls[mode] = grads, cnt
+    nf = calls["1"].get("amx_conv2d_dgrad_fused", 0)
+    assert nf >= 1 and calls["0"].get("amx_conv2d_dgrad_fused", 0) == 0, calls
+    assert calls["0"]["amx_bn_bwd_apply"] - calls["1"].get("amx_bn_bwd_apply", 0) == nf, calls
+    for k in out["0"]:
+        a, b = out["1"][k], out["0"][k]
+        if k == "x" or (k.endswith("weight") and a.ndim == 4):
+            assert torch.equal(a, b), k
+        else:
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()))
+    return nf

@@ -174,6 +174,18 @@ def test_wave_specialised_two_source_layer(monkeypatch):
     C.check_wave_specialised_concat("cpu", monkeypatch)
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 16), (16, 16)])
+def test_bn_backward_formed_in_the_loaders(cin, cout, monkeypatch):
+    """amx_conv2d_dgrad_fused / amx_conv2d_wgrad_fused against amx_bn_bwd_apply + the plain kernels (bit-identical)."""
+    C.check_bwd_fused_in_loaders("cpu", cin, cout, monkeypatch)
+
+
+def test_bn_backward_formed_in_the_loaders_unet(monkeypatch):
+    """U-Net nb_filters 16 at 64x64: c6.0 (two outputs), c5.3 / c2.3 (32 -> 32) and c2.0 (32 -> 16) take the fused path."""
+    assert C.check_bwd_fused_in_loaders("cpu", 0, 0, monkeypatch, hw=64, batch=2, unet=True) == 4
+
+
+
 def test_loss_upstream_gradient_factor():
     C.check_loss_upstream_gradient("cpu")
 

@@ -99,20 +99,76 @@ def test_full_width_vs_oracle_on_device(model, ncls, B, H):
     loss.backward()
     ref_loss, ref_logits, ref_grads = _oracle_on("cuda", sd, x, y, ncls, model)
     # logits and gradients are judged against the oracle in fp64, relative to the noise the oracle's own fp32 run shows
-    # against fp64 (deep nets: 12 residual blocks amplify fp32 rounding and LeakyReLU kink flips; SURVEY section 7
-    # "Parity budget"): two correct fp32 implementations differ from each other by up to twice that floor
+    # against fp64 (deep nets: 12 residual blocks amplify fp32 rounding; SURVEY section 7 "Parity budget"): two correct
+    # fp32 implementations differ from each other by up to twice that floor
     from oracle import seg_oracle as so
     y64 = y if ncls > 1 else y.double()
-    _, logits64, g64 = _oracle_on("cuda", so.cast(sd, torch.float64), x.double(), y64, ncls, model)
+    sd64 = so.cast(sd, torch.float64)
+    _, logits64, g64 = _oracle_on("cuda", sd64, x.double(), y64, ncls, model)
     l64 = logits64.cpu().numpy()
     lfloor = C.relmax(ref_logits.cpu().double().numpy(), l64)
     assert C.relmax(logits.detach().cpu().double().numpy(), l64) < max(2 * lfloor, C.REL_TOL), lfloor
     assert abs(loss.item() - float(ref_loss)) / abs(float(ref_loss)) < 1e-5
+    # Kink-aware gradient bound (the old `max(4 x floor, 1e-3)` slack was never quantified).
+    # LeakyReLU is not differentiable at 0: an input within rounding distance of 0 may take either branch in two correct
+    # fp32 implementations, which changes that element's derivative by a factor 100.  The oracle is run once more in fp64
+    # with EVERY LeakyReLU input closer than 1e-5 to 0 on the opposite branch (seg_oracle.KINK_FLIP); the gradient change
+    # `sens` bounds, to first order, what any choice of branches at those elements can do.  Measured on the MI355X
+    # (profiles/r04_fullsize_parity_probe.log): U-Net 512^2 — 1547 such inputs, worst error 4.1e-5 against a reference-fp32
+    # floor of 1.2e-4 and sens 1.1e-3: the U-Net is held to the north-star 1e-4 with NO kink or floor allowance; dilnet
+    # 2.6e-4 (floor 1.2e-4, sens 5.7e-3), SegResNet 1.3e-4 (= its floor), ResHedNet 1.9e-2 (floor 1.3e-2: 30 layers).
+    so.KINK_FLIP = [1e-5, 0]
+    try:
+        _, _, gflip = _oracle_on("cuda", sd64, x.double(), y64, ncls, model)
+        nkink = so.KINK_FLIP[1]
+    finally:
+        so.KINK_FLIP = None
     gmax = max(float(g.abs().max()) for g in g64.values())
+    report = []
     for k, p in net.named_parameters():
         err = float((p.grad.double() - g64[k]).abs().max()) / gmax
         floor = float((ref_grads[k].double() - g64[k]).abs().max()) / gmax
-        assert err < max(4 * floor, 1e-3), (k, err, floor)
+        sens = float((gflip[k] - g64[k]).abs().max()) / gmax
+        bound = C.REL_TOL if model == "Unet" else C.REL_TOL + sens + 2 * floor
+        report.append((err / bound, k, err, floor, sens))
+        assert err < bound, (k, err, floor, sens, nkink)
+    worst = max(report)
+    print(f"{model}: {nkink} LeakyReLU inputs within 1e-5 of 0; worst gradient error {worst[2]:.2e} ({worst[1]}; reference-fp32 "
+          f"floor {worst[3]:.2e}, kink sensitivity {worst[4]:.2e})")
+
+
+def test_config2_three_step_trajectory_vs_oracle_on_device():
+    """BASELINE configs[1] at its FULL size — Segmentor U-Net nb_classes=3, 512x512, bs 32, three Adam steps — against
+    oracle.seg_oracle.train_step (trainer.py:189-211 restated) executed with stock torch ops on the device (VERDICT r03
+    weak #2: 'nothing compares a bs-32, 512^2, k-step loss trajectory with the oracle').  Measured (profiles/
+    r04_fullsize_parity_probe.log): 5.6e-9 / 7.6e-7 / 2.2e-6 relative to the fp64 oracle — the oracle's own fp32 run is at
+    1.1e-6 / 7.6e-7 / 1.6e-6; asserted: 1e-5 on step 1, the north-star 1e-4 on steps 2 and 3 (Adam's m / sqrt(v) turns
+    rounding-level gradient differences into +-lr parameter moves, so later steps drift)."""
+    import atomai_amd as aoi
+    from oracle import seg_oracle as so
+    rs = np.random.RandomState(0)
+    X = rs.rand(32, 512, 512).astype(np.float32)
+    y = rs.randint(0, 3, (32, 512, 512))
+    m = aoi.models.Segmentor(nb_classes=3, seed=1)
+    m.compile_trainer((X, y, X, y), training_cycles=3, batch_size=32)
+    sd = OrderedDict((k, v.detach().clone().cuda()) for k, v in m.net.state_dict().items())
+    xb, yb = m.X_train[0].detach().clone().cuda(), m.y_train[0].detach().clone().cuda()
+    opt = so.AdamState(lr=1e-3)
+    got, ref = [], []
+    for step in range(3):
+        got.append(m.train_step(m.X_train[0], m.y_train[0])[0])
+        ref.append(so.train_step("Unet", sd, opt, xb, yb, 3))
+        if step == 0:
+            # BatchNorm running statistics after the first step: the same batch statistics on both sides (measured
+            # 4.5e-7).  Not compared later: Adam's first update is -lr * sign(g), so parameters whose gradient is at
+            # rounding level move in opposite directions in two correct fp32 runs (2e-3 apart after one step, measured),
+            # and the running statistics follow them (6e-4 / 2.4e-3 after steps 2 / 3) while the loss stays within 2e-6.
+            for k, v in m.net.state_dict().items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    assert float((v.double() - sd[k].double()).abs().max()) < 1e-5 * max(1.0, float(sd[k].abs().max())), k
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, ref)]
+    assert rel[0] < 1e-5 and max(rel) < C.REL_TOL, (got, ref)
+    assert got[2] < got[1] < got[0]
 
 
 def test_determinism_and_loss_decrease_at_full_size():
@@ -279,6 +335,18 @@ def test_wave_specialised_wgrad_is_bit_identical(cin, cout, H, N, monkeypatch):
     C.check_wgrad_ws_bit_identical("cuda", cin, cout, H, N, monkeypatch)
     if (cin, cout) == (16, 32):
         C.check_wgrad_ws_bit_identical("cuda", cin, cout, H, N, monkeypatch, force_th=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 16), (16, 16)])
+def test_bn_backward_formed_in_the_loaders(cin, cout, monkeypatch):
+    """amx_conv2d_dgrad_fused / amx_conv2d_wgrad_fused against amx_bn_bwd_apply + the plain kernels (bit-identical)."""
+    C.check_bwd_fused_in_loaders("cuda", cin, cout, monkeypatch, hw=128, batch=12)
+
+
+@pytest.mark.gpu
+def test_bn_backward_formed_in_the_loaders_unet(monkeypatch):
+    assert C.check_bwd_fused_in_loaders("cuda", 0, 0, monkeypatch, hw=256, batch=16, unet=True) == 4
 
 
 @pytest.mark.gpu

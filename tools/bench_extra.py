@@ -149,7 +149,20 @@ def bench_predict_full(frames=4096, hw=1024, emit=True):
     out = p.run(stack, compute_coords=False)
     dt = time.perf_counter() - t0
     chk = float(out[::257].mean())
-    del out
+    # Parity of the timed call's OUTPUT (outside the timed region): 8 frames spread over the stack — first, last, and both
+    # sides of chunk borders (16-frame chunks, 3 in flight, collected by a worker thread) — against the oracle's eval
+    # graph (oracle.seg_oracle.predict_probs: stock torch ops, fp64, on the device) on the same globally normalised input
+    # (utils/preproc.py:torch_format_image: (x - min) / ptp over the WHOLE stack, numpy float32 arithmetic).
+    from oracle import seg_oracle as so
+    idx = sorted({i for i in (0, 15, 16, frames // 2 - 1, frames // 2, frames - 17, frames - 16, frames - 1) if 0 <= i < frames})
+    mn, mx = (float(v) for v in torch.aminmax(st))
+    sub = (stack[idx] - np.float32(mn)) / np.float32(mx - mn)
+    sd64 = so.cast({k: v.detach().cpu() for k, v in net.state_dict().items()}, torch.float64)
+    sd64 = {k: v.cuda() for k, v in sd64.items()}
+    ref = so.predict_probs("dilnet", sd64, torch.from_numpy(sub[:, None]).double().cuda(), 1).cpu().numpy()
+    got = out[idx].astype(np.float64)
+    parity = float(np.abs(got - ref).max() / np.abs(ref).max())
+    del out, sd64
     x = torch.from_numpy(stack[:16, None]).cuda()            # device-only rate of the network itself (16-frame chunk)
     from atomai_amd.nets.fcnn import predict_proba
     net.eval()
@@ -163,6 +176,9 @@ def bench_predict_full(frames=4096, hw=1024, emit=True):
            "steady_frames_per_s": round((frames - 256) / (dt - t256), 2) if frames > 256 else None,
            "first_256_frames_s": round(t256, 3), "stack_GB": round(stack.nbytes / 1e9, 2),
            "host_fill_s": round(t_gen, 2), "out_shape": [frames, hw, hw, 1], "out_mean_sample": round(chk, 6),
+           "parity_max_rel": float(f"{parity:.3g}"), "parity_frames": idx,
+           "parity_note": "max |out - oracle| / max |oracle| over the listed frames of the timed call's output; oracle = "
+                          "seg_oracle.predict_probs in fp64 on the device, outside the timed region",
            "device_only_ms_per_frame": round(dk * 1e3, 3), "device_tflops": round(91.62e9 / dk / 1e12, 2),
            "device_frac_of_mfma_peak": round(91.62e9 / dk / 1e12 / PEAK, 4)}
     if emit:
