@@ -509,6 +509,7 @@ def check_wgrad_ws_bit_identical(device, cin, cout, H, N, monkeypatch, W=None, t
         monkeypatch.setenv("AMX_WGRAD_TH", str(force_th))
     else:
         monkeypatch.delenv("AMX_WGRAD_TH", raising=False)
+    monkeypatch.setenv("AMX_WGRAD_WS_MASK", "7")           # every class (the product default leaves the 64-channel one out)
     for ws in ("0", "1"):
         monkeypatch.setenv("AMX_WGRAD_WS", ws)
         rows = lib.amx_conv2d_wgrad_rows(N, H, W, cin, cout, 9, 1)       # (the plan may pick taller tiles for wgrad_ws.hip)
