@@ -7,7 +7,7 @@ static void* amx_conv_profile_buffer = nullptr;
 extern "C" int amx_conv_set_profile_buffer(void* buf) { amx_conv_profile_buffer = buf; return 0; }
 #endif
 
-struct ConvPlan { int nt, th; };
+struct ConvPlan { int nt, th, rem; };
 
 // Tile plan, from the per-shape measurements in profiles/r01_conv_variants.md: this kernel is fastest with MANY
 // small co-resident workgroups (they hide each other's prologue / staging / epilogue), so the default tile is
@@ -23,8 +23,9 @@ bool amx_lattice_mode(int taps, int dil) {
     return !e || atoi(e) != 0;
 }
 
-static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
+static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H, bool allow_rem = true) {
     ConvPlan pl;
+    pl.rem = 0;
     const int cop = amx_round_up(cout, 16);
     const int nchunk = amx_ceil_div(Cin_s, 4 * KG);
     const bool small = taps == 9 && (dil == 1 || amx_lattice_mode(taps, dil));   // 8-row tiles exist for the plain geometry
@@ -35,6 +36,16 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
     if (const char* e = getenv("AMX_CONV_TH")) { const int v = atoi(e); if (v == 16 || (v == 8 && small)) pl.th = v; }
     // experiment: 8-row tiles for the 64-cout dilated variant (AMX_CONV_DIL_TH=8)
     if (taps == 9 && dil > 1 && pl.nt == 4) { if (const char* e = getenv("AMX_CONV_DIL_TH")) { if (atoi(e) == 8) pl.th = 8; } }
+    // Round 4: widths of 25 / 50 filters (dilnet; 28 / 52 stored channels) run as 16 + 3 x 4 / 3 x 16 + 4 columns in ONE cout
+    // block — the 4-wide remainder blocks on v_mfma_f32_4x4x1 (conv_kernel.h, REM) — instead of 32 / 2 x 32 padded
+    // columns.  AMX_CONV_REM=0 switches it off (A/B); the fused classification head keeps the power-of-two plan.
+    if (allow_rem && small && pl.th == 8 && pl.nt == 2) {
+        const int c4 = amx_round_up(cout, 4);
+        bool on = true;
+        if (const char* e = getenv("AMX_CONV_REM")) on = atoi(e) != 0;
+        if (on && c4 == 52) { pl.nt = 3; pl.rem = 1; }
+        if (on && c4 == 28) { pl.nt = 1; pl.rem = 3; }
+    }
     return pl;
 }
 
@@ -42,7 +53,10 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H) {
 // block: 16 couts x 16-row tiles (U-Net's last layer) or <= 32 couts x 8-row tiles (dilnet's).
 static bool head_supported(int Cin_s, int cout, int taps, int dil, int H) {
     if (taps != 9 || dil != 1) return false;
-    const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H);
+    // (the fused head keeps the power-of-two column plan: the 28-column class with the head — 16 + 3 x 4 columns, three
+    //  waves per SIMD — measured SLOWER than 32 padded columns at four, 1.152 vs 1.134 ms per dilnet frame,
+    //  profiles/r04_logs/r04_dilnet_rem_head_ab.log)
+    const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H, false);
     const int cop = amx_round_up(cout, 16);
     return (pl.nt == 1 && pl.th == 16 && cop == 16) || (pl.nt == 2 && pl.th == 8 && cop == 32);
 }
@@ -55,7 +69,7 @@ extern "C" int amx_conv2d_head_supported(int Cin_s, int cout, int taps, int dil,
 static bool dsum_supported(int Cin_s, int cout, int taps, int dil, int H) {
     if (!amx_lattice_mode(taps, dil)) return false;
     const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H);
-    return pl.nt == 2 && pl.th == 8;
+    return (pl.nt == 2 && pl.th == 8) || (pl.rem && pl.th == 8);
 }
 extern "C" int amx_conv2d_dsum_supported(int Cin_s, int cout, int taps, int dil, int H) {
     return dsum_supported(Cin_s, cout, taps, dil, H) ? 1 : 0;
@@ -125,7 +139,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     a.dil = dil; a.slope = slope;
     if (Y0s + Y1s < cout) AMX_BADARG(8);
     hipStream_t s = (hipStream_t)stream;
-    const ConvPlan pl = plan_conv(C0s + C1s, cout, taps, dil, H);
+    const ConvPlan pl = plan_conv(C0s + C1s, cout, taps, dil, H, hout == nullptr);
     a.th = pl.th;
     a.tiles_x = amx_ceil_div(W, TILE); a.tiles_y = amx_ceil_div(H, pl.th);
     const bool tail = a.tail_kg < KG;                       // partial last chunk: cheaper tail path
@@ -139,10 +153,12 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
             if (!dsum_supported(C0s + C1s, cout, taps, dil, H) || nds > 3 || stats || addend || y1 || hout) AMX_BADARG(13);
             for (int l = 0; l < nds; ++l) if (!a.ds_a[l]) AMX_BADARG(13);
             for (int l = 0; l <= nds; ++l) if (!a.ds_sc[l] || !a.ds_sh[l]) AMX_BADARG(13);
+            if (pl.rem) return amx_conv_launch_lat_rem(a, dil, pl.nt, pl.rem, tail, true, s);
             if (dil == 2) return amx_conv_launch_lat2_dsum(a, tail, s);
             if (dil == 4) return amx_conv_launch_lat4_dsum(a, tail, s);
             return amx_conv_launch_lat6_dsum(a, tail, s);
         }
+        if (pl.rem) return amx_conv_launch_lat_rem(a, dil, pl.nt, pl.rem, tail, false, s);
         if (dil == 2) return amx_conv_launch_lat2(a, pl.nt, pl.th, tail, s);
         if (dil == 4) return amx_conv_launch_lat4(a, pl.nt, pl.th, tail, s);
         return amx_conv_launch_lat6(a, pl.nt, pl.th, tail, s);
@@ -154,6 +170,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
         return amx_conv_launch_3x3_head(a, pl.nt, tail, s);
     }
     if (taps == 1) return amx_conv_launch_1x1(a, pl.nt, tail, s);
+    if (dil == 1 && pl.rem) return amx_conv_launch_3x3_rem(a, pl.nt, pl.rem, tail, s);
     if (dil == 1) return amx_conv_launch_3x3(a, pl.nt, pl.th, tail, s);
     return amx_conv_launch_dil(a, pl.nt, tail, s);
 }

@@ -156,23 +156,47 @@ struct ConvFwdArgs {
 // Waves per SIMD the plain-3x3 instantiations are built for.  Co-resident waves are what keeps the matrix pipe fed
 // (utilisation ~ N * t_mfma / (t_mfma + t_other) per SIMD, profiles/r02_conv_phases.md), and these variants sit a
 // handful of registers above the next allocation step: the bound makes the allocator take the step.
-template <int TAPS, int NT, int MAXHALO, int MTW, bool TAIL>
+#ifndef AMX_CONV_REM_GLDS
+#define AMX_CONV_REM_GLDS 1
+#endif
+#ifndef AMX_CONV_REM_WAVES
+#define AMX_CONV_REM_WAVES 3        // waves per SIMD the remainder-column classes are built for (experiment switch)
+#endif
+template <int TAPS, int NT, int MAXHALO, int MTW, bool TAIL, int REM = 0>
 struct ConvWaves {
-    static constexpr int value = (TAPS == 9 && MAXHALO == 1)
+    static constexpr int value = REM ? AMX_CONV_REM_WAVES
+                                     : (TAPS == 9 && MAXHALO == 1)
                                      ? ((MTW == 2 && NT <= 2) ? (AMX_CONV_GLDS ? AMX_CONV_GLDS_WAVES : 4) : ((MTW == 4 && NT == 1) ? 3 : 1))
                                      : 1;
 };
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0>
-__global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
+// REM (round 4): 1..3 extra 4-wide column blocks on v_mfma_f32_4x4x1_16b_f32 behind the NT 16-wide tiles, so that a
+// workgroup covers EXACTLY the stored channels of a layer whose width is not a multiple of 16 — dilnet's 25 / 50 filters
+// (28 / 52 stored): 16 + 3 x 4 and 3 x 16 + 4 columns in ONE cout block instead of 32 and 2 x 32 (27.7 % of the MFMA work
+// of a dilnet forward was column padding, profiles/r03_pmc_dilnet.md, and the second cout block staged the input tile a
+// second time).  The 4x4x1 form (16 independent 4x4 blocks, K = 1; lane map measured in tools/micro/mfma4x4_probe.hip:
+// block = lane / 4, A row = B column = lane % 4, D register = row) runs at the rate of the 16x16x4 form — 8 cycles for a
+// quarter of the MACs — and takes the SAME A fragment registers: lane (g, p) holds channels 4g..4g+3 of pixel p, so block
+// 4g + p/4 multiplies pixels 4(p/4)..+3 at channel 4g + c with the weights of couts n0R + p%4; the four channel sets g
+// of a pixel are separate blocks and are added once, by two xor-shuffles, in the epilogue.
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0, int REM = 0>
+__global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
     static_assert(LAT == 0 || (TAPS == 9 && MAXHALO == 1 && EXACT), "lattice mode runs the plain 3x3 geometry");
     // EPI: 0 = store the activation; 1 = classification head fused in (eval); 2 = sum of a DilatedBlock fused in (eval)
     constexpr bool HEAD = EPI == 1, DSUM = EPI == 2;
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
-    constexpr int NB = NT * 16;
+    constexpr int NB = NT * 16 + REM * 4;                        // columns (couts) of this workgroup
+    constexpr int RQ = REM ? REM : 1;
     constexpr int MAXI = TILE + 2 * MAXHALO;
     constexpr int XLD = ((TH + 2 * MAXHALO) * MAXI * KG + 255) / 256;          // float4 loads per thread (input)
     constexpr int WLD = (TAPS * KG * NB + 255) / 256;            // float4 loads per thread (weights)
+    // weights by LDS-DMA instead of through registers: everywhere under AMX_CONV_GLDS (experiment), and on the
+    // remainder-column classes, whose 52-column weight image would hold 32 registers per thread across the MFMA phase
+#ifdef AMX_EMU
+    constexpr bool GLDS = false;
+#else
+    constexpr bool GLDS = AMX_CONV_GLDS || (REM && AMX_CONV_REM_GLDS);
+#endif
     AMX_DYN_SMEM(float, smem);
 
     const int tid = threadIdx.x;
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     AMX_TICK(15);
 
     float4 xr[XLD];
-    float4 wr[WLD];
+    float4 wr[GLDS ? 1 : WLD];
     float4 r_sc, r_sh;
     float r_islope = 1.f;                                        // post-affine LeakyReLU slope of this thread's source
 
@@ -254,20 +278,20 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 if (src && x_off[i] >= 0) xr[i] = amx_ld4(src + (size_t)x_off[i] * Cs + c);
             }
         }
-#if !AMX_CONV_GLDS
-        const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
-        #pragma unroll
-        for (int i = 0; i < WLD; ++i) {
-            const int idx = tid + i * 256;                       // over [TAPS*KG][NB]
-            wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < TAPS * KG * NB) {
-                const int row = idx / NB, col = idx - row * NB;
-                if (n0 + col < a.cop) wr[i] = amx_ld4(wsrc + ((size_t)row * a.cop + n0 + col) * 4);
+        if constexpr (!GLDS) {
+            const float* wsrc = a.wpk + (size_t)chunk * TAPS * KG * a.cop * 4;
+            #pragma unroll
+            for (int i = 0; i < WLD; ++i) {
+                const int idx = tid + i * 256;                   // over [TAPS*KG][NB]
+                wr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < TAPS * KG * NB) {
+                    const int row = idx / NB, col = idx - row * NB;
+                    if (n0 + col < a.cop) wr[i] = amx_ld4(wsrc + ((size_t)row * a.cop + n0 + col) * 4);
+                }
             }
         }
-#endif
     };
-#if AMX_CONV_GLDS
+#ifndef AMX_EMU
     // weight image of a chunk by LDS-DMA: one wave instruction moves 1 KiB = 64 / NB rows of the [TAPS*KG][NB][4] image
     // (LDS destination = wave-uniform base + lane * 16 B, the global source is per lane)
     auto dma_weights = [&](int chunk) {
@@ -318,20 +342,24 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 }
             }
         }
-#if !AMX_CONV_GLDS
-        #pragma unroll
-        for (int i = 0; i < WLD; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < TAPS * KG * NB) amx_st4(s_w + (size_t)idx * 4, wr[i]);
+        if constexpr (!GLDS) {
+            #pragma unroll
+            for (int i = 0; i < WLD; ++i) {
+                const int idx = tid + i * 256;
+                if (idx < TAPS * KG * NB) amx_st4(s_w + (size_t)idx * 4, wr[i]);
+            }
         }
-#endif
     };
 
     f32x4 acc[MTW][NT];
+    f32x4 accr[MTW][RQ];                                         // remainder blocks (REM): partial over this lane's channel set g
     #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int m = 0; m < MTW; ++m) {
         #pragma unroll
         for (int q = 0; q < NT; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        #pragma unroll
+        for (int q = 0; q < RQ; ++q) accr[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     auto compute_taps = [&](int stage, int tap0, int tap1) {
         const float* s_in = smem + (size_t)stage * stage_floats;
@@ -350,12 +378,23 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             #pragma unroll
             for (int q = 0; q < NT; ++q)
                 bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+            float4 br[RQ];
+            if (REM) {
+                #pragma unroll
+                for (int q = 0; q < REM; ++q)
+                    br[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + NT * 16 + q * 4 + (p & 3)) * 4);
+            }
             // k-subgroup outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32 MFMA has a
             // 40-cycle dependent latency vs a 32-cycle issue interval)
             #define AMX_CONV_MFMA(C)                                                                    \
-                _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
+                _Pragma("unroll") for (int m = 0; m < MTW; ++m) {                                       \
                     _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0); \
+                    if (REM) {                                                                          \
+                        _Pragma("unroll") for (int q = 0; q < REM; ++q)                                 \
+                            accr[m][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[m].C, br[q].C, accr[m][q], 0, 0, 0); \
+                    }                                                                                   \
+                }
             AMX_CONV_MFMA(x) AMX_CONV_MFMA(y) AMX_CONV_MFMA(z) AMX_CONV_MFMA(w)
             #undef AMX_CONV_MFMA
         }
@@ -382,10 +421,21 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
             #pragma unroll
             for (int q = 0; q < NT; ++q)
                 bf[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + q * 16 + p) * 4);
+            float4 br[RQ];
+            if (REM) {
+                #pragma unroll
+                for (int q = 0; q < REM; ++q)
+                    br[q] = amx_ld4(s_w + ((size_t)(tap * KG + g) * NB + NT * 16 + q * 4 + (p & 3)) * 4);
+            }
             #define AMX_CONV_MFMA(C)                                                                    \
-                _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                         \
+                _Pragma("unroll") for (int m = 0; m < MTW; ++m) {                                       \
                     _Pragma("unroll") for (int q = 0; q < NT; ++q)                                      \
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].C, bf[q].C, acc[m][q], 0, 0, 0); \
+                    if (REM) {                                                                          \
+                        _Pragma("unroll") for (int q = 0; q < REM; ++q)                                 \
+                            accr[m][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(af[m].C, br[q].C, accr[m][q], 0, 0, 0); \
+                    }                                                                                   \
+                }
             AMX_CONV_MFMA(x)
             if (nkg > 1) { AMX_CONV_MFMA(y) }
             if (nkg > 2) { AMX_CONV_MFMA(z) }
@@ -402,9 +452,15 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         const int co = n0 + q * 16 + p;
         bias_q[q] = (PREB && a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
+    float bias_r[RQ];
+    #pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+        const int co = n0 + NT * 16 + q * 4 + (p & 3);
+        bias_r[q] = (REM && a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
     issue_loads(0);
-#if AMX_CONV_GLDS
-    dma_weights(0);
+#ifndef AMX_EMU
+    if constexpr (GLDS) dma_weights(0);
 #endif
     AMX_TICK(1);
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
@@ -420,8 +476,8 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
         AMX_SETPRIO(AMX_CONV_PRIO_OUT);
         if (chunk < 2) AMX_TICK(5 + 5 * chunk);
         __syncthreads();
-#if AMX_CONV_GLDS
-        if (chunk + 1 < a.nchunk) dma_weights(chunk + 1);        // (after the barrier: every wave is done with chunk's image)
+#ifndef AMX_EMU
+        if constexpr (GLDS) { if (chunk + 1 < a.nchunk) dma_weights(chunk + 1); }     // (after the barrier: every wave is done with chunk's image)
 #endif
         if (chunk < 2) AMX_TICK(6 + 5 * chunk);
     }
@@ -452,6 +508,29 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 lsum[q] += v;
                 acc[m][q][r] = v;
             }
+    }
+    // remainder blocks: add the four channel sets (lanes g = 0..3 of a pixel group), then the same bias / activation; after
+    // the butterfly every g holds the full value of pixel x = 4 * (p >> 2) + reg, cout n0 + NT * 16 + 4 q + (p & 3)
+    float lsum_r[RQ];
+    if (REM) {
+        #pragma unroll
+        for (int q = 0; q < REM; ++q) {
+            const int co = n0 + NT * 16 + q * 4 + (p & 3);
+            lsum_r[q] = 0.f;
+            #pragma unroll
+            for (int m = 0; m < MTW; ++m)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accr[m][q][r];
+                    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                    v += bias_r[q];
+                    v = v > 0.f ? v : v * a.slope;
+                    const bool ok = (ry + (oy0 + m) * LS < a.H) && (rx + (tx * TILE + 4 * (p >> 2) + r) * LS < a.W) && co < ctot;
+                    v = ok ? v : 0.f;
+                    lsum_r[q] += v;
+                    accr[m][q][r] = v;
+                }
+        }
     }
     AMX_TICK(12);
     // sub-image extent of this workgroup's residue class (the image itself outside lattice mode)
@@ -485,6 +564,30 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 a.stats[(row * 2 + 1) * a.cop + co] = s2;
             }
         }
+        if (REM) {
+            // a lane holds 4 pixels x MTW rows of one remainder cout; the strip's 16 columns are the 4 lane groups p >> 2
+            #pragma unroll
+            for (int q = 0; q < REM; ++q) {
+                float sm = lsum_r[q];
+                sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+                const float mu = sm * inv_cnt;
+                float s2 = 0.f;
+                #pragma unroll
+                for (int m = 0; m < MTW; ++m)
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (oy0 + m < Hs) && (tx * TILE + 4 * (p >> 2) + r < Ws);
+                        const float d = accr[m][q][r] - mu;
+                        s2 += ok ? d * d : 0.f;
+                    }
+                s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+                const int co = n0 + NT * 16 + q * 4 + (p & 3);
+                if (lane < 4 && co < a.cop) {
+                    a.stats[(row * 2) * a.cop + co] = sm;
+                    a.stats[(row * 2 + 1) * a.cop + co] = s2;
+                }
+            }
+        }
     }
     // transpose: [row m][pixel x][cout] in this wave's LDS region, MH rows at a time
     constexpr int MH = MTW < 2 ? MTW : 2;
@@ -498,11 +601,14 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     float* s_epi = smem + (size_t)wave * (MH * TILE * NBE);
     // HEAD: this lane's slice (4 couts) of the folded head weights; lane % CG is the lane's float4 group of a pixel in
     // every iteration of the loops below (64 and MH * TILE * CG are multiples of CG)
+    // (HEAD with remainder columns: CG = 7 float4 groups per pixel are dealt to CGH = 8 lanes, the eighth contributes 0)
+    constexpr int CGH = CG <= 1 ? 1 : (CG <= 2 ? 2 : (CG <= 4 ? 4 : (CG <= 8 ? 8 : 16)));
+    constexpr int CGX = HEAD ? CGH : CG;                         // lanes per pixel in the store loop
     float4 hwq[HEAD ? 3 : 1];
     if (HEAD) {
         #pragma unroll
         for (int k = 0; k < 3; ++k)
-            hwq[k] = k < a.hK ? amx_ld4(a.hw + (size_t)k * a.cop + (lane % CG) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            hwq[k] = (k < a.hK && lane % CGH < CG) ? amx_ld4(a.hw + (size_t)k * a.cop + (lane % CGH) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     #pragma unroll
     for (int m0 = 0; m0 < MTW; m0 += MH) {
@@ -513,11 +619,21 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     s_epi[(mm * TILE + 4 * g + r) * NBE + q * 16 + p] = acc[m0 + mm][q][r];
+        if (REM && g == 0) {                                     // (every g holds the same values after the butterfly)
+            #pragma unroll
+            for (int mm = 0; mm < MH; ++mm)
+                #pragma unroll
+                for (int q = 0; q < REM; ++q)
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_epi[(mm * TILE + 4 * (p >> 2) + r) * NBE + NT * 16 + q * 4 + (p & 3)] = accr[m0 + mm][q][r];
+        }
         amx_wave_sync();                                         // wave-private region: no workgroup barrier needed
         #pragma unroll
-        for (int it = 0; it < MH * TILE * CG / 64; ++it) {
+        for (int it = 0; it < (MH * TILE * CGX + 63) / 64; ++it) {
             const int e = it * 64 + lane;
-            const int pix = e / CG, cgp = e - pix * CG;
+            if ((MH * TILE * CGX) % 64 && e >= MH * TILE * CGX) continue;    // (REM: CG = 7 / 13 float4 groups per pixel)
+            const int pix = e / CGX, cgp = e - pix * CGX;
             const int mm = pix / TILE, x = pix - mm * TILE;
             const int oy = ry + (oy0 + m0 + mm) * LS, ox = rx + (tx * TILE + x) * LS;
             const int co = n0 + cgp * 4;
@@ -525,13 +641,13 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
                 // the final 1x1 convolution (own BatchNorm affine folded in) on the transposed tile: each of the CG
                 // lanes of a pixel contracts its 4 couts, a butterfly over those lanes sums them; the activation is
                 // not written at all
-                const float4 v = amx_ld4(s_epi + (size_t)pix * NBE + cgp * 4);
+                const float4 v = cgp < CG ? amx_ld4(s_epi + (size_t)pix * NBE + cgp * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 float lg[3];
                 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     float d = v.x * hwq[k].x + v.y * hwq[k].y + v.z * hwq[k].z + v.w * hwq[k].w;
                     #pragma unroll
-                    for (int o = 1; o < CG; o <<= 1) d += __shfl_xor(d, o);
+                    for (int o = 1; o < CGH; o <<= 1) d += __shfl_xor(d, o);
                     lg[k] = d + (k < a.hK ? a.hb[k] : 0.f);
                 }
                 if (cgp == 0 && oy < a.H && ox < a.W) {
@@ -587,16 +703,17 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL>::valu
     AMX_TICK(13);
 }
 
-template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0>
+template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0, int REM = 0>
 static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
+    constexpr int NB = NT * 16 + REM * 4;
     const int halo = (TAPS == 9) ? (LAT ? 1 : a.dil) : 0;
     const int I = TILE + 2 * halo;
     const int plane = amx_round_up((4 * MTW + 2 * halo) * I, 16);
-    size_t lds_w = (size_t)TAPS * KG * NT * 16 * 4 * sizeof(float);
-    if (lds_w < (size_t)8 * NT * 16 * sizeof(float)) lds_w = (size_t)8 * NT * 16 * sizeof(float);
+    size_t lds_w = (size_t)TAPS * KG * NB * 4 * sizeof(float);
+    if (lds_w < (size_t)8 * NB * sizeof(float)) lds_w = (size_t)8 * NB * sizeof(float);
     size_t lds = ((size_t)KG * plane * 4 * sizeof(float) + lds_w) ;
     {   // the epilogue's transposition buffers: 4 waves x min(MTW, 2) rows x 16 pixels x NB couts
-        const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * (NT * 16 + AMX_CONV_EPI_PAD) * sizeof(float);
+        const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * (NB + AMX_CONV_EPI_PAD) * sizeof(float);
         if (lds < epi) lds = epi;
     }
     // occupancy experiment: AMX_CONV_MAXWG=k pads the LDS request so that at most k workgroups fit a CU
@@ -604,17 +721,18 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
         const int k = atoi(e);
         if (k >= 1 && k <= 8) { const size_t want = (size_t)(160 * 1024 / k) / 256 * 256; if (want > lds) lds = want; }
     }
-    dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? LAT * LAT : 1), amx_ceil_div(a.cop, NT * 16));
+    // (REM: one cout block covers every stored channel)
+    dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? LAT * LAT : 1), REM ? 1 : amx_ceil_div(a.cop, NT * 16));
 #ifndef AMX_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT>), grid, dim3(256), lds, stream, a);
+    AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -630,6 +748,12 @@ int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_lat2(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);   // lattice mode, dilation 2 / 4 / 6
 int amx_conv_launch_lat4(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
 int amx_conv_launch_lat6(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
+// remainder-column classes (REM: 16 + 3 x 4 and 3 x 16 + 4 columns, 8-row tiles): conv_fwd_rem.hip, conv_fwd_lat{2,4,6}_rem.hip
+int amx_conv_launch_3x3_rem(ConvFwdArgs& a, int nt, int rem, bool tail, hipStream_t s);
+int amx_conv_launch_lat_rem(ConvFwdArgs& a, int dil, int nt, int rem, bool tail, bool dsum, hipStream_t s);
+int amx_conv_launch_lat2_rem(ConvFwdArgs& a, int nt, int rem, bool tail, bool dsum, hipStream_t s);
+int amx_conv_launch_lat4_rem(ConvFwdArgs& a, int nt, int rem, bool tail, bool dsum, hipStream_t s);
+int amx_conv_launch_lat6_rem(ConvFwdArgs& a, int nt, int rem, bool tail, bool dsum, hipStream_t s);
 int amx_conv_launch_lat2_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);           // + fused DilatedBlock sum (eval)
 int amx_conv_launch_lat4_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);
 int amx_conv_launch_lat6_dsum(ConvFwdArgs& a, bool tail, hipStream_t s);

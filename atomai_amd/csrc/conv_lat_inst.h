@@ -21,3 +21,21 @@
     }
 #define AMX_LAT_GO(N_, M_, D_) return tail ? launch_conv_fwd<9, N_, 1, true, M_, 0, true, D_>(a, s)      \
                                            : launch_conv_fwd<9, N_, 1, true, M_, 0, false, D_>(a, s)
+// remainder-column classes: (nt, rem) = (1, 3) | (3, 1); the fused DilatedBlock sum (eval) exists for the 52-column class
+#define AMX_LAT_UNIT_REM(D_)                                                                                 \
+    int amx_conv_launch_lat##D_##_rem(ConvFwdArgs& a, int nt, int rem, bool tail, bool dsum, hipStream_t s) { \
+        if (nt == 3 && rem == 1 && dsum)                                                                     \
+            return tail ? launch_conv_fwd<9, 3, 1, true, 2, 2, true, D_, 1>(a, s)                            \
+                        : launch_conv_fwd<9, 3, 1, true, 2, 2, false, D_, 1>(a, s);                          \
+        if (nt == 1 && rem == 3 && dsum)                                                                     \
+            return tail ? launch_conv_fwd<9, 1, 1, true, 2, 2, true, D_, 3>(a, s)                            \
+                        : launch_conv_fwd<9, 1, 1, true, 2, 2, false, D_, 3>(a, s);                          \
+        if (dsum) AMX_BADARG(16);                                                                            \
+        if (nt == 3 && rem == 1)                                                                             \
+            return tail ? launch_conv_fwd<9, 3, 1, true, 2, 0, true, D_, 1>(a, s)                            \
+                        : launch_conv_fwd<9, 3, 1, true, 2, 0, false, D_, 1>(a, s);                          \
+        if (nt == 1 && rem == 3)                                                                             \
+            return tail ? launch_conv_fwd<9, 1, 1, true, 2, 0, true, D_, 3>(a, s)                            \
+                        : launch_conv_fwd<9, 1, 1, true, 2, 0, false, D_, 3>(a, s);                          \
+        AMX_BADARG(16);                                                                                      \
+    }

@@ -82,6 +82,10 @@ int amx_conv2d_stats_rows(int Cin_s, int cout, int taps, int dil, int N, int H, 
 /* Diagnostic: launches of amx_conv2d_fwd / amx_conv2d_dgrad that the wave-specialised kernel of the thin plain-3x3
  * layers (conv_ws.hip) has taken since the library was loaded (AMX_CONV_WS=0 routes them to the general kernel). */
 long amx_conv2d_ws_launches(void);
+/* Diagnostic: launches taken by the remainder-column classes (conv_kernel.h, REM: widths of 25 / 50 filters in one cout
+ * block of 16 + 3 x 4 / 3 x 16 + 4 columns, the 4-wide blocks on v_mfma_f32_4x4x1; AMX_CONV_REM=0 restores the padded
+ * 32 / 2 x 32 column plan). */
+long amx_conv2d_rem_launches(void);
 
 /* weight gradient of the same convolution (autograd of nn.Conv2d; trainer.py:205 loss.backward()).
  * part: [amx_conv2d_wgrad_rows][taps][round_up(C0s+C1s,16)][round_up(cout,16)] partial rows. */

@@ -595,3 +595,39 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
         else:
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()))
     return nf
+
+
+def check_remainder_columns(device, cases=((50, 50, 1, 40, 2), (50, 50, 2, 44, 2), (25, 50, 4, 36, 1), (50, 25, 1, 32, 2),
+                                           (28, 50, 6, 37, 1))):
+    """conv_kernel.h REM classes (28 = 16 + 3 x 4 and 52 = 3 x 16 + 4 columns, the 4-wide blocks on v_mfma_f32_4x4x1)
+    against the padded power-of-two plan (AMX_CONV_REM=0) on one training-mode ConvBlock / DilatedBlock layer: forward,
+    BatchNorm statistics (through the running buffers), input and parameter gradients.  The 16-wide column tiles run the
+    same MFMA sequence in both plans; the remainder couts sum their channels in another order (fp32 rounding level)."""
+    import copy
+    from atomai_amd import _lib as L
+    from atomai_amd.nets import ConvBlock, DilatedBlock
+    for cin, cout, dil, hw, batch in cases:
+        res = {}
+        for rem in ("1", "0"):
+            os.environ["AMX_CONV_REM"] = rem
+            try:
+                torch.manual_seed(11)
+                m = (ConvBlock(2, 1, cin, cout, batch_norm=True) if dil == 1
+                     else DilatedBlock(2, cin, cout, [dil], [dil], batch_norm=True)).to(device)
+                x = torch.randn(batch, cin, hw, hw + 5, device=device).requires_grad_(True)
+                n0 = L.load().amx_conv2d_rem_launches()
+                y = m(x)
+                torch.manual_seed(12)
+                y.backward(torch.randn_like(y))
+                used = L.load().amx_conv2d_rem_launches() - n0
+            finally:
+                os.environ.pop("AMX_CONV_REM", None)
+            assert (used >= 1) == (rem == "1"), (cin, cout, dil, rem, used)
+            res[rem] = [y.detach().cpu(), x.grad.detach().cpu()] + [p.grad.detach().cpu() for p in m.parameters()] + \
+                       [b.detach().cpu().float() for b in m.buffers()]
+        for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+            tol = 2e-5 * max(1.0, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= tol, (cin, cout, dil, i, float((a - b).abs().max()), tol)
+        if dil == 1:                                   # ConvBlock output = the layer itself: the first 16-wide tiles agree exactly
+            nmain = (-(-cout // 4) * 4 // 16) * 16
+            assert torch.equal(res["1"][0][:, :nmain], res["0"][0][:, :nmain]) or cout < 16

@@ -210,6 +210,19 @@ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks, K = 1.  Lane map measured on the MI355X
+// (tools/micro/mfma4x4_probe.hip): D[lane l][reg r] = A[lane 4*(l/4) + r] * B[lane l] + C[l][r]
+// (block = l/4, row = reg, column = l%4; A's row index is its lane%4, B's column index its lane%4).
+inline f32x4 mfma_4x4x1(float a, float b, f32x4 c) {
+    Block& B = blk(); Fiber* me = B.cur; Wave& W = B.waves[me->wave];
+    int s = me->my_seq++ & 1;
+    W.a[s][me->lane] = a; W.b[s][me->lane] = b;
+    wave_sync();
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) d[r] = fmaf(W.a[s][4 * (me->lane >> 2) + r], W.b[s][me->lane], c[r]);
+    return d;
+}
+
 inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     Block& B = blk(); Fiber* me = B.cur; Wave& W = B.waves[me->wave];
     int s = me->my_seq++ & 1;
@@ -246,6 +259,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 static inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_16x16x4(a, b, c); }
+static inline f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, f32x4 c, int, int, int) { return emu::mfma_4x4x1(a, b, c); }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) { return emu::mfma_32x32x2(a, b, c); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

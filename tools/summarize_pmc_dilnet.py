@@ -21,7 +21,7 @@ for name, c, ns, grid in disp:
     lines.append(f"| `{re.sub(r'[(].*', '', name).replace('void ', '')[:58]}` | {ns/1e6:.3f} | {m/1e9:.1f} | {m/ns/1e3:.1f} | {busy:.3f} |")
 lines += ["", f"Forward: {tot_ns/1e6:.2f} ms of kernels; issued MFMA work {tot_mops*512/1e12:.3f} TFLOP vs {ALG/1e12:.3f} TFLOP algorithmic "
           f"(91.62 GFLOP per frame) = {tot_mops*512/ALG:.3f}x: {100*(1-ALG/(tot_mops*512)):.1f} % of the issued matrix work is channel padding "
-          f"(25 / 50 filters occupy 32 / 64 MFMA columns; the K direction is exact).  Issued rate {tot_mops*512/tot_ns/1e3:.1f} TFLOP/s, "
+          f"(r03: 25 / 50 filters in 32 / 64 MFMA columns; r04: 28 / 52 columns on the dilated layers, the head-fused last layer still 32; the K direction is exact).  Issued rate {tot_mops*512/tot_ns/1e3:.1f} TFLOP/s, "
           f"algorithmic {ALG/tot_ns/1e3:.1f} TFLOP/s over the whole forward."]
 open(f"profiles/{RND}_pmc_dilnet.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
