@@ -57,7 +57,8 @@ __device__ __forceinline__ T km_eval(T r2, T s2, int kind, T* w) {
 }
 
 // ------------------------------------------------------------------ K = k(X1, X2) [+ noise * I]
-template <typename T>
+// DR: register-resident embedding dimensions of a thread's columns (4, 8 or 16 >= D)
+template <typename T, int DR>
 __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict__ X1, const T* __restrict__ X2,
                                                             const T* __restrict__ inv_ls, T s2, int kind,
                                                             T noise, int N, int M, int D, T* __restrict__ K,
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
     }
     __syncthreads();
     const int cg = tid & 63, rg = tid >> 6;              // 64 column groups x 4 row groups
-    // a thread's V columns are the same for every row it writes: for the usual small embedding (D <= 4; dklGPR's
-    // default is 2) their scaled coordinates live in registers and the row loop only reads the row's coordinates
-    // (one broadcast LDS read per dimension) — the [d][col] reads were 8-way bank-conflicted (stride-V lanes)
-    constexpr int DR = 4;
+    // a thread's V columns are the same for every row it writes: their scaled coordinates live in registers (DR >= D
+    // of them: 4 for dklGPR's default embedding of 2, 8 / 16 for wider ones — round 4: D = 8 ran 3x slower than D = 2
+    // through the LDS fallback, 1.7 TB/s) and the row loop only reads the row's coordinates (one broadcast LDS read per
+    // dimension) — the [d][col] reads were 8-way bank-conflicted (stride-V lanes)
     T x2r[V][DR];
     #pragma unroll
     for (int v = 0; v < V; ++v)
@@ -98,18 +99,11 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
         for (int v = 0; v < V; ++v) {
             const int c = cg * V + v;
             T r2 = T(0);
-            if (D <= DR) {
-                #pragma unroll
-                for (int d = 0; d < DR; ++d) {
-                    if (d >= D) break;
-                    const T df = s_x1[r * D + d] - x2r[v][d];
-                    r2 += df * df;
-                }
-            } else {
-                for (int d = 0; d < D; ++d) {
-                    const T df = s_x1[r * D + d] - s_x2[d * COLS + c];
-                    r2 += df * df;
-                }
+            #pragma unroll
+            for (int d = 0; d < DR; ++d) {
+                if (d >= D) break;
+                const T df = s_x1[r * D + d] - x2r[v][d];
+                r2 += df * df;
             }
             T w;
             T k;
@@ -138,8 +132,17 @@ static int launch_km(const void* X1, const void* X2, const void* inv_ls, double 
                      int N, int M, int D, void* K, hipStream_t st) {
     constexpr int COLS = 64 * Vec16<T>::N;
     dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KmRows<T>::value));
-    AMX_LAUNCH(kernel_matrix_kernel<T>, grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
-               (T)s2, kind, (T)noise, N, M, D, (T*)K, getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 3);   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp
+    const int nt = getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 3;   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp
+    if (D <= 4) {
+        AMX_LAUNCH((kernel_matrix_kernel<T, 4>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
+                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
+    } else if (D <= 8) {
+        AMX_LAUNCH((kernel_matrix_kernel<T, 8>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
+                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
+    } else {
+        AMX_LAUNCH((kernel_matrix_kernel<T, 16>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
+                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
+    }
     AMX_CHECK_LAUNCH();
     return 0;
 }

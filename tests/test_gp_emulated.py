@@ -26,6 +26,8 @@ def emulator():
 def test_kernel_matrix_and_matvec(dtype, kind):
     G.check_kernel_matrix("cpu", dtype, kind, N=70, M=45, D=3)
     G.check_kernel_matrix("cpu", dtype, kind, N=33, M=260, D=2)
+    G.check_kernel_matrix("cpu", dtype, kind, N=40, M=130, D=7)          # register-resident column coordinates: 8 ...
+    G.check_kernel_matrix("cpu", dtype, kind, N=21, M=70, D=13)          # ... and 16 dimensions
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern"])

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_kernel_matrix_and_matvec(dtype, kind):
     G.check_kernel_matrix("cuda", dtype, kind, N=700, M=450, D=3)
     G.check_kernel_matrix("cuda", dtype, kind, N=333, M=1260, D=8)
+    G.check_kernel_matrix("cuda", dtype, kind, N=257, M=515, D=13)
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern"])
