@@ -28,8 +28,14 @@
 
 // AMX_WGRAD_PROFILE (dev builds, tools/gpu_wgrad_ws_phases.py): [workgroup][12 wave slots][8] shader-clock totals — consumers:
 // 0 sweep, 1 barrier wait; producers: 2 stage, 3 issue, 4 barrier wait; 6 tiles, 7 lifetime.
+// AMX_WGRAD_WS_WG2: 1 = the 64-channel class (WM 4) is built for TWO workgroups' worth of registers per CU (<= 128 per wave
+// with 8 waves), so that two 128-register convolution waves of the main stream still fit every SIMD next to it
+// (experiment switch, tools/build_variant_lib.sh).
+#ifndef AMX_WGRAD_WS_WG2
+#define AMX_WGRAD_WS_WG2 0
+#endif
 template <int NT, int WM, int WN, int TH, int LAT, int NP>
-__global__ __launch_bounds__(256 + NP) void wgrad_ws_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256 + NP, (AMX_WGRAD_WS_WG2 && WM == 4 && NP == 256) ? 4 : 1) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int TAPS = 9;
     constexpr int LS = LAT ? LAT : 1;
     constexpr int CIB = 16 * WM;

@@ -409,6 +409,12 @@ class ConvNode(_Node):
         # Round 4: layers whose data gradient runs on the wave-specialised kernel form dpre inside BOTH consumers' loaders
         # (amx_conv2d_dgrad_fused / amx_conv2d_wgrad_fused) — no amx_bn_bwd_apply pass, dpre never exists in HBM.
         fused_ws = (not fused and self._bwd_fusable(out)) if self.bn is not None else False
+        # the net's FIRST layer has no data gradient: its BatchNorm backward is only read by the first-layer weight-gradient
+        # kernel, which forms it while loading (amx_conv1_wgrad_fused) — the 512^2 x 16-channel apply pass of U-Net's c1
+        # (0.32 ms at the very end of the backward pass, nothing left to overlap it) is not launched at all
+        if (not fused and self.bn is not None and self.x_plain is not None and self.mask is None and out.gx is None
+                and self.post_slope == 1.0 and _os.environ.get("AMX_BWD_FUSE", "1") != "0"):
+            fused_ws = True
         fused = fused or fused_ws
         k = None
         aux = None

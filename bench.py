@@ -98,6 +98,9 @@ class KernelTimer:
             elif name == "amx_conv2d_dgrad":  # (dpre,Cs@1,wpk,addend,y,Y0s@5,y1,Y1s@7,N@8,H@9,W@10,taps@11,dil,stream)
                 fl = 2.0 * args[1] * (args[5] + args[7]) * args[11] * args[8] * args[9] * args[10]
                 name = "amx_conv2d_fwd"       # same kernel (conv_fwd_kernel): one family
+            elif name == "amx_conv2d_dgrad_fused":   # (dy,aux,k1,k2,k3,bslope,Cs@6,wpk,y,Y0s@9,y1,Y1s@11,N@12,H@13,W@14,taps@15,dil,stream)
+                fl = 2.0 * args[6] * (args[9] + args[11]) * args[15] * args[12] * args[13] * args[14]
+                name = "amx_conv2d_fwd"       # conv_ws_kernel<.., BWD>: the data gradient with the BatchNorm backward in its loader
             elif name == "amx_conv2d_wgrad":  # (.., C0s@3, .., C1s@7, dpre@8, Dos@9, part@10, N@11,H,W,cout@14,taps@15)
                 fl = 2.0 * (args[3] + args[7]) * args[14] * args[15] * args[11] * args[12] * args[13]
             elif name == "amx_conv2d_wgrad_fused":  # (.., C0s@3, .., C1s@7, dy@8, .., Dos@14, part, bpart, N@17,H,W,cout@20,taps@21)
@@ -327,7 +330,7 @@ def main(argv=None, backend=None):
     if world > 1 or force_dp:
         model.dp.timing = True                               # HIP events around the gradient all-reduce of every step
     timer = None if (args.no_kernel_timing or not be.product) else KernelTimer(
-        ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
+        ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_dgrad_fused", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
     from atomai_amd.engine import Tape
     if args.serial:
         Tape.use_side_stream = False
@@ -479,8 +482,8 @@ def main(argv=None, backend=None):
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
                                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic,
                                "traffic_source": tsrc,
-                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> + conv_ws_kernel<NCH,NT> (amx_conv2d_fwd / "
-                                         "amx_conv2d_dgrad: all forward + dgrad launches of the step)",
+                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> + conv_ws_kernel<NCH,NT,BWD> (amx_conv2d_fwd / "
+                                         "amx_conv2d_dgrad / amx_conv2d_dgrad_fused: all forward + dgrad launches of the step)",
                                "launches_per_step": conv["calls"] // ksteps,
                                "ms_per_step": round(conv["total_ms"] / ksteps, 3),
                                "avg_launch_ms": round(conv["total_ms"] / conv["calls"], 4),
@@ -494,7 +497,8 @@ def main(argv=None, backend=None):
             ach = wg["flops"] / (wg["total_ms"] * 1e-3) / 1e12
             out["roofline_wgrad"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
                                      "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4),
-                                     "kernel": "wgrad_kernel<TAPS,NT,WM,HALO> (amx_conv2d_wgrad)",
+                                     "kernel": "wgrad_ws_kernel<NT,WM,WN,TH> (wave-specialised, <= 32 input channels) + wgrad_kernel<TAPS,NT,WM,HALO> "
+                                               "(amx_conv2d_wgrad_fused: all weight-gradient launches of the step)",
                                      "ms_per_step": round(wg["total_ms"] / ksteps, 3)}
     if world == 1 and be.product:
         del model

@@ -587,7 +587,8 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
         out[mode], calls[mode] = grads, cnt
     nf = calls["1"].get("amx_conv2d_dgrad_fused", 0)
     assert nf >= 1 and calls["0"].get("amx_conv2d_dgrad_fused", 0) == 0, calls
-    assert calls["0"]["amx_bn_bwd_apply"] - calls["1"].get("amx_bn_bwd_apply", 0) == nf, calls
+    # (+ the net's first layer, whose BatchNorm backward is formed by amx_conv1_wgrad_fused: it has no data gradient)
+    assert calls["0"]["amx_bn_bwd_apply"] - calls["1"].get("amx_bn_bwd_apply", 0) == nf + calls["1"].get("amx_conv1_wgrad_fused", 0), calls
     for k in out["0"]:
         a, b = out["1"][k], out["0"][k]
         if k == "x" or (k.endswith("weight") and a.ndim == 4):

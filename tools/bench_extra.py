@@ -243,6 +243,8 @@ def _conv_flops(name, a):
         return 2.0 * (a[4] + a[9]) * a[21] * a[22] * a[18] * a[19] * a[20]
     if name == "amx_conv2d_dgrad":
         return 2.0 * a[1] * (a[5] + a[7]) * a[11] * a[8] * a[9] * a[10]
+    if name == "amx_conv2d_dgrad_fused":
+        return 2.0 * a[6] * (a[9] + a[11]) * a[15] * a[12] * a[13] * a[14]
     if name == "amx_conv2d_wgrad_fused":
         return 2.0 * (a[3] + a[7]) * a[20] * a[21] * a[17] * a[18] * a[19]
     if name == "amx_conv2d_wgrad_act":
