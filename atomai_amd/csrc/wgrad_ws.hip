@@ -367,7 +367,15 @@ int amx_wgrad_ws_mask() {
 
 bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int nt, int wm, int th) {
     if (taps != 9 || dil != 1 || lat) return false;
-    if (!(amx_wgrad_ws_mask() & wm)) return false;
+    if (!(amx_wgrad_ws_mask() & wm)) {
+        // The 64-channel class (mask bit 4, off by default) still takes layers of at least 128 image rows: measured per
+        // size inside the step (profiles/r04_logs/r04_step_ab8.log) the 256^2 and 128^2 launches cost nothing there
+        // (17.21-17.25 against 17.24 ms) and are 20 % faster on their own, the 64^2 bottleneck layers lose 0.05-0.07 ms.
+        // AMX_WGRAD_WS_WM4 = h > 0: at least h rows (default 128); h < 0: at most -h rows; 0: never.
+        const char* e = wm == 4 ? getenv("AMX_WGRAD_WS_WM4") : nullptr;
+        const int h = e ? atoi(e) : (wm == 4 && amx_wgrad_ws_mask() ? 128 : 0);
+        if (!(h > 0 && a.H >= h) && !(h < 0 && a.H <= -h)) return false;
+    }
     if (nt == 1) return th == 8;
     return th == 4 || (th == 8 && wm == 1 && a.WN == 1);
 }
