@@ -17,3 +17,9 @@ cd /root/repo
 ( AMX_BENCH_FORCE_DP=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 timeout 600 python bench.py --no-extra --no-cpu-baseline --sustain-seconds 0 ) > gpurun_out/r04_bench_forcedp.log 2>&1
 echo $HEAD > gpurun_out/r04_head.txt
 echo "== pytest"; tail -3 gpurun_out/r04_pytest_gpu.log; echo "== smoke"; tail -2 gpurun_out/r04_smoke.log; echo "== bench"; tail -5 gpurun_out/r04_bench_n1.log | cut -c1-1500; echo "== rocprof"; ls gpurun_out/r04_prof_serial gpurun_out/r04_prof gpurun_out/r04_pmc_FETCH_SIZE 2>&1 | head -12
+# hardware counters: SQ issue / MFMA (serial schedule), dilnet MFMA work + fetch sizes
+bash tools/gpu_pmc_sq.sh $HEAD r04 > gpurun_out/r04_pmc_sq_run.log 2>&1
+bash tools/gpu_pmc_dilnet.sh r04 > gpurun_out/r04_pmc_dilnet_run.log 2>&1
+bash tools/gpu_pmc_dilnet_fetch.sh > gpurun_out/r04_pmc_dilnet_fetch_run.log 2>&1
+tools/gpu_step_timeline.sh final > /dev/null 2>&1
+echo "== pmc"; tail -12 gpurun_out/r04_pmc_sq_run.log | cut -c1-250
