@@ -1,7 +1,7 @@
 // Lane <-> element map of v_mfma_f32_4x4x1_16b_f32 (16 blocks of 4x4, K = 1), found by experiment:
 //   run 1: a[lane] = lane, b = 1  -> D tells which A lane feeds each (lane, reg)
 //   run 2: a = 1, b[lane] = lane  -> which B lane
-// hipcc --offload-arch=gfx950 -o /tmp/mfma4x4_probe tools/micro/mfma4x4_probe.hip && /tmp/mfma4x4_probe
+// hipcc --offload-arch=gfx950 -o tools/micro/mfma4x4_probe.bin tools/micro/mfma4x4_probe.hip && tools/micro/mfma4x4_probe.bin (result: D[lane l][reg r] = A[lane 4*(l/4)+r] * B[lane l])
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
