@@ -26,7 +26,11 @@ and the steps are HIP kernels (csrc/aug.hip).  Same step order and parameter ran
   image); everything around it (draw order, crop windows, size formulas, rounding, the squeeze / drop rule) is pinned to
   the reference's own code run over that restatement (tests/golden/augment_geom.npz).  Class maps travel as the K
   one-hot planes the reference resamples and are squeezed back with its ``sum_c c * mask_c`` rule.
-* Not available: ``custom_transform`` (arbitrary host code).  Passing one raises.
+* ``custom_transform`` (imaug.py:79, 323-324: a user callable applied first, to the normalised images and the one-hot
+  masks) is arbitrary HOST code: the batch is normalised on the device, handed to the callable as the numpy arrays the
+  reference passes — images (N, H, W) float64, masks (N, H, W, C) float64 — and the result is uploaded again; everything
+  after it runs on the device as usual (no second normalisation before the final one, as in the reference).  The masks it
+  returns must still be one-hot / binary; the batch size and image size may change.
 """
 from typing import Callable, Optional, Tuple
 
@@ -36,7 +40,7 @@ import torch
 from .. import _lib as L
 
 _NP = 12
-_UNSUPPORTED = ("custom_transform",)
+_UNSUPPORTED = ()
 
 
 def _minmax(x: torch.Tensor) -> torch.Tensor:
@@ -63,6 +67,9 @@ class datatransform:
             raise NotImplementedError(f"augmentation {bad} is not available on the device path (host-code "
                                       "transforms, see atomai_amd/transforms/imaug.py)")
         self.ch = n_channels
+        self.custom_transform = kwargs.get("custom_transform")
+        if self.custom_transform is not None and not callable(self.custom_transform):
+            raise TypeError("custom_transform must be a callable (images, targets) -> (images, targets)")
         rng = lambda key, dflt: (dflt if kwargs.get(key) is True else kwargs.get(key))   # noqa: E731
         self.rotation = kwargs.get("rotation")
         self.background = kwargs.get("background")
@@ -174,6 +181,38 @@ class datatransform:
                int(clip01), int(round_out), L.stream_ptr(x))
         return y
 
+    def _host_transform(self, x: torch.Tensor, targets: torch.Tensor):
+        """``custom_transform`` (imaug.py:323-324): (x - min) / ptp on the device, then the user's callable on the host
+        with the arrays the reference hands it — images (N, H, W) float64, masks (N, H, W, C) float64 (one-hot planes of a
+        class map, the mask itself for one class) — and the result back on the device as (images fp32, class map int64 /
+        binary mask fp32 in the layout `targets` came in)."""
+        N, H, W = x.shape
+        dev = x.device
+        P = np.zeros((N, _NP))
+        P[:, 0] = 4                                           # no flip: normalisation only
+        xi = self._point(x, P, _minmax(x), None, None).cpu().numpy().astype(np.float64)
+        multi = bool(self.ch and self.ch > 1)
+        tnp = targets.detach().cpu().numpy()
+        if multi:
+            t = np.eye(self.ch)[(tnp[:, 0] if tnp.ndim == 4 else tnp).astype(np.int64)]          # (N, H, W, C)
+        else:
+            t = (tnp[:, 0] if tnp.ndim == 4 else tnp).astype(np.float64)[..., None]
+        xi, t = self.custom_transform(xi, t)
+        xi, t = np.asarray(xi), np.asarray(t)
+        if xi.ndim != 3 or t.ndim != 4 or t.shape[:3] != xi.shape or t.shape[-1] != (self.ch if multi else 1):
+            raise ValueError(f"custom_transform must return images (N, H, W) and masks (N, H, W, {self.ch if multi else 1}); "
+                             f"got {xi.shape} and {t.shape}")
+        x = torch.from_numpy(np.ascontiguousarray(xi, dtype=np.float32)).to(dev)
+        if multi:
+            cls = np.tensordot(t, np.arange(self.ch, dtype=np.float64), axes=([3], [0]))          # sum_c c * mask_c
+            if not np.array_equal(cls, np.round(cls)) or cls.min() < 0 or cls.max() > self.ch - 1 or \
+                    not np.array_equal(t.sum(-1), np.ones(cls.shape)):
+                raise ValueError("custom_transform must return one-hot masks (the device path carries class maps)")
+            tt = torch.from_numpy(cls.astype(np.int64)).to(dev)
+            return x, (tt[:, None] if targets.ndim == 4 else tt)
+        tt = torch.from_numpy(np.ascontiguousarray(t[..., 0], dtype=np.float32)).to(dev)
+        return x, (tt[:, None] if targets.ndim == 4 else tt)
+
     def _geometry(self, planes, zv, out_hw, reps: int, is_mask: bool):
         """zoom (centred zv x zv crop -> short side, INTER_CUBIC) then resize (whole frame -> out_hw, INTER_LINEAR as the
         reference's call executes) of (N * reps, H, W) planes; images are clipped after the zoom, masks rounded."""
@@ -194,6 +233,10 @@ class datatransform:
         fp32 binary masks.  ``fields`` (tests): {'gauss','poisson','sp_flip','sp_salt'} -> (N, H, W) tensors, 'jitter' -> (N, H) ints."""
         x = images[:, 0] if images.ndim == 4 else images
         x = x.float().contiguous()
+        normalised = False
+        if self.custom_transform is not None:
+            x, targets = self._host_transform(x, targets)
+            normalised = True                                 # (the reference normalises ONCE before the callable)
         N, H, W = x.shape
         H0, W0 = H, W
         flips, zv, out_hw, H, W = self.draw_geometry(N, H, W)
@@ -204,7 +247,7 @@ class datatransform:
             # resampled batch with the normalisation and the flip switched off
             P0 = np.zeros((N, _NP))
             P0[:, 0] = flips
-            x = self._point(x, P0, _minmax(x), None, None)
+            x = self._point(x, P0, None if normalised else _minmax(x), None, None)
             x = self._geometry(x, zv, out_hw, 1, False)
             P, extra = self.draw(N, H, W, flips=np.full(N, 4.0))
         else:
@@ -225,7 +268,7 @@ class datatransform:
             PA = P                                            # everything in ONE pass
         if "jitter" in fields:                                # tests: explicit shifts
             extra["jitter"] = np.asarray(fields["jitter"], dtype=np.int32)
-        x = self._point(x, PA, None if geo else _minmax(x), fields, extra.get("jitter"))
+        x = self._point(x, PA, None if (geo or normalised) else _minmax(x), fields, extra.get("jitter"))
         if need_split:
             # ---- pass B: poisson (its scale needs the number of distinct values of the image so far), salt & pepper
             PB = zero.copy()

@@ -120,11 +120,7 @@ def check_class_drop_and_trainer_hook(device):
     assert out.shape == (3, 1, 16, 16) and tl.shape == (3, 16, 16) and tl.dtype == torch.int64
     assert float(out.min()) == 0.0 and float(out.max()) == 1.0
     assert seg_augmentor(3) is None
-    try:
-        seg_augmentor(3, custom_transform=lambda a, b: (a, b))
-        raise AssertionError("custom_transform must raise")
-    except NotImplementedError:
-        pass
+    check_custom_transform(device)
     Xn = rs.rand(8, 16, 16).astype(np.float32)
     yn = rs.randint(0, 3, (8, 16, 16))
     m = aoi.models.Segmentor("Unet", nb_classes=3, nb_filters=4, seed=1)
@@ -133,6 +129,50 @@ def check_class_drop_and_trainer_hook(device):
         m.fit(Xn, yn, Xn[:4], yn[:4], training_cycles=3, batch_size=4, rotation=True, gauss_noise=[20, 40], contrast=True,
               background=True, plot_training_history=False, filename=os.path.join(tmp, "model"))
     assert len(m.loss_acc["train_loss"]) == 3 and all(np.isfinite(m.loss_acc["train_loss"]))
+
+
+def check_custom_transform(device):
+    """``custom_transform`` (reference imaug.py:79, 323-324): the user's host callable sees the normalised images
+    (N, H, W) float64 and the one-hot masks (N, H, W, C) float64 and runs FIRST; the device steps follow without a second
+    normalisation.  Checked through equivalences that need no cv2 / skimage: the identity callable changes nothing, a
+    flip inside the callable equals flipping the inputs (min / max normalisation commutes with it), a callable may drop
+    images, and what it receives is what the reference would pass."""
+    from atomai_amd.transforms import datatransform, seg_augmentor
+    rs = np.random.RandomState(3)
+    X = torch.from_numpy((rs.rand(5, 16, 24) * 3 + 1).astype(np.float32)).to(device)
+    lab = torch.from_numpy(rs.randint(0, 3, (5, 16, 24))).to(device)
+    kw = dict(rotation=True, gauss_noise=[20, 40], contrast=True, background=True)
+    seen = {}
+
+    def ident(a, b):
+        seen["a"], seen["b"] = a.copy(), b.copy()
+        return a, b
+    base = datatransform(3, 7, **kw).run(X, lab)
+    got = datatransform(3, 7, custom_transform=ident, **kw).run(X, lab)
+    assert torch.equal(base[0], got[0]) and torch.equal(base[1], got[1])
+    xn = X.cpu().numpy()
+    assert seen["a"].dtype == np.float64 and seen["a"].shape == (5, 16, 24) and seen["b"].shape == (5, 16, 24, 3)
+    np.testing.assert_allclose(seen["a"], (xn - xn.min()) / np.ptp(xn), rtol=0, atol=2e-7)
+    assert np.array_equal(seen["b"], np.eye(3)[lab.cpu().numpy()])
+    flip = lambda a, b: (a[:, :, ::-1], b[:, :, ::-1])                    # noqa: E731
+    got = datatransform(3, 7, custom_transform=flip, **kw).run(X, lab)
+    ref = datatransform(3, 7, **kw).run(X.flip(2).contiguous(), lab.flip(2).contiguous())
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+    got = datatransform(3, 7, custom_transform=lambda a, b: (a[1:] * 0.5, b[1:]), **kw).run(X, lab)
+    assert got[0].shape[0] <= 4 and got[0].shape[1:] == (1, 16, 24) and float(got[0].max()) == 1.0
+    # binary masks (one class): (N, 1, H, W) float in, the callable sees (N, H, W, 1)
+    Xb = X[:, :16, :16].contiguous()
+    mb = (torch.from_numpy(rs.rand(5, 1, 16, 16)) > 0.5).float().to(device)
+    got = datatransform(1, 2, custom_transform=lambda a, b: (a, 1.0 - b), rotation=True).run(Xb, mb)
+    ref = datatransform(1, 2, rotation=True).run(Xb, 1.0 - mb)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and got[1].shape == (5, 1, 16, 16)
+    try:
+        datatransform(3, 0, custom_transform=lambda a, b: (a, b * 0.5), rotation=True).run(X, lab)
+        raise AssertionError("soft masks must be refused")
+    except ValueError:
+        pass
+    aug = seg_augmentor(3, custom_transform=ident, rotation=True)
+    assert aug is not None
 
 
 def check_augment_geometry_golden(device):
