@@ -57,8 +57,11 @@ def _bind(cdll):
         fn = getattr(cdll, name)          # AttributeError -> symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    cdll.amx_last_error.restype = C.c_char_p     # the one entry point that does not return int
+    cdll.amx_last_error.restype = C.c_char_p     # the two entry points that do not return int
     cdll.amx_last_error.argtypes = []
+    cdll.amx_knob_name.restype = C.c_char_p
+    cdll.amx_knob_name.argtypes = [_I]
+    cdll.amx_knob.argtypes = [C.c_char_p]
     return cdll
 
 
@@ -85,6 +88,42 @@ def _inject_for_tests(cdll) -> None:
 
 def is_test_backend() -> bool:
     return _is_test_backend
+
+
+# ---- launch-plan switches (csrc/knobs.hip): the library resolves its AMX_* environment variables ONCE; the host side
+# reads the same resolved table, so a switch has one value per process no matter who asks.
+_knob_cache = {}
+
+
+def knob(name: str) -> int:
+    """Resolved value of the library switch ``name`` (an AMX_* environment name of csrc/knobs.hip)."""
+    v = _knob_cache.get(name)
+    if v is None:
+        v = load().amx_knob(name.encode())
+        if v == -2 ** 31:
+            raise AmxError(f"{name} is not a switch of libatomai_amd (see amx_knob_name / DESIGN.md §4)")
+        _knob_cache[name] = v
+    return v
+
+
+def knob_names():
+    lib = load()
+    return [lib.amx_knob_name(i).decode() for i in range(lib.amx_knob_count())]
+
+
+def set_knob(name: str, value) -> None:
+    """A/B scripts and tests: set (or, with None, remove) the environment variable of a switch and have the library
+    re-read its table.  Product code never calls this — the plan is frozen at the first launch."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    reload_knobs()
+
+
+def reload_knobs() -> None:
+    _knob_cache.clear()
+    load().amx_knobs_reload()
 
 
 class _StreamPtr(C.c_void_p):

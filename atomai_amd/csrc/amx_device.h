@@ -15,7 +15,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define AMX_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #endif
+#include <atomic>
 #include <cstdint>
+#include "knobs.h"
 
 #define AMX_WAVE 64
 
@@ -41,6 +43,30 @@ extern "C" void amx_set_error(const char* fn, int code, const char* detail);
             return (int)e__;                                      \
         }                                                         \
     } while (0)
+
+// Kernels that ask for more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised — once per
+// kernel AND device (a process may drive several: SegPredictor(device='cuda:1'), DKL replicas), from whichever host
+// thread launches first: a per-call-site atomic bit mask over the device index, no lock.
+#ifdef AMX_EMU
+#define AMX_ALLOW_160K_LDS(...) do { } while (0)
+#else
+#define AMX_ALLOW_160K_LDS(...)                                                                          \
+    do {                                                                                                 \
+        static std::atomic<unsigned> done__{0};                                                          \
+        int dev__ = 0;                                                                                   \
+        (void)hipGetDevice(&dev__);                                                                      \
+        const unsigned bit__ = 1u << (dev__ & 31);                                                       \
+        if (!(done__.load(std::memory_order_acquire) & bit__)) {                                         \
+            hipError_t e__ = hipFuncSetAttribute((const void*)(__VA_ARGS__),                             \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e__ != hipSuccess) {                                                                     \
+                amx_set_error(__func__, (int)e__, AMX_ERRSTR(e__));                                      \
+                return (int)e__;                                                                         \
+            }                                                                                            \
+            done__.fetch_or(bit__, std::memory_order_release);                                           \
+        }                                                                                                \
+    } while (0)
+#endif
 
 // Wave-level ordering point between LDS writes and reads of OTHER lanes of the same wave.  The hardware executes a
 // wave's instructions in lock step, so only the compiler must be kept from reordering (wave_barrier emits no code);
@@ -78,15 +104,15 @@ static inline int amx_num_cus() {
 #ifdef AMX_EMU
     return 4;
 #else
-    static int cached[16] = {0};
+    static std::atomic<int> cached[16];              // zero-initialised; racing first callers store the same value
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (!cached[dev]) {
-        int n = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (!n) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cached[dev] = n;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return n;
 #endif
 }
 static __host__ __device__ __forceinline__ int amx_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -264,7 +264,6 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // floats of the staged range of a block (0 = direct loads: switched off, or the range does not fit)
 static int conv1_stage_len(int ppb, int W, int dil) {
     if (!AMX_CONV1_LDS) return 0;
-    if (const char* e = getenv("AMX_CONV1_LDS")) if (atoi(e) == 0) return 0;
     const long len = (long)ppb + 2L * dil * (W + 1);
     return len <= CONV1_STAGE_MAX ? (int)len : 0;
 }

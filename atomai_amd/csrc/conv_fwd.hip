@@ -19,8 +19,7 @@ struct ConvPlan { int nt, th, rem; };
 // kernels of conv_fwd_dil.hip instead (in-process A/B; dilations 3 and 5 always use those).
 bool amx_lattice_mode(int taps, int dil) {
     if (taps != 9 || (dil != 2 && dil != 4 && dil != 6)) return false;
-    const char* e = getenv("AMX_CONV_LATTICE");
-    return !e || atoi(e) != 0;
+    return amx_knobs().conv_lattice != 0;
 }
 
 static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H, bool allow_rem = true) {
@@ -32,17 +31,15 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H, bool al
     if (cop <= 16) { pl.nt = 1; pl.th = 16; }
     else if (cop >= 64 && (nchunk >= 8 || !small)) { pl.nt = 4; pl.th = 16; }
     else { pl.nt = 2; pl.th = small ? 8 : 16; }
-    if (const char* e = getenv("AMX_CONV_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && v * 16 <= cop) pl.nt = v; }
-    if (const char* e = getenv("AMX_CONV_TH")) { const int v = atoi(e); if (v == 16 || (v == 8 && small)) pl.th = v; }
-    // experiment: 8-row tiles for the 64-cout dilated variant (AMX_CONV_DIL_TH=8)
-    if (taps == 9 && dil > 1 && pl.nt == 4) { if (const char* e = getenv("AMX_CONV_DIL_TH")) { if (atoi(e) == 8) pl.th = 8; } }
+    const AmxKnobs& kn = amx_knobs();
+    { const int v = kn.conv_nt; if ((v == 1 || v == 2 || v == 4) && v * 16 <= cop) pl.nt = v; }       // AMX_CONV_NT (tests, A/B)
+    { const int v = kn.conv_th; if (v == 16 || (v == 8 && small)) pl.th = v; }                        // AMX_CONV_TH
     // Round 4: widths of 25 / 50 filters (dilnet; 28 / 52 stored channels) run as 16 + 3 x 4 / 3 x 16 + 4 columns in ONE cout
     // block — the 4-wide remainder blocks on v_mfma_f32_4x4x1 (conv_kernel.h, REM) — instead of 32 / 2 x 32 padded
     // columns.  AMX_CONV_REM=0 switches it off (A/B); the fused classification head keeps the power-of-two plan.
     if (allow_rem && small && pl.th == 8 && pl.nt == 2) {
         const int c4 = amx_round_up(cout, 4);
-        bool on = true;
-        if (const char* e = getenv("AMX_CONV_REM")) on = atoi(e) != 0;
+        const bool on = kn.conv_rem != 0;
         if (on && c4 == 52) { pl.nt = 3; pl.rem = 1; }
         if (on && c4 == 28) { pl.nt = 1; pl.rem = 3; }
     }
@@ -128,8 +125,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     // dilated launches only.  The counters showed the dilated layers of dilnet fetching 3.3x (dilation 2 / 4) and 7.9x
     // (dilation 6) their input from HBM (profiles/r03_pmc_hbm_extra.md); with the XCD-aware order a dilnet frame goes
     // 1.282 -> 1.257 ms; plain 3x3 layers do not care (U-Net step 17.92 vs 17.93 ms, profiles/r03_conv_xcd_ab.log).
-    int xm = 3;
-    if (const char* e = getenv("AMX_CONV_XCD")) xm = atoi(e);
+    const int xm = amx_knobs().conv_xcd;
     a.xcd = xm == 1 || (xm == 2 && amx_round_up(cout, 16) > 32) || (xm == 3 && dil > 1);
     a.N = N; a.H = H; a.W = W;
     a.cout = cout;
@@ -256,7 +252,7 @@ extern "C" int amx_conv2d_dgrad_fused(const float* dy, const float* aux, const f
 }
 extern "C" int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil) {
     if (Cs <= 0 || Y0s <= 0 || (taps != 1 && taps != 9)) return 0;
-    if (const char* e = getenv("AMX_BWD_FUSE")) if (atoi(e) == 0) return 0;
+    if (!amx_knobs().bwd_fuse) return 0;
     ConvFwdArgs a = {};
     a.C0s = Cs; a.Y0s = Y0s; a.Y1s = Y1s; a.cout = Y0s + Y1s; a.N = N; a.H = H; a.W = W;
     a.bw_aux = reinterpret_cast<const float*>(&a);          // (any non-null value: the query dereferences nothing)

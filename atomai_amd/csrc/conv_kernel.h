@@ -716,22 +716,9 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
         const size_t epi = (size_t)4 * (MTW < 2 ? MTW : 2) * TILE * (NB + AMX_CONV_EPI_PAD) * sizeof(float);
         if (lds < epi) lds = epi;
     }
-    // occupancy experiment: AMX_CONV_MAXWG=k pads the LDS request so that at most k workgroups fit a CU
-    if (const char* e = getenv("AMX_CONV_MAXWG")) {
-        const int k = atoi(e);
-        if (k >= 1 && k <= 8) { const size_t want = (size_t)(160 * 1024 / k) / 256 * 256; if (want > lds) lds = want; }
-    }
     // (REM: one cout block covers every stored channel)
     dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? LAT * LAT : 1), REM ? 1 : amx_ceil_div(a.cop, NT * 16));
-#ifndef AMX_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>);
     AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;

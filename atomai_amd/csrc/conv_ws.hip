@@ -330,14 +330,7 @@ static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
     int wgs = amx_num_cus();
     if (wgs > ntiles) wgs = ntiles;
-#ifndef AMX_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_ws_kernel<NCH, NT, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(conv_ws_kernel<NCH, NT, BWD>);
     AMX_LAUNCH((conv_ws_kernel<NCH, NT, BWD>), dim3(wgs), dim3(1024), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
@@ -361,9 +354,7 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
     // and the lost overlap competes with what the faster kernel wins; measured per class in-process
     // (profiles/r03_dgrad_first_ab.log): forward only 18.17 ms, + c6.0 18.03, + the two 32 -> 32 launches 17.99, while the
     // 32 -> 16 launch costs 0.09 ms (all classes: 18.1-18.5, the round's earlier "no gain" result).
-    int mode = 1, dmask = 7;
-    if (const char* e = getenv("AMX_CONV_WS")) mode = atoi(e);
-    if (const char* e = getenv("AMX_CONV_WS_DGRAD")) dmask = atoi(e);
+    const int mode = amx_knobs().conv_ws, dmask = amx_knobs().conv_ws_dgrad;
     if (mode <= 0) return false;
     if ((mode == 2 && !a.bias) || (mode == 3 && a.bias)) return false;
     if (mode == 1 && !a.bias) {
@@ -381,11 +372,11 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
     return true;
 }
 
-static long ws_launches = 0;
-extern "C" long amx_conv2d_ws_launches(void) { return ws_launches; }
+static std::atomic<long> ws_launches{0};
+extern "C" long amx_conv2d_ws_launches(void) { return ws_launches.load(std::memory_order_relaxed); }
 
 int amx_conv_launch_ws(ConvFwdArgs& a, hipStream_t s) {
-    ++ws_launches;
+    ws_launches.fetch_add(1, std::memory_order_relaxed);
     a.tiles_x = a.W / TILE; a.tiles_y = a.H / TILE;
     const int nch = (a.C0s + a.C1s) / 16;
     if (a.bw_aux) {

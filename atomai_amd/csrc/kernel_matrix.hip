@@ -62,7 +62,7 @@ template <typename T, int DR>
 __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict__ X1, const T* __restrict__ X2,
                                                             const T* __restrict__ inv_ls, T s2, int kind,
                                                             T noise, int N, int M, int D, T* __restrict__ K,
-                                                            int getenv_nt) {
+                                                            int km_mode) {
     constexpr int V = Vec16<T>::N;
     constexpr int COLS = 64 * V;                         // columns per workgroup
     constexpr int KM_ROWS = KmRows<T>::value;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
             }
             T w;
             T k;
-            if (sizeof(T) == 4 && kind == 0 && (getenv_nt & 2)) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2));
+            if (sizeof(T) == 4 && kind == 0 && (km_mode & 2)) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2));
             else k = km_eval<T>(r2, s2, kind, &w);
             if (gi == col0 + c) k += noise;
             out[v] = k;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
         T* dst = K + (size_t)gi * M + gc;
         if (gc + V <= M && ((M * sizeof(T)) % 16 == 0)) {
             if (V == 4) {
-                if (getenv_nt & 1) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
+                if (km_mode & 1) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
                 else *reinterpret_cast<float4*>(dst) = *reinterpret_cast<float4*>(out);
             }
             else { dst[0] = out[0]; dst[1] = out[1]; }
@@ -132,7 +132,7 @@ static int launch_km(const void* X1, const void* X2, const void* inv_ls, double 
                      int N, int M, int D, void* K, hipStream_t st) {
     constexpr int COLS = 64 * Vec16<T>::N;
     dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KmRows<T>::value));
-    const int nt = getenv("AMX_KM_NT") ? atoi(getenv("AMX_KM_NT")) : 3;   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp
+    constexpr int nt = 3;   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp (profiles/r02_logs/r02w_km_ab.log)
     if (D <= 4) {
         AMX_LAUNCH((kernel_matrix_kernel<T, 4>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
                    (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);

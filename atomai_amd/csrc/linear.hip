@@ -199,7 +199,7 @@ extern "C" int amx_gemm_f32_splitk(const float* A, long sam, long sak, const flo
     // 64 x 64 tiles unless they would leave most of the chip idle (< 128 workgroups): then 32 x 32 (4x the workgroups)
     const long wg64 = (long)amx_ceil_div(N, 64) * amx_ceil_div(M, 64);
     int tile = wg64 < 128 ? 32 : 64;
-    if (const char* e = getenv("AMX_GEMM_TILE")) { const int v = atoi(e); if (v == 32 || v == 64) tile = v; }
+    { const int v = amx_knobs().gemm_tile; if (v == 32 || v == 64) tile = v; }                          // AMX_GEMM_TILE (A/B)
     dim3 grid(amx_ceil_div(N, tile), amx_ceil_div(M, tile));
     if (grid.y > 65535) AMX_BADARG(4);
     if (splits > 1) {

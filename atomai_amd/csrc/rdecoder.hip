@@ -682,15 +682,7 @@ template <int HID, int MT>
 static int launch_fwd(const RDecArgs& a, hipStream_t s) {
     const size_t lds = fwd_lds<HID, MT>(a.skip);
     if (lds > 160 * 1024) AMX_BADARG(20);
-#ifndef AMX_EMU
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_fwd_kernel<HID, MT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(rdecoder_fwd_kernel<HID, MT>);
     AMX_LAUNCH((rdecoder_fwd_kernel<HID, MT>), dim3(a.B), dim3(4 * HID), lds, s, a);
     AMX_CHECK_LAUNCH();
     return 0;
@@ -700,15 +692,7 @@ template <int HID, int MT, int NL, bool SAVED>
 static int launch_bwd_v(const RDecArgs& a, hipStream_t s) {
     const size_t lds = bwd_lds<HID, MT, NL>(a.skip);
     if (lds > 160 * 1024) AMX_BADARG(20);
-#ifndef AMX_EMU
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)rdecoder_bwd_kernel<HID, MT, NL, SAVED>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(rdecoder_bwd_kernel<HID, MT, NL, SAVED>);
     AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL, SAVED>), dim3(a.B), dim3(4 * HID), lds, s, a);
     AMX_CHECK_LAUNCH();
     return 0;
@@ -760,7 +744,7 @@ extern "C" int amx_rdecoder_fwd_save(const float* coords, const float* theta, co
     hipStream_t s = (hipStream_t)stream;
     int mt = 64;      // 64-pixel tiles: 66 KB of LDS -> two workgroups per CU (58.8 % vs 53.4 % of MFMA peak measured; round 3:
                       // 32-pixel tiles, three workgroups per CU: rVAE step 4.99 -> 5.13 ms, not instantiated)
-    if (const char* e = getenv("AMX_RDEC_FWD_MT")) mt = atoi(e);
+    mt = amx_knobs().rdec_fwd_mt;
     if (hid == 32) return launch_fwd<32, 128>(a, s);
     if (hid == 64) return launch_fwd<64, 128>(a, s);
     return (skip || mt == 64) ? launch_fwd<128, 64>(a, s) : launch_fwd<128, 128>(a, s);
@@ -814,8 +798,7 @@ extern "C" int amx_rdecoder_bwd_saved(const float* coords, const float* theta, c
     }
     if (hid == 32) { RD_BWD(32, 64) }
     if (hid == 64) { RD_BWD(64, 64) }
-    int mt = 64;
-    if (const char* e = getenv("AMX_RDEC_BWD_MT")) mt = atoi(e);
+    const int mt = amx_knobs().rdec_bwd_mt;
     if (mt == 64 && NL + 1 + (skip ? 1 : 0) <= 4) { RD_BWD(128, 64) }
     RD_BWD(128, 32)
 #undef RD_BWD

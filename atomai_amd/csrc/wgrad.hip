@@ -30,15 +30,13 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     // gradients run on the side stream next to the data-gradient convolutions, and there the lighter
     // one-workgroup-per-CU launch wins (20.79 vs 21.43 ms/step, interleaved A/B with AMX_WGRAD_LIGHT): the step
     // is what is optimised.  AMX_WGRAD_LIGHT=<wgs> switches the stand-alone optimum on for experiments.
-    bool light = false;
-    int light_wgs = 512;
-    if (const char* e = getenv("AMX_WGRAD_LIGHT")) { const int v = atoi(e); if (v >= 64) { light = pl.ci_pad <= 32; light_wgs = v; } }
-    pl.th = (taps == 9 && dil == 1 && (light || pl.NT == 2)) ? 4 : 8;
-    if (const char* e = getenv("AMX_WGRAD_TH")) { const int v = atoi(e); if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }
+    const AmxKnobs& kn = amx_knobs();
+    pl.th = (taps == 9 && dil == 1 && pl.NT == 2) ? 4 : 8;
+    { const int v = kn.wgrad_th; if (v == 8 || (v == 4 && taps == 9 && dil == 1)) pl.th = v; }      // AMX_WGRAD_TH (tests, A/B)
     // 16 -> 32 channels (U-Net c2.0) on the wave-specialised kernel: with 4-row tiles a consumer wave has ONE row (72 MFMAs,
     // ~1 us) per tile and the producers' loads of tile k+2 are not back when tile k+1 must be staged; 8-row tiles double the
     // prefetch distance and cut the halo re-read from 1.69x to 1.41x (profiles/r04_wgrad_ws.md)
-    if (taps == 9 && dil == 1 && !lat && pl.NT == 2 && pl.WM == 1 && pl.WN == 1 && amx_wgrad_ws_mask() & 1 && !getenv("AMX_WGRAD_TH"))
+    if (taps == 9 && dil == 1 && !lat && pl.NT == 2 && pl.WM == 1 && pl.WN == 1 && amx_wgrad_ws_mask() & 1 && !kn.wgrad_th)
         pl.th = 8;
     if (lat) pl.th = pl.NT == 2 ? 4 : 8;                    // the instantiated lattice classes
     if (pl.WK > pl.th) pl.WK = pl.th;
@@ -46,8 +44,8 @@ static WgradPlan plan_wgrad(int N, int H, int W, int Cin_s, int cout, int taps, 
     const int ls = lat ? odil : 1;
     const int ntiles = amx_ceil_div(amx_ceil_div(W, ls), TW) * amx_ceil_div(amx_ceil_div(H, ls), pl.th) * N * ls * ls;
     // split-K workgroups: one per CU (256: 20.98 ms/step, 512: 21.5, 1024: 21.6, 128: 25.2)
-    int target = light ? light_wgs : 256;
-    if (const char* e = getenv("AMX_WGRAD_WGS")) { const int v = atoi(e); if (v >= 1) target = v; }   // (tests: few workgroups, many tiles each)
+    int target = 256;
+    if (kn.wgrad_wgs >= 1) target = kn.wgrad_wgs;            // AMX_WGRAD_WGS (tests: few workgroups, many tiles each)
     int ks = amx_ceil_div(target, blocks);
     if (ks > ntiles) ks = ntiles;
     if (ks < 1) ks = 1;

@@ -327,15 +327,7 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream) {
     const int SD = (COB % 32 == 16) ? COB : COB + 16;
     const size_t lds = ((size_t)(TH + 2 * halo) * (TW + 2 * halo) * SX + (size_t)TH * TW * SD) * sizeof(float);
     dim3 grid(a.ksplit, amx_ceil_div(a.ci_pad, CIB) * a.co_blocks);
-#ifndef AMX_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<TAPS, NT, WM, MAXHALO, TH, LAT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(wgrad_kernel<TAPS, NT, WM, MAXHALO, TH, LAT>);
     AMX_LAUNCH((wgrad_kernel<TAPS, NT, WM, MAXHALO, TH, LAT>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;

@@ -325,15 +325,7 @@ static int launch_wgrad_ws_np(const WgradArgs& a, hipStream_t stream) {
     if (a.WN != WN || a.WK != 4 / (WM * WN)) AMX_BADARG(9);
     const size_t lds = 2 * ((size_t)(TH + 2) * (TW + 2) * SX + (size_t)TH * TW * SD) * sizeof(float);
     dim3 grid(a.ksplit, amx_ceil_div(a.ci_pad, CIB) * a.co_blocks);
-#ifndef AMX_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_ws_kernel<NT, WM, WN, TH, LAT, NP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-#endif
+    AMX_ALLOW_160K_LDS(wgrad_ws_kernel<NT, WM, WN, TH, LAT, NP>);
     AMX_LAUNCH((wgrad_ws_kernel<NT, WM, WN, TH, LAT, NP>), grid, dim3(256 + NP), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
@@ -342,11 +334,10 @@ static int launch_wgrad_ws_np(const WgradArgs& a, hipStream_t stream) {
 // Producer waves: 8 on the <= 32-input-channel classes (with 4 the producers' stage + issue phases fill the whole tile time
 // there and the consumers wait 13-24 % of their life at the barrier; with 8 they wait 2-9 %: 0.66 -> 0.68, 0.60 -> 0.66,
 // 0.74 -> 0.77 of peak stand-alone), 4 on the 64-channel class (no difference: 0.81-0.83 either way);
-// profiles/r04_logs/r04_wgrad_ws_phases2.log, r04_wgrad_ws_np_ab.log.  AMX_WGRAD_WS_PRODUCERS = 4 | 8 overrides (A/B).
+// profiles/r04_logs/r04_wgrad_ws_phases2.log, r04_wgrad_ws_np_ab.log (measured with a since-removed override).
 template <int NT, int WM, int WN, int TH, int LAT>
 static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
-    int np = WM < 4 ? 8 : 4;
-    if (const char* e = getenv("AMX_WGRAD_WS_PRODUCERS")) np = atoi(e) == 4 ? 4 : 8;
+    constexpr int np = WM < 4 ? 8 : 4;
     return np == 4 ? launch_wgrad_ws_np<NT, WM, WN, TH, LAT, 256>(a, stream) : launch_wgrad_ws_np<NT, WM, WN, TH, LAT, 512>(a, stream);
 }
 
@@ -359,10 +350,8 @@ static int launch_wgrad_ws(const WgradArgs& a, hipStream_t stream) {
 // mask 4 (profiles/r04_logs/r04_step_ab5.log; the thin classes are where the loaders' fused BatchNorm backward needs the
 // producer waves: 18.24 ms without the wave-specialised kernel at all).
 int amx_wgrad_ws_mask() {
-    int mode = 1, mask = 3;
-    if (const char* e = getenv("AMX_WGRAD_WS")) mode = atoi(e);
-    if (const char* e = getenv("AMX_WGRAD_WS_MASK")) mask = atoi(e);
-    return mode <= 0 ? 0 : (mask & 7);
+    const AmxKnobs& kn = amx_knobs();
+    return kn.wgrad_ws <= 0 ? 0 : (kn.wgrad_ws_mask & 7);
 }
 
 bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int nt, int wm, int th) {
@@ -372,19 +361,18 @@ bool amx_wgrad_ws_supported(const WgradArgs& a, int taps, int dil, int lat, int 
         // size inside the step (profiles/r04_logs/r04_step_ab8.log) the 256^2 and 128^2 launches cost nothing there
         // (17.21-17.25 against 17.24 ms) and are 20 % faster on their own, the 64^2 bottleneck layers lose 0.05-0.07 ms.
         // AMX_WGRAD_WS_WM4 = h > 0: at least h rows (default 128); h < 0: at most -h rows; 0: never.
-        const char* e = wm == 4 ? getenv("AMX_WGRAD_WS_WM4") : nullptr;
-        const int h = e ? atoi(e) : (wm == 4 && amx_wgrad_ws_mask() ? 128 : 0);
+        const int h = (wm == 4 && amx_wgrad_ws_mask()) ? amx_knobs().wgrad_ws_wm4 : 0;
         if (!(h > 0 && a.H >= h) && !(h < 0 && a.H <= -h)) return false;
     }
     if (nt == 1) return th == 8;
     return th == 4 || (th == 8 && wm == 1 && a.WN == 1);
 }
 
-static long wgrad_ws_launches = 0;
-extern "C" long amx_conv2d_wgrad_ws_launches(void) { return wgrad_ws_launches; }
+static std::atomic<long> wgrad_ws_launches{0};
+extern "C" long amx_conv2d_wgrad_ws_launches(void) { return wgrad_ws_launches.load(std::memory_order_relaxed); }
 
 int amx_wgrad_launch_ws(const WgradArgs& a, int nt, int wm, int th, hipStream_t s) {
-    ++wgrad_ws_launches;
+    wgrad_ws_launches.fetch_add(1, std::memory_order_relaxed);
     if (nt == 1) {                                                // 16 output channels: one cout tile, WN = 1
         if (wm == 1) return launch_wgrad_ws<1, 1, 1, 8, 0>(a, s);
         if (wm == 2) return launch_wgrad_ws<1, 2, 1, 8, 0>(a, s);

@@ -36,6 +36,12 @@ import os as _os
 FUSE = int(_os.environ.get("AMX_FUSE", "2")) & 6
 
 
+def bwd_fuse_enabled() -> bool:
+    """AMX_BWD_FUSE (csrc/knobs.hip, default 1): BatchNorm / LeakyReLU backward formed inside the loaders of the
+    wave-specialised data- and weight-gradient kernels.  The library and the host read the same resolved switch."""
+    return L.knob("AMX_BWD_FUSE") != 0
+
+
 def r4(c: int) -> int:
     return (c + 3) // 4 * 4
 
@@ -134,8 +140,6 @@ class _PackCache:
     def _refresh_all(self, device) -> None:
         gen = _weight_generation[0]
         self.refreshed_gen = gen
-        if _os.environ.get("AMX_PACK_BATCH", "1") == "0":       # experiment switch: per-layer packing only
-            return
         jobs = []
         for ent in self.store.values():
             w = ent[2]()
@@ -413,7 +417,7 @@ class ConvNode(_Node):
         # kernel, which forms it while loading (amx_conv1_wgrad_fused) — the 512^2 x 16-channel apply pass of U-Net's c1
         # (0.32 ms at the very end of the backward pass, nothing left to overlap it) is not launched at all
         if (not fused and self.bn is not None and self.x_plain is not None and self.mask is None and out.gx is None
-                and self.post_slope == 1.0 and _os.environ.get("AMX_BWD_FUSE", "1") != "0"):
+                and self.post_slope == 1.0 and bwd_fuse_enabled()):
             fused_ws = True
         fused = fused or fused_ws
         k = None
@@ -484,10 +488,10 @@ class ConvNode(_Node):
         # The weight gradient (MFMA-bound) has no consumer inside backward: side stream.
         w_in = (dpre, aux, kptr)
         d_in = (dpre, aux, kptr) if dpre_mat is None else (dpre_mat, None, (None, None, None))
-        order = _wgrad_order()
-        if order == 0 or self.x_plain is not None:
-            with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
-                self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
+        # (enqueued BEFORE the layer's data gradient; after it, or on the main stream, measured no different / slower:
+        #  profiles/r04_wgrad_ws.md.  Tape.use_side_stream = False serialises everything for the per-kernel timing pass.)
+        with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
+            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         if self.x_plain is not None:
             return
         s0 = self.srcs[0]
@@ -496,13 +500,6 @@ class ConvNode(_Node):
         C0, C0s = s0.C, s0.Cs
         C1, C1s = (s1.C, s1.Cs) if s1 else (0, 0)
         self._dgrad(tape, d_in[0], d_in[1], d_in[2], s0, s1, N, H, W, C0, C0s, C1, C1s, cos, sp)
-        if order == 1:
-            # the weight gradient starts when this layer's DATA gradient has finished and runs next to the HBM-bound
-            # BatchNorm-backward / pooling passes of the layer below instead of next to the data gradient
-            with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
-                self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
-        elif order == 2:
-            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)       # experiment: everything on one stream
 
     def _bwd_fusable(self, out) -> bool:
         """True when this layer's BatchNorm / LeakyReLU backward can be formed inside the loaders of its two consumers
@@ -666,8 +663,10 @@ class ResOutNode(_Node):
         ds = _empty(g.shape, g)
         # the convolution branch gets its own copy when its producer forwards the gradient tensor unchanged to a
         # weight-gradient kernel on the side stream (no BatchNorm in between) while the residual branch keeps
-        # accumulating into it
-        alias_unsafe = not t.producer
+        # accumulating into it.  With a BatchNorm in between the same hazard exists whenever the producer's backward is
+        # formed inside its consumers' loaders (ConvNode._bwd_fusable): the side stream's weight-gradient kernel then
+        # reads THIS tensor as `dy` while the residual branch's data gradient adds into it on the main stream.
+        alias_unsafe = (not t.producer) or bwd_fuse_enabled()
         ds2 = _empty(g.shape, g) if (alias_unsafe and r.needs_grad) else None
         L.call("amx_lrelu_bwd", L.ptr(g), L.ptr(self.out.t), None, None, self.slope, t.npix, t.Cs, L.ptr(ds),
                L.ptr(ds2), _sp(g))
@@ -1009,16 +1008,6 @@ def _side_stream(dev) -> "torch.cuda.Stream":
     with a fresh stream per step every 4th one landed on the main stream's queue and that step lost the
     weight-gradient overlap (+2.6 ms, visible as a period-4 pattern in the per-step times)."""
     return aux_stream(dev, 0)
-
-
-def _wgrad_order() -> int:
-    """AMX_WGRAD_ORDER (read per backward, so an in-process A/B can flip it): 0 = the weight gradient of a layer is
-    enqueued on the side stream BEFORE the layer's data gradient (both MFMA kernels share the CUs), 1 = after it (the side
-    stream waits for the data gradient), 2 = on the main stream after it (no overlap at all)."""
-    return int(_os.environ.get("AMX_WGRAD_ORDER", _WGRAD_ORDER_DEFAULT))
-
-
-_WGRAD_ORDER_DEFAULT = "0"
 
 
 class _SideCtx:

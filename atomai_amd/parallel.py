@@ -108,6 +108,12 @@ def init_distributed(backend: str = None, force: bool = False):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
+        # One process per GPU shares the host: torch's intra-op pool defaults to every logical CPU, so 8 ranks would
+        # run 8 x 256 spinning OpenMP threads behind each staging copy (the effect measured on the predict pipeline,
+        # DESIGN.md §4).  Each rank keeps its share of the cores; AMX_RANK_THREADS overrides.
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        share = max(1, (os.cpu_count() or 1) // max(1, local_world))
+        torch.set_num_threads(int(os.environ.get("AMX_RANK_THREADS", min(torch.get_num_threads(), share))))
         import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("AMX_DIST_TIMEOUT_S", "600"))))

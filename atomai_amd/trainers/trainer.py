@@ -30,6 +30,9 @@ def _shuffle(arr: np.ndarray, random_state: int) -> np.ndarray:
     return shuffle(arr, random_state=random_state)
 
 
+EARLY_LOSS = os.environ.get("AMX_EARLY_LOSS", "1") != "0"       # host-side switch, read once at import (see _EarlyScalar)
+
+
 class _EarlyScalar:
     """``loss.item()`` without draining the stream.  The reference reads the loss after ``optimizer.step()``
     (trainer.py:205-211); ``.item()`` there waits for everything queued so far — backward and Adam included — and only
@@ -42,7 +45,7 @@ class _EarlyScalar:
 
     def __init__(self, t: torch.Tensor):
         self.t, self.ev = t, None
-        if not t.is_cuda or os.environ.get("AMX_EARLY_LOSS", "1") == "0":
+        if not t.is_cuda or not EARLY_LOSS:
             return
         from ..engine import aux_stream
         dev = t.device

@@ -202,14 +202,27 @@ class datatransform:
         if xi.ndim != 3 or t.ndim != 4 or t.shape[:3] != xi.shape or t.shape[-1] != (self.ch if multi else 1):
             raise ValueError(f"custom_transform must return images (N, H, W) and masks (N, H, W, {self.ch if multi else 1}); "
                              f"got {xi.shape} and {t.shape}")
-        x = torch.from_numpy(np.ascontiguousarray(xi, dtype=np.float32)).to(dev)
         if multi:
-            cls = np.tensordot(t, np.arange(self.ch, dtype=np.float64), axes=([3], [0]))          # sum_c c * mask_c
-            if not np.array_equal(cls, np.round(cls)) or cls.min() < 0 or cls.max() > self.ch - 1 or \
-                    not np.array_equal(t.sum(-1), np.ones(cls.shape)):
-                raise ValueError("custom_transform must return one-hot masks (the device path carries class maps)")
+            # The reference hands whatever the callable returned to its geometric steps (each followed by np.around on
+            # the masks) and finally to squeeze_channels: label = sum_c c * mask_c, the pair is kept iff exactly C
+            # distinct labels occur (imaug.py:361-393) — it never raises.  Same here: masks are rounded, squeezed, and a
+            # frame whose labels leave [0, C-1] (overlapping channels) is dropped, as the reference's rule drops a frame
+            # that shows all C classes plus such a value.  (A frame that LACKS a class and has an out-of-range label in
+            # its place survives in the reference with that bogus label; here it is dropped too — the device path
+            # carries class maps, which cannot hold it.)  Uncovered pixels become class 0, as in the reference.
+            cls = np.tensordot(np.around(t), np.arange(self.ch, dtype=np.float64), axes=([3], [0]))   # sum_c c * mask_c
+            flat = cls.reshape(len(cls), -1)
+            ok = (flat.min(1) >= 0) & (flat.max(1) <= self.ch - 1)
+            if not ok.all():
+                xi, cls = xi[ok], cls[ok]
+            if not len(xi):
+                raise RuntimeError("custom_transform left no usable frame: every returned mask has pixels whose channels "
+                                   "overlap (label sum_c c * mask_c outside [0, n_channels - 1]); the reference's "
+                                   "squeeze_channels rule drops such frames (transforms/imaug.py:361-393)")
+            x = torch.from_numpy(np.ascontiguousarray(xi, dtype=np.float32)).to(dev)
             tt = torch.from_numpy(cls.astype(np.int64)).to(dev)
             return x, (tt[:, None] if targets.ndim == 4 else tt)
+        x = torch.from_numpy(np.ascontiguousarray(xi, dtype=np.float32)).to(dev)
         tt = torch.from_numpy(np.ascontiguousarray(t[..., 0], dtype=np.float32)).to(dev)
         return x, (tt[:, None] if targets.ndim == 4 else tt)
 

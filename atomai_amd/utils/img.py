@@ -48,24 +48,21 @@ def extract_subimages(imgdata: np.ndarray, coordinates: Union[Dict[int, np.ndarr
                       window_size: int, coord_class: int = 0) -> Tuple[np.ndarray]:
     """Sub-images centred on the detected objects of one class, for every frame (img.py:298-350): returns
     (stack, centres, frame numbers) — the usual bridge from ``Segmentor.predict`` output to ``rVAE.fit`` input."""
-    if isinstance(coordinates, np.ndarray):
-        coordinates = {0: np.concatenate((coordinates, np.zeros((coordinates.shape[0], 1))), axis=-1)}
-    if np.ndim(imgdata) == 2:
-        imgdata = imgdata[None, ..., None]
-    subimages_all, com_all, frames_all = [], [], []
-    for i, (img, coord) in enumerate(zip(imgdata, coordinates.values())):
-        coord_i = coord[np.where(coord[:, 2] == coord_class)][:, :2]
-        stack_i, com_i = get_imgstack(img, coord_i, window_size)
-        if stack_i is None:
-            continue
-        subimages_all.append(stack_i)
-        com_all.append(com_i)
-        frames_all.append(np.ones(len(com_i), int) * i)
-    if len(subimages_all) > 0:
-        subimages_all = np.concatenate(subimages_all, axis=0)
-        com_all = np.concatenate(com_all, axis=0)
-        frames_all = np.concatenate(frames_all, axis=0)
-    return subimages_all, com_all, frames_all
+    single = isinstance(coordinates, np.ndarray)
+    per_frame = [np.column_stack((coordinates, np.zeros(len(coordinates))))] if single else list(coordinates.values())
+    frames = np.asarray(imgdata)
+    if frames.ndim == 2:
+        frames = frames[None, :, :, None]
+    parts = []                                          # (windows, centres, frame index) of every frame that yields any
+    for frame_no, (frame, table) in enumerate(zip(frames, per_frame)):
+        table = np.asarray(table)
+        wanted = table[table[:, 2] == coord_class, :2]
+        windows, centres = get_imgstack(frame, wanted, window_size)
+        if windows is not None:
+            parts.append((windows, centres, np.full(len(centres), frame_no, dtype=int)))
+    if not parts:
+        return [], [], []                               # the reference's return value when nothing survives
+    return tuple(np.concatenate(col, axis=0) for col in zip(*parts))
 
 
 def crop_borders(imgdata: np.ndarray, thresh: float = 0) -> np.ndarray:

@@ -34,6 +34,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -230,16 +231,59 @@ def _free_port() -> int:
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU) from here."""
     port = _free_port()
-    procs = []
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), AMX_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env))
-    rc = 0
+        # every rank's stderr goes to its own temporary file: the tail of the FIRST rank that fails is what the
+        # launcher prints (eight interleaved tracebacks, seven of them "peer closed the connection", tell nothing)
+        ef = tempfile.TemporaryFile(mode="w+b")
+        errs.append(ef)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env,
+                                      stderr=ef))
+    # Poll instead of waiting rank by rank: a rank that dies leaves the others inside the next collective until the
+    # process-group timeout (AMX_DIST_TIMEOUT_S, minutes) — the first non-zero exit ends the job within a second.
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        else:
+            time.sleep(0.2)
+    if failed is None:
+        for r, ef in enumerate(errs):                        # warnings of healthy ranks are still worth seeing
+            _relay_stderr(ef, r, n, tail=None)
+        return 0
+    rc = procs[failed].returncode
+    for r, p in enumerate(procs):
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.time() + 5.0
     for p in procs:
-        rc = p.wait() or rc
-    return rc
+        try:
+            p.wait(timeout=max(0.1, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    print(f"bench.py: rank {failed} of {n} exited with code {rc}; the other ranks were stopped.  "
+          f"Its stderr (tail):", file=sys.stderr, flush=True)
+    _relay_stderr(errs[failed], failed, n, tail=40)
+    return rc if rc > 0 else 1
+
+
+def _relay_stderr(ef, rank: int, n: int, tail=None) -> None:
+    ef.seek(0)
+    lines = ef.read().decode(errors="replace").splitlines()
+    ef.close()
+    if tail is not None:
+        lines = lines[-tail:]
+    for ln in lines:
+        print(f"[rank {rank}/{n}] {ln}", file=sys.stderr)
+    sys.stderr.flush()
 
 
 def extra_configs():
@@ -269,9 +313,21 @@ class _Mi355x:
     dist_backend = None                                      # init_distributed's default on a GPU host: nccl (= RCCL)
     collective = "nccl (RCCL)"
 
-    def check(self):
+    def check(self, gpus=1):
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+        seen = torch.cuda.device_count()
+        if seen < gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but only {seen} GPU(s) are visible to this process "
+                             f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', 'unset')}, "
+                             f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES', 'unset')})")
+
+    def collective_version(self):
+        try:
+            v = torch.cuda.nccl.version()                    # RCCL reports through torch's nccl binding
+            return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception as e:                               # never let a version string take the line down
+            return f"unknown ({type(e).__name__})"
 
     def device(self, local):
         torch.cuda.set_device(local)
@@ -301,14 +357,16 @@ def main(argv=None, backend=None):
     ap.add_argument("--hw", type=int, default=H, help="TEST ONLY: image size")
     ap.add_argument("--bs", type=int, default=BS, help="TEST ONLY: batch size per GPU")
     ap.add_argument("--nb-filters", type=int, default=16, help="TEST ONLY: U-Net width")
+    ap.add_argument("--fail-rank", type=int, default=-1,
+                    help="TEST ONLY: this rank raises after the warm-up (the launcher must end the job at once)")
     args = ap.parse_args(argv)
     be = backend or _Mi355x()
 
+    if int(os.environ.get("WORLD_SIZE", str(args.gpus))) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
+    be.check(args.gpus)                                      # (before any rank is spawned: one clear line, not N tracebacks)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
-    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
-    be.check()
     import atomai_amd as aoi
     from atomai_amd.parallel import DataParallelGrads, init_distributed
     force_dp = os.environ.get("AMX_BENCH_FORCE_DP") == "1"      # N=1 through the RCCL branch (a 1-rank nccl group)
@@ -348,6 +406,8 @@ def main(argv=None, backend=None):
     for i in range(args.warmup):
         losses.append(one_step(i))
         wmarks.append(time.perf_counter())
+    if args.fail_rank == rank:
+        raise RuntimeError(f"--fail-rank {rank}: injected failure (launcher test)")
     barrier()
     ms0 = be.memory_stats(dev)
     t0 = time.perf_counter()
@@ -444,8 +504,11 @@ def main(argv=None, backend=None):
         "config": {"workload": f"Segmentor U-Net nb_classes=3, {hw}x{hw}, bs={bs}/GPU, fp32, CE loss, Adam 1e-3 "
                                "(BASELINE.json configs[1]); step = fwd+bwd+allreduce+Adam+loss.item()",
                    "global_batch": world * bs, "parallelism": f"dp{world}",
-                   "world_size_seen": world,
+                   "world_size_seen": (torch.distributed.get_world_size() if torch.distributed.is_initialized()
+                                       else world),          # what the process group itself reports
                    "collective_backend": be.collective if (world > 1 or force_dp) else None,
+                   "rccl_version": be.collective_version() if (world > 1 or force_dp) else None,
+                   "cpu_threads_per_rank": torch.get_num_threads(),
                    "launcher": "self" if os.environ.get("AMX_BENCH_SELF_LAUNCHED") else
                                ("torchrun" if "WORLD_SIZE" in os.environ else "single"),
                    "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]},

@@ -28,6 +28,18 @@ extern "C" {
 const char* amx_last_error(void);
 int amx_clear_error(void);
 
+/* ---- launch-plan switches (no reference counterpart: stock PyTorch picks its kernels inside ATen).
+ * Every AMX_* environment variable the library understands is a row of ONE table (csrc/knobs.hip; DESIGN.md §4
+ * "Switches").  The table is read once, on the first call that needs a plan, under a lock, into an immutable plan that
+ * every launch reads afterwards — no getenv on the launch path, the same plan on every host thread / stream.
+ *   amx_knob(name)      value of the resolved switch `name` ("AMX_CONV_WS", ...); INT_MIN for an unknown name
+ *   amx_knob_count()    number of rows;  amx_knob_name(i)  environment name of row i (NULL out of range)
+ *   amx_knobs_reload()  re-reads the environment: the hook of in-process A/B scripts and plan-comparison tests */
+int amx_knob(const char* name);
+int amx_knob_count(void);
+const char* amx_knob_name(int i);
+int amx_knobs_reload(void);
+
 /* ---- convolution: nn.Conv2d(k=3|1, padding=dilation) + bias + LeakyReLU + BN batch statistics,
  * reading torch.cat([src0, src1], 1) with each source's BN affine applied on load.
  * atomai/nets/blocks.py:61-76 (ConvBlock), :122-132 (UpsampleBlock 1x1), :300-318 (DilatedBlock);

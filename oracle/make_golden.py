@@ -207,7 +207,7 @@ def make_predict(aoi):
     print("predict ok", out["Unet|probs"].shape, out["dilnet|probs"].shape)
 
 
-def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3, nb_classes=0):
+def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3, nb_classes=0, loss="mse"):
     x = rs.rand(B, *in_dim).astype(np.float32)
     eps_all = rs.randn(steps, B, 8).astype(np.float32)
     out[f"{name}|x"], out[f"{name}|eps"] = x, eps_all
@@ -232,7 +232,7 @@ def _vae_run(out, rs, name, ctor, fit_kw, in_dim, B, steps=3, nb_classes=0):
             m.kdict_["phi_prior"] = fit_kw.get("rotation_prior", 0.1)
         if "capacity" in fit_kw:
             m.kdict_["capacity"] = fit_kw["capacity"]
-        m.loss = "mse"
+        m.loss = loss                                          # what fit(loss=...) sets (rvae.py:196, vae.py:729)
         m.compile_trainer((x, y), None, batch_size=B)
         yt = None if y is None else torch.from_numpy(y).long()
         state = {"i": 0}
@@ -308,6 +308,38 @@ def make_vae(aoi):
     finally:
         os.chdir(cwd)
     np.savez_compressed(os.path.join(GOLD, "vae.npz"), **out)
+
+
+def make_vae_ce(aoi):
+    """Reconstruction loss 'ce' (vi_losses.py:27-34): binary cross entropy with logits.  For a 2-D in_dim it is summed
+    over the pixels of a sample; for a 3-D in_dim the reference's reshape makes it a sum over the CHANNELS only, so the
+    later .mean() runs over samples x pixels — both pinned here."""
+    out = {}
+    rs = np.random.RandomState(11)
+
+    def run(*a, **k):
+        _vae_run(out, rs, *a, **k)
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        run("rvae16_ce", lambda: aoi.models.rVAE((16, 16), latent_dim=2, seed=0, numhidden_encoder=32,
+                                                 numhidden_decoder=32), dict(), (16, 16), 6, loss="ce")
+        run("vae16_ce", lambda: aoi.models.VAE((16, 16), latent_dim=2, seed=0, numhidden_encoder=32,
+                                               numhidden_decoder=32), dict(), (16, 16), 6, loss="ce")
+        run("rvae12_rgb_ce", lambda: aoi.models.rVAE((12, 12, 3), latent_dim=2, seed=0, numhidden_encoder=32,
+                                                     numhidden_decoder=32), dict(), (12, 12, 3), 5, loss="ce")
+        run("vae16_ce_cap", lambda: aoi.models.VAE((16, 16), latent_dim=2, seed=0, numhidden_encoder=32,
+                                                   numhidden_decoder=32), dict(capacity=[5.0, 100, 2.0]), (16, 16), 4,
+            loss="ce")
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "vae_ce.npz"), **out)
+
+
+def make_seg_k9(aoi):
+    """nb_classes = 9 (> the 8 classes the register-resident head kernels hold): px conv, CrossEntropyLoss, one step."""
+    _seg_case(aoi, "seg_unet_c9_nf4_b2_32", "Unet", 9, 4, 2, 32, 1)
+    _seg_case(aoi, "seg_dilnet_c11_nf5_b2_32", "dilnet", 11, 5, 2, 32, 2)
 
 
 def make_vae_cond(aoi):
@@ -705,10 +737,10 @@ def make_gp(aoi):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp", "dil_drop", "iou", "augment_geom"]
+    what = sys.argv[1:] or ["seg", "blocks", "config1", "predict", "vae", "vae_conv", "ckpt", "locator", "ensemble", "vae_api", "vae_cond", "augment", "gp", "dil_drop", "iou", "augment_geom", "vae_ce", "seg_k9"]
     aoi = ref_harness.import_reference()
     torch.set_num_threads(8)
     for w in what:
         {"seg": make_seg, "blocks": make_blocks, "config1": make_config1,
-         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp, "dil_drop": make_dil_drop, "iou": make_iou, "augment_geom": make_augment_geom}[w](aoi)
+         "predict": make_predict, "vae": make_vae, "vae_conv": make_vae_conv, "ckpt": make_ckpt, "locator": make_locator, "seg_res": make_seg_res, "seg_hed": make_seg_hed, "ensemble": make_ensemble, "vae_api": make_vae_api, "vae_cond": make_vae_cond, "augment": make_augment, "gp": make_gp, "dil_drop": make_dil_drop, "iou": make_iou, "augment_geom": make_augment_geom, "vae_ce": make_vae_ce, "seg_k9": make_seg_k9}[w](aoi)
     print("done ->", GOLD)

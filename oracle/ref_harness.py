@@ -10,7 +10,9 @@ The reference does not import on this image as-is:
   * cv2 / skimage / torchvision / mendeleev / gpytorch / progressbar / ase are absent
     -> served as auto-stub modules by a meta-path finder;
   * ``torch.utils.data.TensorDataset()`` with zero tensors raises on torch 2.10
-    (atomai/trainers/trainer.py:90-91) -> __init__ shim.
+    (atomai/trainers/trainer.py:90-91) -> __init__ shim;
+  * ``np.product`` (atomai/losses_metrics/vi_losses.py:28, the 'ce' reconstruction loss) was removed in
+    numpy 2 -> the alias ``np.product = np.prod`` is restored for the reference's benefit.
 """
 import importlib.abc
 import importlib.machinery
@@ -92,6 +94,9 @@ def import_reference():
                 return
             _orig(self, *tensors)
         torch.utils.data.TensorDataset.__init__ = _init
+        import numpy
+        if not hasattr(numpy, "product"):
+            numpy.product = numpy.prod
         sys.path.insert(0, REFERENCE_ROOT)
         _installed = True
     import atomai

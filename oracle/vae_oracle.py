@@ -100,6 +100,26 @@ def reconstruction_mse(x: Tensor, x_rec: Tensor) -> Tensor:
     return 0.5 * ((x_rec.reshape(B, -1) - x.reshape(B, -1)) ** 2).sum(1)
 
 
+def reconstruction_ce(x: Tensor, x_rec: Tensor, in_dim: Sequence[int]) -> Tensor:
+    """'ce' branch (vi_losses.py:27-34): binary_cross_entropy_with_logits(reduction='none') of the decoder output
+    against the image, reshaped to (-1, H*W) for a 2-D in_dim and to (-1, H*W, C) for a 3-D one, then ``.sum(-1)``:
+    per-SAMPLE sums (B,) in the first case, per-PIXEL sums over the channels (B, H*W) in the second — the callers'
+    ``.mean()`` then averages over samples, or over samples x pixels."""
+    rs = (int(in_dim[0]) * int(in_dim[1]),)
+    if len(in_dim) == 3:
+        rs = rs + (int(in_dim[-1]),)
+    return torch.nn.functional.binary_cross_entropy_with_logits(x_rec.reshape(-1, *rs), x.reshape(-1, *rs),
+                                                                reduction="none").sum(-1)
+
+
+def reconstruction(loss: str, x: Tensor, x_rec: Tensor, in_dim=None) -> Tensor:
+    if loss == "mse":
+        return reconstruction_mse(x, x_rec)
+    if loss == "ce":
+        return reconstruction_ce(x, x_rec, in_dim if in_dim is not None else tuple(x.shape[1:]))
+    raise NotImplementedError("Reconstruction loss must be 'mse' or 'ce'")
+
+
 def kld_normal(mu: Tensor, log_sd: Tensor) -> Tensor:
     """KL(N(mu, sd) || N(0,1)) summed over latent dims (vi_losses.py:40-57)."""
     return (-log_sd + 0.5 * torch.exp(log_sd) ** 2 + 0.5 * mu ** 2 - 0.5).sum(-1)
@@ -117,19 +137,20 @@ def infocapacity(kl: Tensor, capacity: Sequence[float], num_iter: int) -> Tensor
     return gamma * torch.abs(kl - cap)
 
 
-def rvae_elbo(x, x_rec, z_mean, z_logsd, phi_prior: float = 0.1, capacity=None, num_iter: int = 0) -> Tensor:
-    """rvae_loss with 'mse' (vi_losses.py:111-137): the rotation latent gets the dedicated prior, the
+def rvae_elbo(x, x_rec, z_mean, z_logsd, phi_prior: float = 0.1, capacity=None, num_iter: int = 0,
+              loss: str = "mse", in_dim=None) -> Tensor:
+    """rvae_loss (vi_losses.py:111-137): the rotation latent gets the dedicated prior, the
     translation latents enter kld_normal together with the content latents."""
-    like = -reconstruction_mse(x, x_rec).mean()
+    like = -reconstruction(loss, x, x_rec, in_dim).mean()
     kl = kld_normal(z_mean[:, 1:], z_logsd[:, 1:]).mean() + kld_rot(phi_prior, z_logsd[:, 0]).mean()
     if capacity is not None:
         kl = infocapacity(kl, capacity, num_iter)
     return like - kl
 
 
-def vae_elbo(x, x_rec, z_mean, z_logsd, capacity=None, num_iter: int = 0) -> Tensor:
-    """vae_loss with 'mse' (vi_losses.py:87-108)."""
-    like = -reconstruction_mse(x, x_rec).mean()
+def vae_elbo(x, x_rec, z_mean, z_logsd, capacity=None, num_iter: int = 0, loss: str = "mse", in_dim=None) -> Tensor:
+    """vae_loss (vi_losses.py:87-108)."""
+    like = -reconstruction(loss, x, x_rec, in_dim).mean()
     kl = kld_normal(z_mean, z_logsd).mean()
     if capacity is not None:
         kl = infocapacity(kl, capacity, num_iter)
@@ -139,7 +160,7 @@ def vae_elbo(x, x_rec, z_mean, z_logsd, capacity=None, num_iter: int = 0) -> Ten
 def rvae_forward_elbo(enc: StateDict, dec: StateDict, x: Tensor, eps: Tensor, x_coord: Tensor,
                       translation: bool = True, dx_prior: float = 0.1, phi_prior: float = 0.1,
                       skip: bool = False, capacity=None, num_iter: int = 0, num_layers=(2, 2),
-                      conv_enc: bool = False) -> Tensor:
+                      conv_enc: bool = False, loss: str = "mse") -> Tensor:
     """rVAE.forward_compute_elbo, training mode, with the reparameterisation noise injected
     (atomai/models/dgm/rvae.py:110-147; trainers/vitrainer.py:223-234)."""
     B = x.shape[0]
@@ -152,14 +173,14 @@ def rvae_forward_elbo(enc: StateDict, dec: StateDict, x: Tensor, eps: Tensor, x_
     else:
         dx, zc = 0, z[:, 1:]
     coords = transform_coordinates(x_coord.expand(B, *x_coord.shape), phi, dx)
-    x_rec = r_decoder(dec, coords, zc, tuple(x.shape[1:3]), num_layers[1], skip)
-    return rvae_elbo(x, x_rec, z_mean, z_logsd, phi_prior, capacity, num_iter)
+    x_rec = r_decoder(dec, coords, zc, tuple(x.shape[1:]), num_layers[1], skip)     # (H, W) or (H, W, C), ed.py:606-609
+    return rvae_elbo(x, x_rec, z_mean, z_logsd, phi_prior, capacity, num_iter, loss, tuple(x.shape[1:]))
 
 
 def vae_forward_elbo(enc: StateDict, dec: StateDict, x: Tensor, eps: Tensor, capacity=None,
-                     num_iter: int = 0, num_layers=(2, 2)) -> Tensor:
+                     num_iter: int = 0, num_layers=(2, 2), loss: str = "mse") -> Tensor:
     """VAE.forward_compute_elbo (atomai/models/dgm/vae.py:661-687)."""
     z_mean, z_logsd = fc_encoder(enc, x, num_layers[0])
     z = z_mean + torch.exp(z_logsd) * eps[:, : z_mean.shape[1]]
     x_rec = fc_decoder(dec, z, tuple(x.shape[1:3]), num_layers[1])
-    return vae_elbo(x, x_rec, z_mean, z_logsd, capacity, num_iter)
+    return vae_elbo(x, x_rec, z_mean, z_logsd, capacity, num_iter, loss, tuple(x.shape[1:]))

@@ -166,11 +166,23 @@ def check_custom_transform(device):
     got = datatransform(1, 2, custom_transform=lambda a, b: (a, 1.0 - b), rotation=True).run(Xb, mb)
     ref = datatransform(1, 2, rotation=True).run(Xb, 1.0 - mb)
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and got[1].shape == (5, 1, 16, 16)
+    # masks that are not exactly one-hot: the reference never raises — it carries them through its
+    # geometric steps and squeeze_channels decides per frame.  Here they are rounded and squeezed on arrival:
+    soft = lambda a, b: (a, 0.9 * b + 0.04)                               # noqa: E731  (rounds back to the one-hot masks)
+    got = datatransform(3, 7, custom_transform=soft, **kw).run(X, lab)
+    assert torch.equal(base[0], got[0]) and torch.equal(base[1], got[1])
+
+    def overlap_first(a, b):                                  # frame 0: a patch where every channel is set (label 3 > 2)
+        b = b.copy()
+        b[0, :4, :4, :] = 1.0
+        return a, b
+    got = datatransform(3, 7, custom_transform=overlap_first, rotation=True).run(X, lab)
+    assert got[0].shape[0] <= 4                                # that frame is dropped, the batch goes on
     try:
-        datatransform(3, 0, custom_transform=lambda a, b: (a, b * 0.5), rotation=True).run(X, lab)
-        raise AssertionError("soft masks must be refused")
-    except ValueError:
-        pass
+        datatransform(3, 0, custom_transform=lambda a, b: (a, b * 0.0 + 1.0), rotation=True).run(X, lab)
+        raise AssertionError("a batch whose every frame is unusable must say so")
+    except RuntimeError as e:
+        assert "custom_transform left no usable frame" in str(e)
     aug = seg_augmentor(3, custom_transform=ident, rotation=True)
     assert aug is not None
 

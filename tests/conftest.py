@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _default_plan_after_each_test():
+    # set up before `monkeypatch` (no dependency on it) => torn down after it has restored the environment
+    yield
+    from atomai_amd import _lib as L
+    if L._lib is not None:
+        L.reload_knobs()

@@ -20,9 +20,12 @@ class EmulatedDevice:
     dist_backend = "gloo"
     collective = "gloo (CPU emulator of the kernel sources)"
 
-    def check(self):
+    def check(self, gpus=1):
         import emu_backend
         emu_backend.use_emulator()
+
+    def collective_version(self):
+        return "gloo"
 
     def device(self, local):
         return torch.device("cpu")

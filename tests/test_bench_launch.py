@@ -93,3 +93,36 @@ def test_gpus_flag_must_match_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + TINY, env=env,     # the product script
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.timeout(600)
+def test_a_failing_rank_ends_the_job_at_once():
+    """when one rank dies the launcher must not leave the others inside the next collective until the
+    process-group timeout (minutes).  `--fail-rank 1` makes rank 1 raise after the warm-up; the launcher returns
+    non-zero within seconds of that, names the rank and relays ITS stderr tail."""
+    import time
+    if torch.cuda.is_available():
+        pytest.skip("CPU/gloo tier")
+    env = dict(_clean_env(), AMX_DIST_TIMEOUT_S="600")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--fail-rank", "1"] + TINY, env=env,
+                       capture_output=True, text=True, timeout=500)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert "rank 1 of 2 exited with code" in r.stderr, r.stderr[-2000:]
+    assert "injected failure" in r.stderr and "[rank 1/2]" in r.stderr, r.stderr[-2000:]
+    assert not _json_lines(r.stdout)                      # no measurement line from a broken job
+    # start-up (imports, emulator load, 1 warm-up step) dominates; the point is: far below the 600 s collective timeout
+    assert took < 120, took
+
+
+def test_more_gpus_asked_than_visible_is_one_clear_line():
+    """`bench.py --gpus N` with fewer than N visible devices: one line, before any rank is spawned (here: no GPU at all)."""
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("needs a host with fewer than 8 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + TINY, env=_clean_env(),
+                       capture_output=True, text=True, timeout=300)
+    msg = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert ("only" in msg and "visible" in msg) or "needs an MI355X" in msg, msg[-1000:]
+    assert "Traceback" not in msg

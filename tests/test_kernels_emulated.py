@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from _knobs import set_knob
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 
 
@@ -89,13 +91,13 @@ def test_conv_layer_wide_channels(cin, cout, H, N):
 def test_conv_layer_16_row_tiles(cin, cout, H, monkeypatch):
     """The 16-row tile variant forced where the plan would pick 8 rows, with image heights that are not a
     multiple of either tile."""
-    monkeypatch.setenv("AMX_CONV_TH", "16")
+    set_knob(monkeypatch, "AMX_CONV_TH", "16")
     test_conv_layer_wide_channels(cin, cout, H, 1)
 
 
 @pytest.mark.parametrize("cin,cout,H", [(64, 32, 20), (16, 16, 36)])
 def test_wgrad_4_row_tiles(cin, cout, H, monkeypatch):
-    monkeypatch.setenv("AMX_WGRAD_TH", "4")
+    set_knob(monkeypatch, "AMX_WGRAD_TH", "4")
     test_conv_layer_wide_channels(cin, cout, H, 1)
 
 
@@ -109,7 +111,7 @@ def test_wave_specialised_wgrad_is_bit_identical(cin, cout, H, N, monkeypatch):
     S.check_wgrad_ws_bit_identical("cpu", cin, cout, H, N, monkeypatch)
     if (cin, cout) == (16, 32):                       # the class whose plan differs: same tile height for both kernels
         S.check_wgrad_ws_bit_identical("cpu", cin, cout, H, N, monkeypatch, force_th=8)
-    monkeypatch.setenv("AMX_WGRAD_WGS", "3")          # 1-3 workgroups: every one walks several tiles (both LDS images,
+    set_knob(monkeypatch, "AMX_WGRAD_WGS", "3")          # 1-3 workgroups: every one walks several tiles (both LDS images,
     S.check_wgrad_ws_bit_identical("cpu", cin, cout, H, N, monkeypatch)     # the two-tiles-ahead load issue)
 
 

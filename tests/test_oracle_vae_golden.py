@@ -13,6 +13,12 @@ CASES = {
     "rvae16_cap": dict(kind="rvae", translation=False, skip=True, capacity=[5.0, 100, 2.0]),
     "vae16": dict(kind="vae", capacity=None),
     "rvae16_conv": dict(kind="rvae", translation=True, skip=False, capacity=None, conv=True, file="vae_conv.npz"),
+    # reconstruction loss 'ce' (vi_losses.py:27-34; the reference needs np.product restored under numpy 2, ref_harness.py)
+    "rvae16_ce": dict(kind="rvae", translation=True, skip=False, capacity=None, loss="ce", file="vae_ce.npz"),
+    "vae16_ce": dict(kind="vae", capacity=None, loss="ce", file="vae_ce.npz"),
+    "rvae12_rgb_ce": dict(kind="rvae", translation=True, skip=False, capacity=None, loss="ce", file="vae_ce.npz",
+                          grid=(12, 12)),
+    "vae16_ce_cap": dict(kind="vae", capacity=[5.0, 100, 2.0], loss="ce", file="vae_ce.npz"),
 }
 
 
@@ -42,10 +48,11 @@ def test_elbo_and_grads(golden_dir, name, tag, dtype, tol):
     e = {k: leaves[("e", k)] for k in enc}
     d = {k: leaves[("d", k)] for k in dec}
     if c["kind"] == "rvae":
-        elbo = vo.rvae_forward_elbo(e, d, x, eps, vo.imcoordgrid((16, 16), dtype), c["translation"], 0.1, 0.1,
-                                    c["skip"], c["capacity"], num_iter=1, conv_enc=c.get("conv", False))
+        elbo = vo.rvae_forward_elbo(e, d, x, eps, vo.imcoordgrid(c.get("grid", (16, 16)), dtype), c["translation"], 0.1,
+                                    0.1, c["skip"], c["capacity"], num_iter=1, conv_enc=c.get("conv", False),
+                                    loss=c.get("loss", "mse"))
     else:
-        elbo = vo.vae_forward_elbo(e, d, x, eps, c["capacity"], num_iter=1)
+        elbo = vo.vae_forward_elbo(e, d, x, eps, c["capacity"], num_iter=1, loss=c.get("loss", "mse"))
     np.testing.assert_allclose(float(elbo), g[f"{name}|elbo|{tag}"][0], rtol=tol)
     (-elbo).backward()
     for (which, k), v in leaves.items():

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from _knobs import set_knob
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
 import _seg_checks as C  # noqa: E402
 
@@ -148,7 +150,7 @@ def test_dilated_layers_on_ragged_sizes():
 
 def test_dilated_layers_halo_class_kernels_still_agree(monkeypatch):
     """AMX_CONV_LATTICE=0 keeps the halo-class kernels of conv_fwd_dil.hip reachable (in-process A/B switch)."""
-    monkeypatch.setenv("AMX_CONV_LATTICE", "0")
+    set_knob(monkeypatch, "AMX_CONV_LATTICE", "0")
     C.check_dilated_ragged("cpu", cases=((16, 20, 23, 41, 1),))
 
 
@@ -184,6 +186,12 @@ def test_bn_backward_formed_in_the_loaders_unet(monkeypatch):
     """U-Net nb_filters 16 at 64x64: c6.0 (two outputs), c5.3 / c2.3 (32 -> 32) and c2.0 (32 -> 16) take the fused path."""
     assert C.check_bwd_fused_in_loaders("cpu", 0, 0, monkeypatch, hw=64, batch=2, unet=True) == 4
 
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 16), (32, 32)])
+def test_bn_backward_formed_in_the_loaders_resblock(cin, cout, monkeypatch):
+    """ResBlocks through the fused BatchNorm-backward loaders (c1 and c2 of every block) against the two-pass form."""
+    assert C.check_bwd_fused_in_loaders("cpu", cin, cout, monkeypatch, hw=32, batch=2, res=True, repeats=2) >= 2
 
 
 def test_loss_upstream_gradient_factor():

@@ -350,6 +350,15 @@ def test_bn_backward_formed_in_the_loaders_unet(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(8, 16), (32, 32)])
+def test_bn_backward_formed_in_the_loaders_resblock(cin, cout, monkeypatch):
+    """ResBlocks (16 / 32 channels, >= 2 x CUs tiles) through the fused loaders; 6 repetitions must agree bit
+    for bit with each other (a side-stream / main-stream race on the shared gradient tensor would not) and with
+    AMX_BWD_FUSE=0."""
+    assert C.check_bwd_fused_in_loaders("cuda", cin, cout, monkeypatch, hw=128, batch=12, res=True, repeats=6) >= 2
+
+
+@pytest.mark.gpu
 def test_loss_upstream_gradient_factor():
     C.check_loss_upstream_gradient("cuda")
 

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import atomai_amd as aoi
+from atomai_amd import _lib as L
 name, vals = sys.argv[1], sys.argv[2].split(",")
 rs = np.random.RandomState(0)
 X = rs.rand(64, 512, 512).astype(np.float32); y = rs.randint(0, 3, (64, 512, 512))
@@ -11,7 +12,7 @@ m.compile_trainer((X, y, X[:32], y[:32]), training_cycles=10, batch_size=32)
 res = {v: [] for v in vals}
 for rep in range(3):
     for v in vals:
-        os.environ[name] = v
+        L.set_knob(name, v)
         for i in range(3): m.train_step(m.X_train[i % 2], m.y_train[i % 2])
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(8): m.train_step(m.X_train[i % 2], m.y_train[i % 2])

@@ -1,8 +1,8 @@
 """In-process A/B of library / environment-selected kernel variants on whole workloads (dev tool):
      U-Net bs 32 512^2 training step (ms/step, min of 3 x 8 steps) and dilnet 1024^2 predict (device ms/frame).
    python tools/gpu_step_ab.py "AMX_CONV_PERSIST=0" "AMX_CONV_PERSIST=1" "AMX_CONV_PERSIST=2" ...
-The C library reads its switches with getenv at every launch, so variants interleave in ONE process (same clocks,
-same allocator state)."""
+The library freezes its switches at the first launch (csrc/knobs.hip); a variant change re-reads them through
+amx_knobs_reload, so variants interleave in ONE process (same clocks, same allocator state)."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,6 +24,7 @@ def setenv(v):
     if name not in _libs:
         _libs[name] = _lib._bind(ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f"libatomai_amd_{name}.so")))
     _lib._lib = _libs[name]
+    _lib.reload_knobs()                   # every build carries its own switch table
     from atomai_amd import engine
     engine._pack_cache.store.clear()      # weight images are library-specific (layout of a partial last K chunk)
     engine.FUSE_HEAD = os.environ.get("AMX_FUSE_HEAD", "1") != "0"     # (python-level switch)
@@ -65,4 +66,4 @@ for k, v in res.items():
           f"dilnet {min(v['dilnet_ms_per_frame']):6.3f} ms/frame = {91.62e9 / min(v['dilnet_ms_per_frame']) / 1e9:5.1f} TF"
           f"  (max |out - first variant| {v['dilnet_max_abs_diff_vs_first']:.1e})", flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/r02_step_ab.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/step_ab.json", "w"), indent=1)
