@@ -309,6 +309,11 @@ extern "C" int amx_aug_labels(const long long* t, long long* out, const float* p
 //   cubic:   taps s - 1 .. s + 2 with indices clamped to [0, src - 1];  weights (A = -0.75, formed in float):
 //            w0 = ((A (t + 1) - 5A)(t + 1) + 8A)(t + 1) - 4A,  w1 = ((A + 2) t - (A + 3)) t^2 + 1,
 //            w2 = ((A + 2)(1 - t) - (A + 3))(1 - t)^2 + 1,     w3 = 1 - w0 - w1 - w2
+//   area (mode 2, cv2.INTER_AREA when the image is ENLARGED along an axis — what utils/img.py:cv_resize selects for
+//            `img.shape[0] < target`, predictors/predictor.py:203-204): OpenCV runs its linear kernel with "area-mode"
+//            coefficients:  s = floor(d * src / dst),  t = (d + 1) - (s + 1) * dst / src,  t <= 0 -> 0 else t - floor(t);
+//            same border rule as linear.  (True area averaging — both axes shrunk under INTER_AREA — is a different
+//            kernel and is not provided: cv_resize only reaches it for non-square frames.)
 //   horizontal pass first, then vertical (separable; evaluated per output pixel here).
 // win: per image (y0, x0, h, w) of the source window inside the [Hs][Ws] frame (zoom: centred crop; resize: whole frame).
 struct ResampleTaps { int idx[4]; float w[4]; int n; };
@@ -319,7 +324,13 @@ static __device__ __forceinline__ ResampleTaps resample_taps(int d, int src, int
     const float f = (float)(((double)d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     float t = f - (float)s;
-    if (mode == 0) {
+    if (mode == 2) {
+        const double inv_scale = (double)dst / (double)src;
+        s = (int)floor((double)d * scale);
+        t = (float)((double)(d + 1) - (double)(s + 1) * inv_scale);
+        t = t <= 0.f ? 0.f : t - floorf(t);
+    }
+    if (mode == 0 || mode == 2) {
         if (s < 0) { s = 0; t = 0.f; }
         if (s >= src - 1) { s = src - 1; t = 0.f; }
         r.n = 2;
@@ -364,7 +375,7 @@ __global__ void aug_resample_kernel(const float* __restrict__ x, float* __restri
 extern "C" int amx_aug_resample(const float* x, float* y, const int* win, int N, int Hs, int Ws, int Hd, int Wd, int mode,
                                 int clip01, int round_out, void* stream) {
     if (!x || !y || !win || x == y) AMX_BADARG(1);
-    if (N <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || mode < 0 || mode > 1) AMX_BADARG(2);
+    if (N <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || mode < 0 || mode > 2) AMX_BADARG(2);
     long nb = ((long)N * Hd * Wd + 255) / 256;
     if (nb > 16384) nb = 16384;
     AMX_LAUNCH(aug_resample_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, win, N, Hs, Ws, Hd, Wd,

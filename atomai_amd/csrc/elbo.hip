@@ -1,6 +1,9 @@
 // elbo.hip — the VAE / rVAE evidence lower bound terms, forward and backward (HBM-bound, tiny).
 //
 //   reconstruction_loss('mse'): 0.5 * sum_pixels (x_rec - x)^2 per sample   atomai/losses_metrics/vi_losses.py:23-26
+//   reconstruction_loss('ce'):  sum of binary_cross_entropy_with_logits(x_rec, x) = max(v,0) - v t + log1p(exp(-|v|)),
+//       per sample for a 2-D in_dim; for a 3-D in_dim the reference sums over the channels only and its .mean() then
+//       runs over samples x pixels — i.e. the per-sample sum times 1 / (H W): `recon_scale`     vi_losses.py:27-34
 //   kld_normal: sum_d (-logsd + 0.5 sd^2 + 0.5 mu^2 - 0.5)                  vi_losses.py:40-57
 //   kld_rot:    -logsd_phi + log(phi_prior) + sd_phi^2 / (2 phi_prior^2) - 0.5   vi_losses.py:77-84
 //   rvae_loss: the rotation latent (index 0) gets kld_rot, ALL remaining latents (translation + content)
@@ -9,23 +12,39 @@
 // optional capacity term |KL - C| are B-element plumbing on the host side).
 #include "amx_device.h"
 
+// recon_kind: 0 = 'mse', 1 = 'ce' (logits in xrec).  Term and derivative of one element:
+static __device__ __forceinline__ float elbo_recon_term(int kind, float v, float t) {
+    if (kind == 0) { const float d = v - t; return d * d; }                       // (0.5 applied once to the sum)
+    return fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+}
+static __device__ __forceinline__ float elbo_recon_grad(int kind, float v, float t) {
+    if (kind == 0) return v - t;
+    const float e = expf(-fabsf(v));
+    return (v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e)) - t;                      // sigmoid(v) - t
+}
+
 __global__ __launch_bounds__(256) void elbo_terms_fwd_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ xrec,
                                                              const float* __restrict__ zmean,
                                                              const float* __restrict__ zlogsd, int n, int Z,
-                                                             int rot, float phi_prior, float* __restrict__ recon,
+                                                             int rot, float phi_prior, int recon_kind,
+                                                             float recon_scale, float* __restrict__ recon,
                                                              float* __restrict__ klz, float* __restrict__ klrot) {
     __shared__ float red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     float acc = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const float d = xrec[(size_t)b * n + i] - x[(size_t)b * n + i];
-        acc = fmaf(d, d, acc);
+    if (recon_kind == 0) {
+        for (int i = tid; i < n; i += 256) {
+            const float d = xrec[(size_t)b * n + i] - x[(size_t)b * n + i];
+            acc = fmaf(d, d, acc);
+        }
+    } else {
+        for (int i = tid; i < n; i += 256) acc += elbo_recon_term(1, xrec[(size_t)b * n + i], x[(size_t)b * n + i]);
     }
     red[tid] = acc; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) {
-        recon[b] = 0.5f * red[0];
+        recon[b] = recon_kind == 0 ? 0.5f * red[0] : recon_scale * red[0];
         float kz = 0.f;
         for (int d = rot ? 1 : 0; d < Z; ++d) {
             const float ls = zlogsd[(size_t)b * Z + d], mu = zmean[(size_t)b * Z + d];
@@ -42,12 +61,13 @@ __global__ __launch_bounds__(256) void elbo_terms_fwd_kernel(const float* __rest
 }
 
 extern "C" int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
-                                  int B, int n, int Z, int rot, float phi_prior, float* recon, float* klz,
-                                  float* klrot, void* stream) {
+                                  int B, int n, int Z, int rot, float phi_prior, int recon_kind, float recon_scale,
+                                  float* recon, float* klz, float* klrot, void* stream) {
     if (!x || !xrec || !zmean || !zlogsd || !recon || !klz || (rot && !klrot)) AMX_BADARG(1);
     if (B <= 0 || n <= 0 || Z <= 0 || (rot && phi_prior <= 0.f)) AMX_BADARG(2);
+    if (recon_kind < 0 || recon_kind > 1 || !(recon_scale > 0.f)) AMX_BADARG(3);
     AMX_LAUNCH(elbo_terms_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, xrec, zmean, zlogsd, n, Z,
-               rot, phi_prior, recon, klz, klrot);
+               rot, phi_prior, recon_kind, recon_scale, recon, klz, klrot);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -62,12 +82,18 @@ __global__ __launch_bounds__(256) void elbo_terms_bwd_kernel(const float* __rest
                                                              const float* __restrict__ g_recon,
                                                              const float* __restrict__ g_klz,
                                                              const float* __restrict__ g_klrot, int n, int Z,
-                                                             int rot, float phi_prior, float* __restrict__ dxrec,
+                                                             int rot, float phi_prior, int recon_kind,
+                                                             float recon_scale, float* __restrict__ dxrec,
                                                              float* __restrict__ dmean, float* __restrict__ dlogsd) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float gr = g_recon[b];
-    for (int i = tid; i < n; i += 256)
-        dxrec[(size_t)b * n + i] = gr * (xrec[(size_t)b * n + i] - x[(size_t)b * n + i]);
+    const float gr = recon_kind == 0 ? g_recon[b] : g_recon[b] * recon_scale;
+    if (recon_kind == 0) {
+        for (int i = tid; i < n; i += 256)
+            dxrec[(size_t)b * n + i] = gr * (xrec[(size_t)b * n + i] - x[(size_t)b * n + i]);
+    } else {
+        for (int i = tid; i < n; i += 256)
+            dxrec[(size_t)b * n + i] = gr * elbo_recon_grad(1, xrec[(size_t)b * n + i], x[(size_t)b * n + i]);
+    }
     if (tid < Z) {
         const float ls = zlogsd[(size_t)b * Z + tid], mu = zmean[(size_t)b * Z + tid];
         const float sd2 = expf(2.f * ls);
@@ -81,13 +107,14 @@ __global__ __launch_bounds__(256) void elbo_terms_bwd_kernel(const float* __rest
 
 extern "C" int amx_elbo_terms_bwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
                                   const float* g_recon, const float* g_klz, const float* g_klrot, int B, int n,
-                                  int Z, int rot, float phi_prior, float* dxrec, float* dmean, float* dlogsd,
-                                  void* stream) {
+                                  int Z, int rot, float phi_prior, int recon_kind, float recon_scale, float* dxrec,
+                                  float* dmean, float* dlogsd, void* stream) {
     if (!x || !xrec || !zmean || !zlogsd || !g_recon || !g_klz || !dxrec || !dmean || !dlogsd) AMX_BADARG(1);
     if (rot && !g_klrot) AMX_BADARG(2);
     if (B <= 0 || n <= 0 || Z <= 0 || Z > 256) AMX_BADARG(3);
+    if (recon_kind < 0 || recon_kind > 1 || !(recon_scale > 0.f)) AMX_BADARG(4);
     AMX_LAUNCH(elbo_terms_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, xrec, zmean, zlogsd,
-               g_recon, g_klz, g_klrot, n, Z, rot, phi_prior, dxrec, dmean, dlogsd);
+               g_recon, g_klz, g_klrot, n, Z, rot, phi_prior, recon_kind, recon_scale, dxrec, dmean, dlogsd);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -121,12 +148,19 @@ __global__ __launch_bounds__(256) void elbo_bwd_scalar_kernel(const float* __res
                                                               const float* __restrict__ zmean,
                                                               const float* __restrict__ zlogsd,
                                                               const float* __restrict__ gscalar, float coef, int n, int Z,
-                                                              int rot, float phi_prior, float* __restrict__ dxrec,
+                                                              int rot, float phi_prior, int recon_kind, float recon_scale,
+                                                              float* __restrict__ dxrec,
                                                               float* __restrict__ dmean, float* __restrict__ dlogsd) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const float gr = gscalar[0] * coef;
-    for (int i = tid; i < n; i += 256)
-        dxrec[(size_t)b * n + i] = gr * (xrec[(size_t)b * n + i] - x[(size_t)b * n + i]);
+    if (recon_kind == 0) {
+        for (int i = tid; i < n; i += 256)
+            dxrec[(size_t)b * n + i] = gr * (xrec[(size_t)b * n + i] - x[(size_t)b * n + i]);
+    } else {
+        const float gc = gr * recon_scale;
+        for (int i = tid; i < n; i += 256)
+            dxrec[(size_t)b * n + i] = gc * elbo_recon_grad(1, xrec[(size_t)b * n + i], x[(size_t)b * n + i]);
+    }
     if (tid < Z) {
         const float ls = zlogsd[(size_t)b * Z + tid], mu = zmean[(size_t)b * Z + tid];
         const float sd2 = expf(2.f * ls);
@@ -140,11 +174,13 @@ __global__ __launch_bounds__(256) void elbo_bwd_scalar_kernel(const float* __res
 
 extern "C" int amx_elbo_bwd_scalar(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
                                    const float* gscalar, float coef, int B, int n, int Z, int rot, float phi_prior,
-                                   float* dxrec, float* dmean, float* dlogsd, void* stream) {
+                                   int recon_kind, float recon_scale, float* dxrec, float* dmean, float* dlogsd,
+                                   void* stream) {
     if (!x || !xrec || !zmean || !zlogsd || !gscalar || !dxrec || !dmean || !dlogsd) AMX_BADARG(1);
     if (B <= 0 || n <= 0 || Z <= 0 || Z > 256 || (rot && phi_prior <= 0.f)) AMX_BADARG(2);
+    if (recon_kind < 0 || recon_kind > 1 || !(recon_scale > 0.f)) AMX_BADARG(3);
     AMX_LAUNCH(elbo_bwd_scalar_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, xrec, zmean, zlogsd, gscalar, coef,
-               n, Z, rot, phi_prior, dxrec, dmean, dlogsd);
+               n, Z, rot, phi_prior, recon_kind, recon_scale, dxrec, dmean, dlogsd);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -77,11 +77,76 @@ __global__ __launch_bounds__(256) void px_fwd_kernel(const float* __restrict__ a
     }
 }
 
+// More than MAXCLS classes (the reference's px / CrossEntropyLoss take any count, fcnn.py:115, losses.py:155): the same
+// arithmetic in chunks of MAXCLS classes — a pixel's channels are re-read per chunk (L1 / L2 hits), the per-class FMA
+// chain over the channels is the one of the kernel above, so logits agree bit for bit for any K.  mode 1 writes the
+// logits of a pixel to its NHWC row first and normalises the row in place (the same thread owns it).
+__global__ __launch_bounds__(256) void px_fwd_generic_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ out,
+                                                             long npix, long HW, int C, int Cs, int K, int mode) {
+    const int G = Cs >> 2;
+    const long stride = (long)gridDim.x * 256;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride) {
+        const long n = p / HW, hw = p - n * HW;
+        for (int k0 = 0; k0 < K; k0 += MAXCLS) {
+            const int kc = K - k0 < MAXCLS ? K - k0 : MAXCLS;
+            float acc[MAXCLS];
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) acc[k] = k < kc ? b[k0 + k] : 0.f;
+            for (int cg = 0; cg < G; ++cg) {
+                float4 v = amx_ld4(a + (size_t)p * Cs + cg * 4);
+                if (scale) {
+                    const float4 sc = amx_ld4(scale + cg * 4), sh = amx_ld4(shift + cg * 4);
+                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+                    v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                #pragma unroll
+                for (int k = 0; k < MAXCLS; ++k) {
+                    if (k >= kc) break;
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = cg * 4 + e;
+                        if (c < C) acc[k] = fmaf(vv[e], w[(k0 + k) * C + c], acc[k]);
+                    }
+                }
+            }
+            #pragma unroll
+            for (int k = 0; k < MAXCLS; ++k) {
+                if (k >= kc) break;
+                if (mode == 0) out[((size_t)n * K + k0 + k) * HW + hw] = acc[k];
+                else out[(size_t)p * K + k0 + k] = acc[k];
+            }
+        }
+        if (mode != 0) {                                        // softmax of the row this thread has just written
+            float* row = out + (size_t)p * K;
+            float mx = row[0];
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, row[k]);
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) { const float e = expf(row[k] - mx); row[k] = e; s += e; }
+            for (int k = 0; k < K; ++k) row[k] = row[k] / s;
+        }
+    }
+}
+
 extern "C" int amx_px_fwd(const float* a, const float* scale, const float* shift, const float* w,
                           const float* b, float* out, int N, int H, int W, int C, int Cs, int K, int mode,
                           void* stream) {
     if (!a || !w || !b || !out || (Cs & 3) || C <= 0 || Cs < C || Cs > 256) AMX_BADARG(1);
-    if (K < 1 || K > MAXCLS) AMX_BADARG(2);
+    if (K < 1) AMX_BADARG(2);
+    if (K > MAXCLS) {
+        if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
+        const long npix_g = (long)N * H * W;
+        long nbg = (npix_g + 255) / 256;
+        if (nbg > 16384) nbg = 16384;
+        AMX_LAUNCH(px_fwd_generic_kernel, dim3((unsigned)nbg), dim3(256), 0, (hipStream_t)stream, a, scale, shift, w, b,
+                   out, npix_g, (long)H * W, C, Cs, K, mode);
+        AMX_CHECK_LAUNCH();
+        return 0;
+    }
     if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
     const long npix = (long)N * H * W;
     long nb = (npix + 255) / 256;
@@ -104,7 +169,11 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ w, float* __restrict__ dxn,
                                                      float* __restrict__ part, float* __restrict__ partb,
                                                      float* __restrict__ bstats,
-                                                     long npix, long HW, int C, int Cs, int K, int ppb) {
+                                                     long npix, long HW, int C, int Cs, int K, int ppb,
+                                                     int Kall, int kbase, int accum) {
+    // (K classes kbase .. kbase + K - 1 of Kall: one launch when Kall <= MAXCLS; more classes run as chunks of MAXCLS,
+    //  every chunk after the first adding to the dxn the earlier ones wrote — `accum` — and only the last one, which
+    //  sees the final dxn, forming the BatchNorm-backward sums `bstats`)
     const int G = Cs >> 2, PL = 256 / G;
     const int tid = threadIdx.x;
     const int pl = tid / G, cg = tid - pl * G;
@@ -121,8 +190,9 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
         wk[k] = make_float4(0, 0, 0, 0);
         if (k < K && active) {
             const int c = cg * 4;
-            wk[k].x = c + 0 < C ? w[k * C + c + 0] : 0.f; wk[k].y = c + 1 < C ? w[k * C + c + 1] : 0.f;
-            wk[k].z = c + 2 < C ? w[k * C + c + 2] : 0.f; wk[k].w = c + 3 < C ? w[k * C + c + 3] : 0.f;
+            const float* wr = w + (size_t)(kbase + k) * C;
+            wk[k].x = c + 0 < C ? wr[c + 0] : 0.f; wk[k].y = c + 1 < C ? wr[c + 1] : 0.f;
+            wk[k].z = c + 2 < C ? wr[c + 2] : 0.f; wk[k].w = c + 3 < C ? wr[c + 3] : 0.f;
         }
     }
     const long p0 = (long)blockIdx.x * ppb;
@@ -146,7 +216,7 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
                 const long n = pu / HW, hw = pu - n * HW;
                 av[u] = amx_ld4(a + (size_t)pu * Cs + cg * 4);
                 #pragma unroll
-                for (int k = 0; k < KT; ++k) gv[u][k] = k < K ? dl[((size_t)n * K + k) * HW + hw] : 0.f;
+                for (int k = 0; k < KT; ++k) gv[u][k] = k < K ? dl[((size_t)n * Kall + kbase + k) * HW + hw] : 0.f;
             }
             #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -156,6 +226,7 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
                 v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
                 v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                 float4 d = make_float4(0, 0, 0, 0);
+                if (accum) d = amx_ld4(dxn + (size_t)(p + (long)u * PL) * Cs + cg * 4);
                 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
                     if (k >= K) break;
@@ -187,12 +258,12 @@ __global__ __launch_bounds__(256) void px_bwd_kernel(const float* __restrict__ d
     for (int i = tid; i < K * Cs; i += 256) {
         float acc = 0.f;
         for (int q = 0; q < PL; ++q) acc += s[(size_t)q * K * Cs + i];
-        part[(size_t)blockIdx.x * K * Cs + i] = acc;
+        part[((size_t)blockIdx.x * Kall + kbase) * Cs + i] = acc;
     }
     if (tid < K) {
         float acc = 0.f;
         for (int q = 0; q < PL; ++q) acc += s[(size_t)PL * K * Cs + q * K + tid];
-        partb[(size_t)blockIdx.x * K + tid] = acc;
+        partb[(size_t)blockIdx.x * Kall + kbase + tid] = acc;
     }
     if (bstats) {
         const float* sb = s + (size_t)PL * K * Cs + (size_t)PL * K;
@@ -211,15 +282,26 @@ extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, c
                           int W, int C, int Cs, int K, int rows, int rows_pix, void* stream) {
     if (!dl || !a || !w || !dxn || !part || !partb || (Cs & 3) || C <= 0 || Cs < C || Cs > 256)
         AMX_BADARG(1);
-    if (K < 1 || K > MAXCLS) AMX_BADARG(2);
+    if (K < 1) AMX_BADARG(2);
     if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
     const long npix = (long)N * H * W;
     if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(4);
     const int PL = 256 / (Cs / 4);
+    if (K > MAXCLS) {                                           // chunks of MAXCLS classes (see the kernel's note)
+        for (int k0 = 0; k0 < K; k0 += MAXCLS) {
+            const int kc = K - k0 < MAXCLS ? K - k0 : MAXCLS;
+            const size_t ldc = ((size_t)PL * kc * Cs + (size_t)PL * kc + 4 + (size_t)2 * PL * Cs) * sizeof(float);
+            AMX_LAUNCH(px_bwd_kernel<MAXCLS>, dim3(rows), dim3(256), ldc, (hipStream_t)stream, dl, a, scale, shift, w, dxn,
+                       part, partb, (k0 + kc == K) ? bstats : (float*)nullptr, npix, (long)H * W, C, Cs, kc, rows_pix, K,
+                       k0, k0 > 0 ? 1 : 0);
+            AMX_CHECK_LAUNCH();
+        }
+        return 0;
+    }
     const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K + 4 + (size_t)2 * PL * Cs) * sizeof(float);
 #define PX_BWD_LAUNCH(KT_)                                                                                              \
     AMX_LAUNCH(px_bwd_kernel<KT_>, dim3(rows), dim3(256), lds, (hipStream_t)stream, dl, a, scale, shift, w, dxn, part, \
-               partb, bstats, npix, (long)H * W, C, Cs, K, rows_pix)
+               partb, bstats, npix, (long)H * W, C, Cs, K, rows_pix, K, 0, 0)
     switch (K) {
         case 1: PX_BWD_LAUNCH(1); break;
         case 2: PX_BWD_LAUNCH(2); break;
@@ -280,10 +362,51 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     if (tid == 0) part[blockIdx.x] = red[0];
 }
 
+// More than MAXCLS classes: the logits of a pixel are read three times (max, sum of exponentials, gradient) instead of
+// being kept in registers; same operations in the same order as above.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_generic_kernel(const float* __restrict__ x,
+                                                                 const long long* __restrict__ tgt,
+                                                                 float* __restrict__ dx, float* __restrict__ part,
+                                                                 long npix, long HW, int K, float inv_count) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float lsum = 0.f;
+    for (long p = (long)blockIdx.x * 256 + tid; p < npix; p += (long)gridDim.x * 256) {
+        const long n = p / HW, hw = p - n * HW;
+        const float* xp = x + (size_t)n * K * HW + hw;
+        float mx = -3.4e38f;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, xp[(size_t)k * HW]);
+        const int t = (int)tgt[p];
+        float s = 0.f, xt = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float v = xp[(size_t)k * HW] - mx;
+            if (k == t) xt = v;
+            s += expf(v);
+        }
+        if (dx) {
+            const float inv_s = 1.f / s;
+            for (int k = 0; k < K; ++k) {
+                const float sm = expf(xp[(size_t)k * HW] - mx) * inv_s;
+                dx[(size_t)n * K * HW + (size_t)k * HW + hw] = (sm - (k == t ? 1.f : 0.f)) * inv_count;
+            }
+        }
+        lsum += logf(s) - xt;
+    }
+    red[tid] = lsum; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+
 extern "C" int amx_ce_fwd_bwd(const float* logits, const long long* target, float* dlogits, float* part,
                               int rows, int N, int K, long HW, void* stream) {
-    if (!logits || !target || !part || K < 2 || K > MAXCLS || rows <= 0) AMX_BADARG(1);
+    if (!logits || !target || !part || K < 2 || rows <= 0) AMX_BADARG(1);
     const long npix = (long)N * HW;
+    if (K > MAXCLS) {
+        AMX_LAUNCH(ce_fwd_bwd_generic_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits,
+                   part, npix, HW, K, 1.0f / (float)npix);
+        AMX_CHECK_LAUNCH();
+        return 0;
+    }
     AMX_LAUNCH(ce_fwd_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, target, dlogits,
                part, npix, HW, K, 1.0f / (float)npix);
     AMX_CHECK_LAUNCH();
@@ -346,9 +469,11 @@ extern "C" int amx_scale_unless_one(float* x, const float* g, long n, void* stre
 // atomics: exact and order independent); the host reads N*Kc*Kc integers and finishes the 10-flop Jaccard arithmetic.
 // logits NCHW [N][K][HW]; truth int64 [N][HW] (K > 1) or float [N][HW] (K == 1, binary masks); Kc = max(K, 2);
 // hist int32 [N][Kc][Kc] (zeroed by the caller).  Pixels whose label is outside [0, Kc) are skipped (metrics.py:73).
+// activation: 1 = x holds logits (softmax / sigmoid applied here, metrics.py:37-41), 0 = x holds probabilities already.
 __global__ __launch_bounds__(256) void iou_hist_kernel(const float* __restrict__ x, const long long* __restrict__ ti,
                                                        const float* __restrict__ tf, int* __restrict__ hist,
-                                                       long HW, int K, int Kc, float thresh, int blocks_per_img) {
+                                                       long HW, int K, int Kc, float thresh, int blocks_per_img,
+                                                       int activation) {
     __shared__ int sh[MAXCLS * MAXCLS < 4 ? 4 : MAXCLS * MAXCLS];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / blocks_per_img, b = blockIdx.x - n * blocks_per_img;
@@ -358,16 +483,19 @@ __global__ __launch_bounds__(256) void iou_hist_kernel(const float* __restrict__
         const float* xp = x + (size_t)n * K * HW + hw;
         int pred = 0;
         if (K == 1) {
-            const float p = 1.f / (1.f + expf(-xp[0]));
+            const float p = activation ? 1.f / (1.f + expf(-xp[0])) : xp[0];
             pred = p > thresh ? 1 : 0;
         } else {
             float v[MAXCLS];
             float mx = -3.4e38f;
             #pragma unroll
             for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = xp[(size_t)k * HW]; mx = fmaxf(mx, v[k]); }
-            float s = 0.f;
-            #pragma unroll
-            for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = expf(v[k] - mx); s += v[k]; }
+            float s = 1.f;
+            if (activation) {
+                s = 0.f;
+                #pragma unroll
+                for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; v[k] = expf(v[k] - mx); s += v[k]; }
+            }
             #pragma unroll
             for (int k = 0; k < MAXCLS; ++k) { if (k >= K) break; if (v[k] / s > thresh) pred += k; }
             if (pred > K - 1) pred = 0;                          // squeeze_channels(clip=True), imaug.py:385-386
@@ -380,16 +508,47 @@ __global__ __launch_bounds__(256) void iou_hist_kernel(const float* __restrict__
         if (sh[i]) atomicAdd(&hist[(size_t)n * Kc * Kc + i], sh[i]);
 }
 
+// More than MAXCLS classes: the class scores of a pixel are re-read instead of held in registers, and the K x K counts
+// go to the global histogram directly (integer atomics: still exact).
+__global__ __launch_bounds__(256) void iou_hist_generic_kernel(const float* __restrict__ x, const long long* __restrict__ ti,
+                                                               const float* __restrict__ tf, int* __restrict__ hist,
+                                                               long HW, int K, float thresh, int blocks_per_img,
+                                                               int activation) {
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / blocks_per_img, b = blockIdx.x - n * blocks_per_img;
+    for (long hw = (long)b * 256 + tid; hw < HW; hw += (long)blocks_per_img * 256) {
+        const float* xp = x + (size_t)n * K * HW + hw;
+        float mx = -3.4e38f, s = 1.f;
+        if (activation) {
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, xp[(size_t)k * HW]);
+            s = 0.f;
+            for (int k = 0; k < K; ++k) s += expf(xp[(size_t)k * HW] - mx);
+        }
+        int pred = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = activation ? expf(xp[(size_t)k * HW] - mx) : xp[(size_t)k * HW];
+            if (v / s > thresh) pred += k;
+        }
+        if (pred > K - 1) pred = 0;
+        const long t = ti ? (long)ti[(size_t)n * HW + hw] : (long)tf[(size_t)n * HW + hw];
+        if (t >= 0 && t < K) atomicAdd(&hist[((size_t)n * K + (int)t) * K + pred], 1);
+    }
+}
+
 extern "C" int amx_iou_hist(const float* logits, const long long* truth_i64, const float* truth_f32, int N, int K,
-                            long HW, float thresh, int* hist, void* stream) {
-    if (!logits || !hist || N <= 0 || HW <= 0 || K < 1 || K > MAXCLS) AMX_BADARG(1);
+                            long HW, float thresh, int activation, int* hist, void* stream) {
+    if (!logits || !hist || N <= 0 || HW <= 0 || K < 1) AMX_BADARG(1);
     if ((truth_i64 == nullptr) == (truth_f32 == nullptr)) AMX_BADARG(2);
     const int Kc = K < 2 ? 2 : K;
     long bpi = (HW + 256L * 16 - 1) / (256L * 16);               // ~16 pixels per thread
     if (bpi < 1) bpi = 1;
     if (bpi > 1024) bpi = 1024;
-    AMX_LAUNCH(iou_hist_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, (hipStream_t)stream, logits, truth_i64,
-               truth_f32, hist, HW, K, Kc, thresh, (int)bpi);
+    if (K > MAXCLS)
+        AMX_LAUNCH(iou_hist_generic_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, (hipStream_t)stream, logits,
+                   truth_i64, truth_f32, hist, HW, K, thresh, (int)bpi, activation ? 1 : 0);
+    else
+        AMX_LAUNCH(iou_hist_kernel, dim3((unsigned)(N * bpi)), dim3(256), 0, (hipStream_t)stream, logits, truth_i64,
+                   truth_f32, hist, HW, K, Kc, thresh, (int)bpi, activation ? 1 : 0);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -16,14 +16,8 @@ class IoU:
     """Mean intersection over union of (labels, thresholded predictions)."""
 
     def __init__(self, true: torch.Tensor, pred: torch.Tensor, activation: bool = True, thresh: float = 0.5):
-        if not activation:
-            raise NotImplementedError("IoU(activation=False) (probabilities in, as `pred`) is not on the device "
-                                      "path: the trainers always pass logits (trainers/trainer.py:727-737)")
         if pred.ndim != 4:
             raise AssertionError("expected predictions of shape (N, K, H, W)")
-        if pred.shape[1] > 8:
-            raise NotImplementedError(f"IoU on the device supports up to 8 classes (got {pred.shape[1]}): the per-frame "
-                                      "confusion histogram of amx_iou_hist is K x K <= 8 x 8, like the CE loss kernel")
         self.thresh = thresh
         N, K = pred.shape[0], pred.shape[1]
         HW = pred.shape[2] * pred.shape[3]
@@ -38,8 +32,9 @@ class IoU:
         else:
             ti = true.long().contiguous()
         self.hist = torch.zeros((N, self.nb_classes, self.nb_classes), dtype=torch.int32, device=x.device)
-        L.call("amx_iou_hist", L.ptr(x), L.ptr(ti), L.ptr(tf), N, K, HW, float(thresh), L.ptr(self.hist),
-               L.stream_ptr(x))
+        # activation=False: `pred` already holds probabilities (metrics.py:37-41 skipped); any number of classes
+        L.call("amx_iou_hist", L.ptr(x), L.ptr(ti), L.ptr(tf), N, K, HW, float(thresh), int(bool(activation)),
+               L.ptr(self.hist), L.stream_ptr(x))
 
     def evaluate(self) -> float:
         """Mean Jaccard index over the classes (metrics.py:80-95), in float32 like the reference: the per-frame count

@@ -104,6 +104,9 @@ class rVAE(BaseVAE):
                 self.kdict_[k] = v
         self.compile_trainer((X_train, y_train), (X_test, y_test), **kwargs)
         self.loss = loss
+        if self.loss == "ce":                                 # decode() then applies a sigmoid ("prediction" stage)
+            self.sigmoid_out = True
+            self.metadict["sigmoid_out"] = True
         if kwargs.get("recording", False):
             raise NotImplementedError("manifold recording (matplotlib/torchvision tooling) is out of scope")
         self._fit_loop()

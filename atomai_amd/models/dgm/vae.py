@@ -210,4 +210,7 @@ class VAE(BaseVAE):
                 self.kdict_[k] = v
         self.compile_trainer((X_train, y_train), (X_test, y_test), **kwargs)
         self.loss = loss
+        if self.loss == "ce":                                 # decode() then applies a sigmoid ("prediction" stage)
+            self.sigmoid_out = True
+            self.metadict["sigmoid_out"] = True
         self._fit_loop()

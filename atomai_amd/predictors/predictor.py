@@ -17,7 +17,7 @@ import torch
 from ..nets.fcnn import _HipNet, predict_proba
 from .locator import Locator, locate_device
 from .. import _lib as L
-from ..utils import get_downsample_factor, get_nb_classes, img_pad, set_train_rng, torch_format_image
+from ..utils import get_downsample_factor, get_nb_classes, img_pad, img_resize, set_train_rng, torch_format_image
 
 
 class BasePredictor:
@@ -139,7 +139,7 @@ class SegPredictor(BasePredictor):
             elif image_data.shape[1] == 1:
                 image_data = image_data[:, 0, ...]
         if self.resize is not None:
-            raise NotImplementedError("resize needs cv2 (outside the MI355X hot path of this build)")
+            image_data = img_resize(image_data, self.resize)  # predictor.py:203-204 (cv2.resize restated on the device)
         image_data = img_pad(image_data, self.downsampling)
         self._norm = None
         on_device = str(self.device).startswith("cuda") or L.is_test_backend()

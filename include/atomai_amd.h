@@ -251,9 +251,11 @@ int amx_scale_unless_one(float* x, const float* g, long n, void* stream);
  * confusion counts of (label, thresholded softmax / sigmoid class map) in one pass over the NCHW logits, replacing the
  * reference's host round trip (cv2.threshold per image + squeeze_channels + torch.bincount).  Exactly one of truth_i64
  * ([N][HW] class maps, K > 1) / truth_f32 ([N][HW] binary masks, K == 1) is non-NULL; hist is int32
- * [N][Kc][Kc], Kc = max(K, 2), zeroed by the caller. */
+ * [N][Kc][Kc], Kc = max(K, 2), zeroed by the caller.  activation 1: `logits` are logits (softmax / sigmoid applied
+ * here, metrics.py:37-41); 0: they are probabilities already (IoU(..., activation=False)).  Any class count (more than
+ * 8 classes re-read a pixel's scores instead of holding them in registers). */
 int amx_iou_hist(const float* logits, const long long* truth_i64, const float* truth_f32, int N, int K, long HW,
-                 float thresh, int* hist, void* stream);
+                 float thresh, int activation, int* hist, void* stream);
 
 /* ---- training-mode nn.Dropout of ConvBlock (Conv2d -> Dropout(p) -> LeakyReLU -> BatchNorm2d, atomai/nets/blocks.py:
  * 59-76): applied AFTER the fused conv + LeakyReLU (LeakyReLU is positively homogeneous, the mask multiplier is >= 0).
@@ -287,7 +289,9 @@ int amx_aug_labels(const long long* t, long long* out, const float* params, int*
                    void* stream);
 /* apply_zoom / apply_imresize (transforms/imaug.py:195-227, 276-300): cv2.resize of a per-image source window win[n] =
  * (y0, x0, h, w) of the [Hs][Ws] frame to [Hd][Wd]; mode 0 = INTER_LINEAR (what apply_imresize executes: its method
- * argument lands in cv2.resize's `dst` slot), 1 = INTER_CUBIC (a = -0.75; apply_zoom).  clip01: np.clip(img, 0, 1);
+ * argument lands in cv2.resize's `dst` slot), 1 = INTER_CUBIC (a = -0.75; apply_zoom and the shrinking branch of
+ * utils/img.py:cv_resize), 2 = INTER_AREA in its enlarging form (linear kernel with area-mode coefficients: the other
+ * branch of cv_resize, predictors/predictor.py:203-204).  clip01: np.clip(img, 0, 1);
  * round_out: np.around (masks).  int64 class maps travel as the reference moves them: amx_aug_onehot expands them to K
  * float planes ([N][K][HW], unsqueeze_channels imaug.py:396-403), the planes are resampled like images with round_out,
  * amx_aug_squeeze forms label = sum_c c * mask_c (squeeze_channels, imaug.py:361-393) and values[n] |= 1 << label (caller
@@ -345,19 +349,24 @@ int amx_rdecoder_bwd_saved(const float* coords, const float* theta, const float*
                            float* dz, float* pW, float* pb, float* pWo, float* pbo, float* pWc, float* pbc, float* pWz,
                            int B, int n, int L, int hid, int NL, int skip, int C, void* stream);
 
-/* ---- ELBO terms of vae_loss / rvae_loss with 'mse' (atomai/losses_metrics/vi_losses.py:13-137), fwd and bwd */
+/* ---- ELBO terms of vae_loss / rvae_loss (atomai/losses_metrics/vi_losses.py:13-137), fwd and bwd.
+ * recon_kind 0 = 'mse' (0.5 * sum (xrec - x)^2, vi_losses.py:23-26; recon_scale unused), 1 = 'ce' (sum of
+ * binary_cross_entropy_with_logits(xrec, x), vi_losses.py:27-34) times recon_scale: 1 for a 2-D in_dim, 1 / (H*W) for a
+ * 3-D one, where the reference sums over the channels only and its .mean() runs over samples x pixels. */
 int amx_elbo_terms_fwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd, int B, int n,
-                       int Z, int rot, float phi_prior, float* recon, float* klz, float* klrot, void* stream);
+                       int Z, int rot, float phi_prior, int recon_kind, float recon_scale, float* recon, float* klz,
+                       float* klrot, void* stream);
 int amx_elbo_terms_bwd(const float* x, const float* xrec, const float* zmean, const float* zlogsd,
                        const float* g_recon, const float* g_klz, const float* g_klrot, int B, int n, int Z,
-                       int rot, float phi_prior, float* dxrec, float* dmean, float* dlogsd, void* stream);
+                       int rot, float phi_prior, int recon_kind, float recon_scale, float* dxrec, float* dmean,
+                       float* dlogsd, void* stream);
 /* Scalar ELBO without a capacity term (vi_losses.py:105-108, 129-137): out[0] = -mean(recon) - mean(klz) - mean(klrot)
  * (klrot may be NULL), fixed-order fp64 sum; amx_elbo_bwd_scalar = amx_elbo_terms_bwd with all three per-sample upstream
  * gradients equal to coef * gscalar[0] (gscalar: the device scalar autograd hands to the loss; coef = -1 / B). */
 int amx_elbo_combine(const float* recon, const float* klz, const float* klrot, int B, float* out, void* stream);
 int amx_elbo_bwd_scalar(const float* x, const float* xrec, const float* zmean, const float* zlogsd, const float* gscalar,
-                        float coef, int B, int n, int Z, int rot, float phi_prior, float* dxrec, float* dmean,
-                        float* dlogsd, void* stream);
+                        float coef, int B, int n, int Z, int rot, float phi_prior, int recon_kind, float recon_scale,
+                        float* dxrec, float* dmean, float* dlogsd, void* stream);
 /* rVAE latent plumbing (models/dgm/rvae.py:118-137) in one pass each way: z = mean + exp(logsd) * eps; theta [B][3] =
  * (z0, z1 * dx_prior, z2 * dx_prior) (translation) or (z0, 0, 0); zc [B][Z - 3 | Z - 1] = the content latents. */
 int amx_rvae_latent_fwd(const float* zmean, const float* zlogsd, const float* eps, int B, int Z, int translation,

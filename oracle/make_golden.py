@@ -641,6 +641,22 @@ def make_iou(aoi):
         out[f"{name}|iou"] = np.array(rm.IoU(torch.from_numpy(true), torch.from_numpy(logits), True, thr).evaluate())
         print("iou", name, out[f"{name}|iou"])
     np.savez_compressed(os.path.join(GOLD, "iou.npz"), **out)
+    # round 5: more than 8 classes, and activation=False (probabilities handed in, metrics.py:37-41 skipped)
+    out = {}
+    for name, (N, K, H, W, thr, scale, act) in {"c9": (2, 9, 16, 20, 0.5, 4.0, True), "c12_t02": (2, 12, 16, 16, 0.2, 3.0, True),
+                                                "c3_noact": (3, 3, 20, 24, 0.5, 2.0, False),
+                                                "c1_noact": (2, 1, 17, 19, 0.6, 1.5, False),
+                                                "c10_noact": (2, 10, 12, 12, 0.3, 3.0, False)}.items():
+        logits = (scale * rs.randn(N, K, H, W)).astype(np.float32)
+        pred = logits if act else (torch.softmax(torch.from_numpy(logits), 1).numpy() if K > 1
+                                   else torch.sigmoid(torch.from_numpy(logits)).numpy())
+        true = ((rs.rand(N, 1, H, W) > 0.5).astype(np.float32) if K == 1
+                else rs.randint(0, K, (N, H, W)).astype(np.int64))
+        out[f"{name}|pred"], out[f"{name}|true"] = pred, true
+        out[f"{name}|cfg"] = np.array([K, thr, int(act)])
+        out[f"{name}|iou"] = np.array(rm.IoU(torch.from_numpy(true), torch.from_numpy(pred), act, thr).evaluate())
+        print("iou", name, out[f"{name}|iou"])
+    np.savez_compressed(os.path.join(GOLD, "iou_wide.npz"), **out)
 
 
 def make_augment_geom(aoi):

@@ -187,6 +187,36 @@ def check_custom_transform(device):
     assert aug is not None
 
 
+def check_img_resize(device):
+    """utils.img_resize / SegPredictor(resize=...) (reference utils/img.py:20-68, predictors/predictor.py:203-204) on
+    amx_aug_resample against the numpy restatement oracle/aug_oracle.py:img_resize (both UNPINNED against cv2 itself):
+    enlarging (INTER_AREA, mode 2), shrinking (INTER_CUBIC), the swapped non-square target, rounding, same-shape copy."""
+    from oracle import aug_oracle as ao
+    import atomai_amd as aoi
+    from atomai_amd.utils import img_resize
+    rs = np.random.RandomState(5)
+    st = rs.rand(3, 20, 20).astype(np.float32)
+    for target in ((32, 32), (40, 40), (27, 27), (12, 12), (16, 24)):
+        got = img_resize(st, target)
+        ref = ao.img_resize(st.astype(np.float64), target)
+        assert got.shape == ref.shape and got.dtype == np.float64, target
+        assert np.abs(got - ref).max() < 5e-6, (target, np.abs(got - ref).max())
+    assert np.array_equal(img_resize(st, (40, 40))[:, ::2, ::2], st.astype(np.float64))   # x2 INTER_AREA replicates
+    same = img_resize(st, (20, 20))
+    assert np.array_equal(same, st) and same is not st
+    lab = img_resize((st > 0.5).astype(np.float32), (28, 28), round_=True)
+    assert np.array_equal(lab, ao.img_resize((st > 0.5).astype(np.float64), (28, 28), round_=True))
+    # the predictor resizes before padding / normalising (predictor.py:203-206): outputs come back at the new size
+    torch.manual_seed(0)
+    net, _ = aoi.nets.init_fcnn_model("Unet", 3, nb_filters=4)
+    p = aoi.predictors.SegPredictor(net, resize=(32, 32), use_gpu=(device != "cpu"), verbose=False)
+    out = p.predict(st, compute_coords=False)
+    assert out.shape == (3, 32, 32, 3)
+    p0 = aoi.predictors.SegPredictor(net, use_gpu=(device != "cpu"), verbose=False)
+    ref = p0.predict(img_resize(st, (32, 32)).astype(np.float32), compute_coords=False)
+    assert np.abs(out - ref).max() < 1e-6
+
+
 def check_augment_geometry_golden(device):
     """rotation -> zoom -> resize against tests/golden/augment_geom.npz: the reference's own seg_augmentor / datatransform
     code run over the documented cv2 semantics (oracle/make_golden.py augment_geom).  Same seed -> the reference's zoom

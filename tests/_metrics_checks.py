@@ -22,6 +22,21 @@ def check_iou_golden(device):
         assert abs(got - float(g[f"{name}|iou"])) < 1e-6, (name, got, float(g[f"{name}|iou"]))
 
 
+def check_iou_wide_golden(device):
+    """IoU vs tests/golden/iou_wide.npz (the reference's IoU.evaluate): more than 8 classes (the scores of a pixel are
+    re-read instead of held in registers) and activation=False (probabilities in)."""
+    from atomai_amd.losses_metrics import IoU
+    g = np.load(os.path.join(GOLD, "iou_wide.npz"))
+    names = sorted({k.split("|")[0] for k in g.files})
+    assert len(names) == 5
+    for name in names:
+        K, thr, act = g[f"{name}|cfg"]
+        pred = torch.from_numpy(g[f"{name}|pred"]).to(device)
+        true = torch.from_numpy(g[f"{name}|true"]).to(device)
+        got = IoU(true, pred, bool(act), float(thr)).evaluate()
+        assert abs(got - float(g[f"{name}|iou"])) < 1e-6, (name, got, float(g[f"{name}|iou"]))
+
+
 def check_fit_with_accuracy(device_is_gpu, tmp_path):
     """Segmentor.fit(compute_accuracy=True): the IoU of every train / test mini-batch is recorded as the reference does
     (trainer.py:163-172) and equals a host evaluation of the reference's formula on the same logits."""

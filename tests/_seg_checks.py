@@ -22,6 +22,9 @@ CASES = {
     "seg_reshednet_c3_nf4_b2_32": ("ResHedNet", dict(layers=[2, 2, 2])),
     "seg_reshednet_c3_nf4_b2_22": ("ResHedNet", dict(layers=[1, 1, 1])),
     "seg_reshednet_c1_nf4_b2_22_nearest": ("ResHedNet", dict(upsampling="nearest", layers=[1, 2, 1])),
+    # more classes than the register-resident head kernels hold (8): chunked px / re-reading CE kernels (head.hip)
+    "seg_unet_c9_nf4_b2_32": ("Unet", dict()),
+    "seg_dilnet_c11_nf5_b2_32": ("dilnet", dict()),
 }
 REL_TOL = 1e-4          # north_star: "within 1e-4 rel fp32"
 
@@ -82,6 +85,27 @@ def check_net_case(name, device):
         ev = net(x).cpu().numpy()
     ref = g["eval_logits|f32"]
     assert relmax(ev, ref.astype(np.float64)) < 2e-2        # parameters after Adam steps: loose
+
+
+def check_many_classes_predict(device, ncls=11):
+    """predict path with more than 8 classes: amx_px_fwd mode 1 (probabilities, NHWC) on the chunked kernel against the
+    softmax of the module's own logits; SegPredictor end to end (shape, rows sum to one)."""
+    import atomai_amd as aoi
+    from atomai_amd.nets import init_fcnn_model
+    from atomai_amd.nets.fcnn import predict_proba
+    torch.manual_seed(3)
+    net, _ = init_fcnn_model("Unet", ncls, nb_filters=4)
+    net = net.to(device).eval()
+    x = torch.rand(2, 1, 32, 32, device=device)
+    with torch.no_grad():
+        logits = net(x)
+    prob = predict_proba(net, x)
+    assert tuple(prob.shape) == (2, 32, 32, ncls)
+    ref = torch.softmax(logits.double(), 1).permute(0, 2, 3, 1)
+    assert float((prob.double() - ref).abs().max()) < 1e-6
+    out = aoi.predictors.SegPredictor(net, use_gpu=(device != "cpu"), verbose=False).predict(
+        x[:, 0].cpu().numpy(), compute_coords=False)
+    assert out.shape == (2, 32, 32, ncls) and np.allclose(out.sum(-1), 1.0, atol=1e-5)
 
 
 def check_vs_oracle_small(model, ncls, device, nf=4, B=2, H=16, seed=5, **kw):

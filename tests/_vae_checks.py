@@ -25,6 +25,16 @@ CASES = {
     # 3-channel patches, 4 hidden layers of 64 units in the spatial decoder
     "rvae12_rgb": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=64, numlayers_decoder=4),
                        fit=dict(), file="vae_cond.npz", in_dim=(12, 12, 3)),
+    # reconstruction loss 'ce' (vi_losses.py:27-34): per-sample sums for 2-D patches, the reference's channel-sum /
+    # pixel-mean quirk for 3-D ones, and the capacity form (per-sample term vectors instead of the fused scalar)
+    "rvae16_ce": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32), fit=dict(), loss="ce",
+                      file="vae_ce.npz"),
+    "vae16_ce": dict(cls="VAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32), fit=dict(), loss="ce",
+                     file="vae_ce.npz"),
+    "rvae12_rgb_ce": dict(cls="rVAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32), fit=dict(), loss="ce",
+                          file="vae_ce.npz", in_dim=(12, 12, 3)),
+    "vae16_ce_cap": dict(cls="VAE", ctor=dict(numhidden_encoder=32, numhidden_decoder=32),
+                         fit=dict(capacity=[5.0, 100, 2.0]), loss="ce", file="vae_ce.npz"),
 }
 
 
@@ -46,6 +56,7 @@ def check_vae_case(name, device):
     if "capacity" in c["fit"]:
         m.kdict_["capacity"] = c["fit"]["capacity"]
     y = g[f"{name}|y"] if f"{name}|y" in g.files else None
+    m.loss = c.get("loss", "mse")                            # what fit(loss=...) sets (rvae.py:196, vae.py:729)
     m.compile_trainer((x, y), None, batch_size=x.shape[0])
     yt = None if y is None else torch.from_numpy(y).long().to(device)
     state = {"i": 0}

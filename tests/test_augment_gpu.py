@@ -25,3 +25,11 @@ def test_class_drop_and_trainer_hook():
 
 def test_zoom_and_resize_vs_reference_golden():
     A.check_augment_geometry_golden("cuda")
+
+
+def test_img_resize_and_predictor_resize():
+    A.check_img_resize("cuda")
+
+
+def test_custom_transform_host_callable():
+    A.check_custom_transform("cuda")

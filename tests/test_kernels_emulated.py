@@ -197,6 +197,16 @@ def test_iou_vs_reference_golden():
     M.check_iou_golden("cpu")
 
 
+def test_iou_many_classes_and_probabilities_in():
+    import _metrics_checks as M
+    M.check_iou_wide_golden("cpu")
+
+
+def test_predict_with_more_than_eight_classes():
+    import _seg_checks as C
+    C.check_many_classes_predict("cpu")
+
+
 def test_fit_with_compute_accuracy(tmp_path):
     import _metrics_checks as M
     M.check_fit_with_accuracy(False, tmp_path)

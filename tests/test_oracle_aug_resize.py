@@ -42,3 +42,43 @@ def test_candidate_sizes_follow_the_reference_formulas():
     assert list(ao.zoom_values(48, 80, 2)) == [24, 32, 40, 48]
     rh, rw = ao.resize_sizes(64, 64, [2, 1.5])
     assert rh[0] == 32 and rh[-1] < 96 and np.array_equal(rh, rw) and len(rh) == 9       # s = 0.125: 8 / 64
+
+
+def test_inter_area_enlarging_form_known_values():
+    """cv2.INTER_AREA with an ENLARGED axis (what utils/img.py:cv_resize picks for small frames, predictor.py:203-204):
+    OpenCV's linear kernel with area-mode coefficients = the overlap of an output pixel's footprint with the source
+    pixels.  Integer factors replicate pixels (OpenCV's documented "similar to INTER_NEAREST" when zooming); 2 -> 3
+    pixels gives (a, (a + b) / 2, b)."""
+    row = np.array([[1.0, 5.0, 2.0]])
+    up2 = ao.cv_resize(row, (1, 6), "area_up")
+    np.testing.assert_allclose(up2[0], [1, 1, 5, 5, 2, 2], atol=0)
+    up = ao.cv_resize(np.array([[2.0, 4.0]]), (1, 3), "area_up")
+    np.testing.assert_allclose(up[0], [2.0, 3.0, 4.0], atol=1e-7)
+    # footprint overlap in general: dst pixel d covers [d, d + 1) * src / dst of the source axis (<= 2 source pixels)
+    rs = np.random.RandomState(0)
+    src = rs.rand(1, 7)
+    dst_n = 10
+    got = ao.cv_resize(src, (1, dst_n), "area_up")[0]
+    ref = np.zeros(dst_n)
+    for d in range(dst_n):
+        lo, hi = d * 7 / dst_n, (d + 1) * 7 / dst_n
+        for s_ in range(7):
+            ref[d] += max(0.0, min(hi, s_ + 1) - max(lo, s_)) / (hi - lo) * src[0, s_]
+    np.testing.assert_allclose(got, ref, atol=2e-6)
+
+
+def test_img_resize_quirks_of_the_reference():
+    """utils/img.py:20-68: unequal target entries are swapped; same shape -> copy; INTER_AREA below the target size,
+    INTER_CUBIC above it; float64 stack out."""
+    rs = np.random.RandomState(1)
+    st = rs.rand(3, 16, 16)
+    same = ao.img_resize(st, (16, 16))
+    assert np.array_equal(same, st) and same is not st
+    up = ao.img_resize(st, (32, 32))
+    assert up.shape == (3, 32, 32) and up.dtype == np.float64
+    np.testing.assert_allclose(up[:, ::2, ::2], st, atol=0)              # x2 under INTER_AREA replicates pixels
+    down = ao.img_resize(st, (8, 8))
+    np.testing.assert_allclose(down[1], ao.cv_resize(st[1], (8, 8), "cubic"), atol=0)
+    assert ao.img_resize(rs.rand(2, 8, 8), (16, 24)).shape == (2, 24, 16)  # (16, 24) is swapped to (24, 16)
+    lab = ao.img_resize((st > 0.5).astype(float), (24, 24), round_=True)
+    assert set(np.unique(lab)) <= {0.0, 1.0}

@@ -190,9 +190,13 @@ def test_determinism_and_loss_decrease_at_full_size():
 
 
 def test_kernel_level_large_shapes():
-    """wgrad / dgrad kernels at config-2 layer shapes against torch's conv backward on the same device."""
+    """wgrad / dgrad kernels at config-2 layer shapes against torch's conv -> LeakyReLU -> BatchNorm backward on the same
+    device, in the kink-aware form of the full-size net tests (this test used a relative-L2 bound of
+    1e-3).  Reference = the torch graph in fp64; floor = the same graph in fp32 against it; sens = the fp64 gradient
+    change when every LeakyReLU input within 1e-5 of 0 takes the other branch (what two correct fp32 implementations may
+    legitimately disagree on).  Per tensor, max-abs normalised by that tensor's largest entry:
+    err < 1e-4 + sens + 2 x floor.  Measured: profiles/r05_fullsize_parity_probe.log (the printed lines)."""
     import torch.nn.functional as F
-    from atomai_amd import engine
     from atomai_amd.engine import Tape
     import torch.nn as nn
     torch.manual_seed(0)
@@ -207,18 +211,41 @@ def test_kernel_level_large_shapes():
         gy = torch.randn_like(o.value)
         o.grad_out = gy
         tape.backward()
-        xr = [x.detach().clone().requires_grad_(True) for x in xs]
-        ref = F.batch_norm(F.leaky_relu(F.conv2d(torch.cat(xr, 1), conv.weight, conv.bias, padding=1), 0.01),
-                           None, None, bn.weight, bn.bias, True)
-        assert C.relmax(o.value.cpu().numpy(), ref.detach().cpu().double().numpy()) < C.REL_TOL
-        grads = torch.autograd.grad(ref, xr + [conv.weight, conv.bias, bn.weight, bn.bias], gy)
         got = [n.grad_nchw for n in ins] + [tape.param_grads[id(p)][1] for p in
                                             (conv.weight, conv.bias, bn.weight, bn.bias)]
-        for a, b in zip(got, grads):
-            # relative L2: both sides are fp32, and an element whose pre-activation rounds to the other side
-            # of the LeakyReLU kink changes single entries by O(1%) in either implementation
-            rel = float((a.view_as(b) - b).norm() / b.norm())
-            assert rel < 1e-3, (B, H, C0, C1, Co, a.shape, rel)
+        names = [f"dx{i}" for i in range(len(xs))] + ["dW", "db", "dgamma", "dbeta"]
+
+        def torch_graph(dtype, flip=None):
+            xr = [x.detach().to(dtype).requires_grad_(True) for x in xs]
+            ps = [p.detach().to(dtype).requires_grad_(True) for p in (conv.weight, conv.bias, bn.weight, bn.bias)]
+            pre = F.conv2d(torch.cat(xr, 1), ps[0], ps[1], padding=1)
+            nk = 0
+            if flip is None:
+                act = F.leaky_relu(pre, 0.01)
+            else:
+                near = pre.detach().abs() < flip
+                nk = int(near.sum())
+                neg = (pre.detach() < 0) ^ near
+                act = torch.where(neg, 0.01 * pre, pre)
+            y = F.batch_norm(act, None, None, ps[2], ps[3], True)
+            return y.detach(), torch.autograd.grad(y, xr + ps, gy.to(dtype)), nk
+        y64, g64, _ = torch_graph(torch.float64)
+        y32, g32, _ = torch_graph(torch.float32)
+        _, gflip, nkink = torch_graph(torch.float64, flip=1e-5)
+        yfloor = C.relmax(y32.cpu().double().numpy(), y64.cpu().numpy())
+        assert C.relmax(o.value.cpu().double().numpy(), y64.cpu().numpy()) < max(C.REL_TOL, 2 * yfloor)
+        report = []
+        for nm, a, r64, r32, rf in zip(names, got, g64, g32, gflip):
+            sc = float(r64.abs().max())
+            err = float((a.view_as(r64).double() - r64).abs().max()) / sc
+            floor = float((r32.double() - r64).abs().max()) / sc
+            sens = float((rf - r64).abs().max()) / sc
+            bound = C.REL_TOL + sens + 2 * floor
+            report.append((err / bound, nm, err, floor, sens))
+            assert err < bound, (B, H, C0, C1, Co, nm, err, floor, sens, nkink)
+        worst = max(report)
+        print(f"conv block {C0}+{C1}->{Co} @ {H}^2 x {B}: {nkink} LeakyReLU inputs within 1e-5 of 0; worst {worst[1]} error "
+              f"{worst[2]:.2e} (torch-fp32 floor {worst[3]:.2e}, kink sensitivity {worst[4]:.2e})")
 
 
 def test_config3_dilnet_predict_full_size_vs_oracle_on_device():
@@ -307,6 +334,15 @@ def test_dilated_block_sum_in_the_last_conv_epilogue():
 def test_iou_vs_reference_golden():
     import _metrics_checks as M
     M.check_iou_golden("cuda")
+
+
+def test_iou_many_classes_and_probabilities_in():
+    import _metrics_checks as M
+    M.check_iou_wide_golden("cuda")
+
+
+def test_predict_with_more_than_eight_classes():
+    C.check_many_classes_predict("cuda")
 
 
 def test_fit_with_compute_accuracy(tmp_path):

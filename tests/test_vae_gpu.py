@@ -26,7 +26,12 @@ def test_rdecoder_shapes(hid, nl, skip, hw):
 @pytest.mark.parametrize("B", [128, 512])
 def test_rvae_config4_vs_oracle_on_device(B):
     """BASELINE.json configs[3] shape (rVAE latent_dim=2, 64x64 windows, default 128-wide nets) at bs=128 and at the
-    FULL bs=512: ELBO and every gradient against the oracle graph executed with stock torch ops on the same GPU."""
+    FULL bs=512, with the treatment config 2 got in round 4: the oracle graph (stock torch ops on the
+    same GPU) is run in fp64 = the reference, and once more in fp32 = the floor two correct fp32 implementations may
+    differ by.  Asserted: ELBO within 1e-5 of the fp64 value; every gradient within max(1e-4, 2 x floor) of the fp64
+    gradient, errors normalised by the largest gradient entry of the whole model (no kinks on this path: tanh).
+    The kernel's 5-instruction rd_tanh (rdecoder.hip, abs err <= 2e-7) is inside this budget, and a regression of it
+    would not be.  Measured on the MI355X: see profiles/r05_fullsize_parity_probe.log (this test's printed line)."""
     import atomai_amd as aoi
     from oracle import vae_oracle as vo
     m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
@@ -38,15 +43,34 @@ def test_rvae_config4_vs_oracle_on_device(B):
     m.encoder_net.train(), m.decoder_net.train()
     elbo = m.forward_compute_elbo(x)
     (-elbo).backward()
-    enc = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in m.encoder_net.state_dict().items())
-    dec = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in m.decoder_net.state_dict().items())
-    ref = vo.rvae_forward_elbo(enc, dec, x, eps, m.x_coord, True, 0.1, 0.1, False, None, 1)
-    (-ref).backward()
-    assert abs(elbo.item() - ref.item()) / abs(ref.item()) < V.REL_TOL
-    for net, sd in ((m.encoder_net, enc), (m.decoder_net, dec)):
+
+    def oracle(dtype):
+        enc = OrderedDict((k, v.detach().to(dtype).requires_grad_(True)) for k, v in m.encoder_net.state_dict().items())
+        dec = OrderedDict((k, v.detach().to(dtype).requires_grad_(True)) for k, v in m.decoder_net.state_dict().items())
+        ref = vo.rvae_forward_elbo(enc, dec, x.to(dtype), eps.to(dtype), m.x_coord.to(dtype), True, 0.1, 0.1, False, None, 1)
+        (-ref).backward()
+        grads = {("enc", k): v.grad.double() for k, v in enc.items()}
+        grads.update({("dec", k): v.grad.double() for k, v in dec.items()})
+        return float(ref), grads
+    e64, g64 = oracle(torch.float64)
+    e32, g32 = oracle(torch.float32)
+    torch.cuda.empty_cache()
+    assert abs(elbo.item() - e64) / abs(e64) < 1e-5, (elbo.item(), e64, e32)
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    report = []
+    for which, net in (("enc", m.encoder_net), ("dec", m.decoder_net)):
         for k, p in net.named_parameters():
-            r = sd[k].grad
-            assert float((p.grad - r).abs().max() / r.abs().max()) < 5e-4, k
+            ref = g64[(which, k)]
+            err = float((p.grad.double() - ref).abs().max()) / gmax
+            floor = float((g32[(which, k)] - ref).abs().max()) / gmax
+            bound = max(V.REL_TOL, 2 * floor)
+            report.append((err / bound, f"{which}.{k}", err, floor))
+            assert err < bound, (which, k, err, floor)
+    worst = max(report)
+    wfloor = max(r[3] for r in report)
+    print(f"rVAE config 4, bs {B}: ELBO rel. error {abs(elbo.item() - e64) / abs(e64):.2e} (oracle fp32: "
+          f"{abs(e32 - e64) / abs(e64):.2e}); worst gradient error {worst[2]:.2e} of the global scale ({worst[1]}; oracle-fp32 "
+          f"floor of that tensor {worst[3]:.2e}, largest floor {wfloor:.2e})")
 
 
 def test_rvae_fit_loss_improves_and_is_deterministic(tmp_path):
