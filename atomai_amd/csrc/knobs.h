@@ -12,7 +12,6 @@ struct AmxKnobs {
     int conv_nt;          // AMX_CONV_NT         0: plan_conv's choice; 1|2|4: cout tiles of 16 per workgroup
     int conv_th;          // AMX_CONV_TH         0: plan_conv's choice; 8|16: tile rows
     int conv_rem;         // AMX_CONV_REM        1: 28 / 52 stored channels as 16+3x4 / 3x16+4 columns; 0: padded 32 / 2x32
-    int conv_rem_head;    // AMX_CONV_REM_HEAD   remainder-column plan for the head-fused last layer (see conv_fwd.hip)
     int conv_xcd;         // AMX_CONV_XCD        0 off, 1 all, 2 launches with > 1 cout block, 3 dilated launches only
     int bwd_fuse;         // AMX_BWD_FUSE        1: BatchNorm / LeakyReLU backward inside the consumers' loaders
     int conv_ws;          // AMX_CONV_WS         0 off, 1 default classes, 2 forward only, 3 data gradients only
@@ -25,7 +24,6 @@ struct AmxKnobs {
     int gemm_tile;        // AMX_GEMM_TILE       0: by workgroup count; 32|64
     int rdec_fwd_mt;      // AMX_RDEC_FWD_MT     pixels per tile of the 128-unit rDecoder forward kernel (64|128)
     int rdec_bwd_mt;      // AMX_RDEC_BWD_MT     pixels per tile of the 128-unit rDecoder backward kernel (64|32)
-    int rdec_ws;          // AMX_RDEC_WS         rDecoder backward tile schedule (see rdecoder.hip)
 };
 
 // The frozen plan switches (first call resolves them; lock-free afterwards).

@@ -15,7 +15,6 @@ const KnobRow kRows[] = {
     {"AMX_CONV_NT", &AmxKnobs::conv_nt, 0},
     {"AMX_CONV_TH", &AmxKnobs::conv_th, 0},
     {"AMX_CONV_REM", &AmxKnobs::conv_rem, 1},
-    {"AMX_CONV_REM_HEAD", &AmxKnobs::conv_rem_head, 0},
     {"AMX_CONV_XCD", &AmxKnobs::conv_xcd, 3},
     {"AMX_BWD_FUSE", &AmxKnobs::bwd_fuse, 1},
     {"AMX_CONV_WS", &AmxKnobs::conv_ws, 1},
@@ -28,7 +27,6 @@ const KnobRow kRows[] = {
     {"AMX_GEMM_TILE", &AmxKnobs::gemm_tile, 0},
     {"AMX_RDEC_FWD_MT", &AmxKnobs::rdec_fwd_mt, 64},
     {"AMX_RDEC_BWD_MT", &AmxKnobs::rdec_bwd_mt, 64},
-    {"AMX_RDEC_WS", &AmxKnobs::rdec_ws, 1},
 };
 constexpr int kNumRows = (int)(sizeof(kRows) / sizeof(kRows[0]));
 
