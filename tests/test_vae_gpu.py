@@ -28,10 +28,13 @@ def test_rvae_config4_vs_oracle_on_device(B):
     """BASELINE.json configs[3] shape (rVAE latent_dim=2, 64x64 windows, default 128-wide nets) at bs=128 and at the
     FULL bs=512, with the treatment config 2 got in round 4: the oracle graph (stock torch ops on the
     same GPU) is run in fp64 = the reference, and once more in fp32 = the floor two correct fp32 implementations may
-    differ by.  Asserted: ELBO within 1e-5 of the fp64 value; every gradient within max(1e-4, 2 x floor) of the fp64
-    gradient, errors normalised by the largest gradient entry of the whole model (no kinks on this path: tanh).
-    The kernel's 5-instruction rd_tanh (rdecoder.hip, abs err <= 2e-7) is inside this budget, and a regression of it
-    would not be.  Measured on the MI355X: see profiles/r05_fullsize_parity_probe.log (this test's printed line)."""
+    differ by.  Asserted: ELBO within 1e-5 of the fp64 value; every gradient within max(1e-5, 2 x floor) of the fp64
+    gradient — ten times tighter than the north-star 1e-4 —, errors normalised by the largest gradient entry of the whole
+    model (no kinks on this path: tanh).  Measured on the MI355X (profiles/r05_fullsize_parity_probe.log, this test's
+    printed line): bs 128 — ELBO 7.5e-9, worst gradient 3.4e-8, largest oracle-fp32 floor 4.1e-7; bs 512 — 5.8e-9, 1.5e-8,
+    4.4e-7: the kernels (fixed-order fp64 reductions of the per-sample partial rows, the 5-instruction rd_tanh of
+    rdecoder.hip with abs err <= 2e-7) sit BELOW the floor of the stock fp32 graph; a regression of rd_tanh to 1e-5
+    would fail this test."""
     import atomai_amd as aoi
     from oracle import vae_oracle as vo
     m = aoi.models.rVAE((64, 64), latent_dim=2, seed=0)
@@ -63,7 +66,7 @@ def test_rvae_config4_vs_oracle_on_device(B):
             ref = g64[(which, k)]
             err = float((p.grad.double() - ref).abs().max()) / gmax
             floor = float((g32[(which, k)] - ref).abs().max()) / gmax
-            bound = max(V.REL_TOL, 2 * floor)
+            bound = max(0.1 * V.REL_TOL, 2 * floor)
             report.append((err / bound, f"{which}.{k}", err, floor))
             assert err < bound, (which, k, err, floor)
     worst = max(report)
