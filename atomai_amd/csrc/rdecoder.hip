@@ -67,7 +67,13 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
 #define RD_TICK(i) do { } while (0)
 #endif
 #ifndef RD_PLANE_PAD
-#define RD_PLANE_PAD 4        // compile-time experiment switch: 0 = the unpadded round-1 layout
+#define RD_PLANE_PAD 6        // slots (16 B) of padding per activation plane; 0 = the unpadded round-1 layout.  Round 5 sweep of the
+                              // config-4 step (profiles/r05_logs/r05_rvae_pad_sweep.log, bit-identical gradients): pad 4 (rounds
+                              // 2-4) 4.941 ms, 1 / 2 / 9 4.90, 5 4.877, 7 4.867, 3 4.858, 6 4.846, 8 / 12 5.13 (plane stride back
+                              // on a multiple of 32 banks).  Also measured there: the weight gradient's B operands by
+                              // ds_read_b128 with permuted accumulator columns (2 reads per k-step instead of 8 b32 reads,
+                              // bit-identical): 4.961 vs 4.963 ms at pad 4, 4.906 vs 4.888 at pad 5 — the phase is not bound by
+                              // its LDS instruction count; not kept.
 #endif
 #ifndef RD_SAVE_H0
 #define RD_SAVE_H0 0          // experiment switch: 1 = the saved-activation mode also keeps h0 (the coordinate layer's output) so
@@ -100,10 +106,10 @@ struct Geo {
     static constexpr int NT = 64 * NW;           // threads
     static constexpr int KG = HID / 4;           // feature groups of 4
     static constexpr int PT = MT / 16;           // pixel tiles per wave GEMM
-    // Plane stride of an activation image [kg][pixel][4] in 16-byte slots: MT + 4.  With a stride of MT (a multiple of 32
-    // banks) the scalar operand reads of the in-kernel weight gradient — lane (p, g) reads feature 16w+p of pixel 4s+g,
-    // i.e. planes (16w+p)>>2 — hit each bank four times; 4 slots (16 banks) of padding bring that to the minimum of two
-    // lanes per bank.  The float4 fragment reads / writes of the other phases stay conflict free (8 consecutive lanes
+    // Plane stride of an activation image [kg][pixel][4] in 16-byte slots: MT + RD_PLANE_PAD.  With a stride of MT (a
+    // multiple of 32 banks) the scalar operand reads of the in-kernel weight gradient — lane (p, g) reads feature 16w+p of
+    // pixel 4s+g, i.e. planes (16w+p)>>2 — hit each bank four times; padding spreads the planes over the banks (the sweep
+    // behind the value: RD_PLANE_PAD above).  The float4 fragment reads / writes of the other phases stay conflict free (8 consecutive lanes
     // still cover 128 contiguous bytes).  tools/gpu_rdec_phases.py: the wgrad phase was LDS-bound (23.2 k clocks per
     // tile for 16.4 k of MFMA time).
     static constexpr int PS = MT + RD_PLANE_PAD;

@@ -28,6 +28,25 @@ def step(i):
 libs = {"": L.load()}
 for name in sys.argv[1:]:
     libs[name] = L._bind(ctypes.CDLL(os.path.join(os.path.dirname(L.LIB_PATH), f"libatomai_amd_{name}.so")))
+# bit-identity of the builds: one forward + backward on the same weights / input / noise, every gradient compared
+torch.manual_seed(7)
+eps = torch.randn(B, 5, device="cuda")
+m.reparameterize = lambda zm, zs: zm + zs * eps
+ref = None
+for name, lib in libs.items():
+    L._lib = lib
+    m.optim.zero_grad()
+    elbo = m.forward_compute_elbo(xs[0])
+    (-elbo).backward()
+    g = [p.grad.detach().clone() for net in (m.encoder_net, m.decoder_net) for p in net.parameters()]
+    if ref is None:
+        ref = (elbo.item(), g)
+    else:
+        same = elbo.item() == ref[0] and all(torch.equal(a, b) for a, b in zip(g, ref[1]))
+        worst = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(g, ref[1]))
+        print(f"lib {name}: gradients bit-identical to the product build: {same} (worst relative difference {worst:.1e})", flush=True)
+del m.reparameterize
+m.optim.zero_grad()
 res = {k: [] for k in libs}
 for rep in range(3):
     for name, lib in libs.items():
