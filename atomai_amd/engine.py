@@ -640,6 +640,60 @@ class ConvNode(_Node):
             L.call("amx_add_inplace", L.ptr(tgt[1][0]), L.ptr(scratch), scratch.numel(), sp)
 
 
+# UpsampleBlock forward in one pass (csrc/upconv.hip): AMX_FUSE_UPCONV=0 keeps the two launches (host-side switch, read once)
+FUSE_UPCONV = _os.environ.get("AMX_FUSE_UPCONV", "1") != "0"
+UPCONV_MIN_PIXELS = 1 << 20      # low-res pixels of the launch from which the one-pass kernel wins (profiles/r05_logs/r05_upconv_ab3.log:
+#                                  x16 512^2 926 -> 717 us, x32 256^2 238 -> 167 us; x32 128^2 120 vs 126, x32 64^2 69 vs 81)
+
+
+def upconv_fusable(src: "Act", conv) -> bool:
+    """True when UpsampleBlock's 1x1 convolution + x2 interpolation of `src` runs as ONE launch (amx_upconv1x1_fwd):
+    a shape the kernel takes (its results are bit-identical to the two-kernel path there) and large enough to pay."""
+    if not FUSE_UPCONV or src.post_slope != 1.0 or src.npix < UPCONV_MIN_PIXELS:
+        return False
+    w = conv.weight
+    if w.dtype != torch.float32 or tuple(w.shape[2:]) != (1, 1) or w.shape[1] != src.C:
+        return False
+    return bool(L.load().amx_upconv1x1_supported(src.C, src.Cs, w.shape[0], r4(w.shape[0])))
+
+
+class UpConvNode(ConvNode):
+    """UpsampleBlock (atomai/nets/blocks.py:86-132) as one node: forward = amx_upconv1x1_fwd (1x1 convolution at low
+    resolution + x2 interpolation, the low-resolution tensor never written); backward = amx_upsample2x_bwd, then the
+    ordinary 1x1 weight / data gradients of ConvNode on the low-resolution gradient — exactly the launches of the
+    UpsampleNode + ConvNode pair it replaces."""
+
+    def __init__(self, tape, src: Act, conv, mode: str):
+        self.up_mode = {"bilinear": 0, "nearest": 1}[mode]
+        super().__init__(tape, [src], conv, None, 1.0)
+
+    def _forward(self, tape) -> Act:
+        s0 = self.srcs[0]
+        cos = r4(self.cout)
+        y = _empty((s0.N, 2 * s0.H, 2 * s0.W, cos), s0.t)
+        w, b = self.conv.weight, self.conv.bias
+        L.call("amx_upconv1x1_fwd", L.ptr(s0.t), L.ptr(s0.scale), L.ptr(s0.shift), L.ptr(w.detach().contiguous()),
+               L.ptr(b.detach() if b is not None else None), L.ptr(y), s0.N, s0.H, s0.W, s0.C, s0.Cs, self.cout, cos,
+               self.up_mode, _sp(y))
+        return Act(y, self.cout, needs_grad=tape.need_grad)
+
+    def backward(self, tape) -> None:
+        hi = self.out
+        g = hi.grad if hi.grad is not None else hi.gx
+        if g is None:
+            return
+        s0 = self.srcs[0]
+        dv = _empty((s0.N, s0.H, s0.W, hi.Cs), g)
+        L.call("amx_upsample2x_bwd", L.ptr(g), L.ptr(dv), s0.N, s0.H, s0.W, hi.Cs, self.up_mode, _sp(g))
+        lo = Act(dv, self.cout, needs_grad=True)             # the low-resolution convolution output's stand-in: only its
+        lo.grad = dv                                          # gradient exists (the tensor itself never did)
+        self.out = lo
+        try:
+            super().backward(tape)
+        finally:
+            self.out = hi
+
+
 class ResOutNode(_Node):
     """Tail of a ResBlock (atomai/nets/blocks.py:210-213): out = LeakyReLU(bn2(t) + r), materialised.
     ``t`` carries bn2 as its pending affine; ``r`` is the block's c0 output (plain tensor)."""
@@ -1092,6 +1146,9 @@ class Tape:
 
     def upsample(self, src: Act, mode: str) -> Act:
         return self._push(UpsampleNode(self, src, mode)).out
+
+    def upconv(self, src: Act, conv, mode: str) -> Act:
+        return self._push(UpConvNode(self, src, conv, mode)).out
 
     def resize_cat(self, srcs, H: int, W: int, mode: str) -> Act:
         return self._push(ResizeCatNode(self, srcs, H, W, mode)).out

@@ -132,6 +132,9 @@ class UpsampleBlock(_HipBlock):
         self.conv = nn.Conv2d(input_channels, output_channels, kernel_size=1, stride=1, padding=0)
 
     def _emit(self, tape, srcs):
+        from ..engine import upconv_fusable
+        if len(srcs) == 1 and upconv_fusable(srcs[0], self.conv):
+            return tape.upconv(srcs[0], self.conv, self.mode)          # one launch, same bits (csrc/upconv.hip)
         v = tape.conv(srcs, self.conv, None, 1.0)
         return tape.upsample(v, self.mode)
 

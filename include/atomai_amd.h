@@ -221,6 +221,15 @@ int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const fl
                     const float* skip, float* dy, float* bstats, int N, int H, int W, int Cs, void* stream);
 int amx_pool2x2_bwd_rows(int N, int H, int W, int Cs);
 int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode, void* stream);
+/* UpsampleBlock forward in ONE pass (atomai/nets/blocks.py:122-132; round 5): y[N][2h][2w][Cs_out] = x2 interpolation
+ * (mode 0 bilinear align_corners=False / 1 nearest) of the 1x1 convolution W[Cout][Cin] (+ bias) of x[N][h][w][Cs_in] with
+ * the producer's BatchNorm affine (sc, sh: Cs_in floats each, or both NULL) applied on load.  Bit-identical to
+ * amx_conv2d_fwd(taps = 1) followed by amx_upsample2x_fwd; the low-resolution result never reaches HBM.
+ * amx_upconv1x1_supported: Cout <= 64 (not 33..48), stored input channels = 0 or 4 mod 16 (the shapes whose summation
+ * order equals the two-kernel path's), the layer's weights + one tile fit the LDS. */
+int amx_upconv1x1_supported(int Cin, int Cs_in, int Cout, int Cs_out);
+int amx_upconv1x1_fwd(const float* x, const float* sc, const float* sh, const float* w, const float* bias, float* y, int N,
+                      int h, int w_, int Cin, int Cs_in, int Cout, int Cs_out, int mode, void* stream);
 int amx_upsample2x_bwd(const float* du, float* dv, int N, int h, int w, int Cs, int mode, void* stream);
 int amx_dilated_sum(const float* const* a, const float* const* scale, const float* const* shift, int n,
                     float slope, int accumulate, float* out, long npix, int Cs, void* stream);

@@ -684,3 +684,78 @@ def check_remainder_columns(device, cases=((50, 50, 1, 40, 2), (50, 50, 2, 44, 2
         if dil == 1:                                   # ConvBlock output = the layer itself: the first 16-wide tiles agree exactly
             nmain = (-(-cout // 4) * 4 // 16) * 16
             assert torch.equal(res["1"][0][:, :nmain], res["0"][0][:, :nmain]) or cout < 16
+
+
+def check_upconv_fused_kernel(device, cases=((50, 25, 2, 20, 33, 0), (128, 64, 2, 13, 16, 0), (64, 32, 1, 16, 30, 1),
+                                             (32, 16, 3, 7, 5, 0), (20, 8, 2, 15, 29, 0), (3, 5, 1, 6, 14, 1))):
+    """amx_upconv1x1_fwd (UpsampleBlock forward in one pass, upconv.hip) against the two-kernel path it replaces —
+    amx_conv2d_fwd(taps = 1) with the producer's BatchNorm affine on load, then amx_upsample2x_fwd — BIT for bit, on ragged
+    sizes (tiles of 6 x 14 low-res pixels: partial tiles on both axes), both interpolation modes, channel counts that are
+    not multiples of 4 / 16; and against torch's own F.interpolate -> Conv2d (the reference's order of the two operations)."""
+    import torch.nn.functional as F
+    from atomai_amd import _lib as L
+    from atomai_amd import engine as E
+    for cin, cout, N, h, w, mode in cases:
+        torch.manual_seed(cin + cout)
+        conv = torch.nn.Conv2d(cin, cout, 1).to(device)
+        x = torch.randn(N, cin, h, w, device=device)
+        sc = (torch.rand(cin, device=device) + 0.5)
+        sh = torch.randn(cin, device=device) * 0.3
+        tape = E.Tape(False, False)
+        src = tape.input(x).out
+        cs_in, cs_out = src.Cs, E.r4(cout)
+        scp, shp = E.padded_vec(sc, cs_in), E.padded_vec(sh, cs_in)
+        src.scale, src.shift = scp, shp
+        v = tape.conv([src], conv, None, 1.0)                  # low-res 1x1 convolution (affine on load)
+        ref = tape.upsample(v, "bilinear" if mode == 0 else "nearest").t
+        assert L.load().amx_upconv1x1_supported(cin, cs_in, cout, cs_out) == 1
+        assert L.load().amx_upconv1x1_supported(6, 8, 8, 8) == 0        # 2-group tail: another summation order -> two kernels
+        y = torch.empty((N, 2 * h, 2 * w, cs_out), dtype=torch.float32, device=x.device)
+        L.call("amx_upconv1x1_fwd", L.ptr(src.t), L.ptr(scp), L.ptr(shp), L.ptr(conv.weight.detach().contiguous()),
+               L.ptr(conv.bias.detach()), L.ptr(y), N, h, w, cin, cs_in, cout, cs_out, mode, L.stream_ptr(y))
+        assert torch.equal(y[..., :cout], ref[..., :cout]), (cin, cout, N, h, w, mode,
+                                                               float((y[..., :cout] - ref[..., :cout]).abs().max()))
+        assert float(y[..., cout:].abs().max()) == 0.0 if cs_out > cout else True
+        xa = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        up = F.interpolate(xa.double(), scale_factor=2, mode="bilinear" if mode == 0 else "nearest",
+                           **({"align_corners": False} if mode == 0 else {}))
+        want = F.conv2d(up, conv.weight.double(), conv.bias.double()).permute(0, 2, 3, 1)
+        assert float((y[..., :cout].double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def check_upconv_node(device, hw=32, batch=2):
+    """UpsampleBlock as ONE forward launch (engine.UpConvNode) inside whole nets: U-Net (three UpsampleBlocks, BatchNorm
+    affine of the producer on load) and dilnet (50 -> 25 channels, no affine) — logits and EVERY gradient bit-identical to
+    the UpsampleNode + ConvNode pair (the size threshold is lowered so that the small test shapes take the fused path)."""
+    import atomai_amd as aoi
+    from atomai_amd import _lib as L
+    from atomai_amd import engine as E
+    real_call = L.call
+    for model, ncls, nf in (("Unet", 3, 16), ("dilnet", 1, 25)):
+        out = {}
+        for thr in (1 << 40, 0):
+            cnt = {}
+
+            def counting(name, *a, _c=cnt):
+                _c[name] = _c.get(name, 0) + 1
+                return real_call(name, *a)
+            prev = E.UPCONV_MIN_PIXELS
+            E.UPCONV_MIN_PIXELS = thr
+            L.call = counting
+            try:
+                torch.manual_seed(5)
+                net, _ = aoi.nets.init_fcnn_model(model, ncls, nb_filters=nf)
+                net = net.to(device).train()
+                x = torch.randn(batch, 1, hw, hw, device=device)
+                y = net(x)
+                y.backward(torch.ones_like(y) / y.numel())
+                out[thr] = ([y.detach().cpu()] + [p.grad.detach().cpu() for p in net.parameters()], cnt)
+            finally:
+                L.call = real_call
+                E.UPCONV_MIN_PIXELS = prev
+        n_up = 3 if model == "Unet" else 1
+        assert out[0][1].get("amx_upconv1x1_fwd", 0) == n_up and out[1 << 40][1].get("amx_upconv1x1_fwd", 0) == 0, model
+        assert out[1 << 40][1]["amx_upsample2x_fwd"] - out[0][1].get("amx_upsample2x_fwd", 0) == n_up
+        assert out[0][1]["amx_upsample2x_bwd"] == out[1 << 40][1]["amx_upsample2x_bwd"] == n_up
+        for i, (a, b) in enumerate(zip(out[0][0], out[1 << 40][0])):
+            assert torch.equal(a, b), (model, i, float((a - b).abs().max()))

@@ -209,3 +209,7 @@ def test_upsample_forward_is_exact():
 def test_remainder_column_classes_vs_padded_plan():
     """25 / 50-filter layers on the 16 + 3 x 4 / 3 x 16 + 4 column plan (v_mfma_f32_4x4x1 remainder blocks)."""
     C.check_remainder_columns("cpu", cases=((50, 50, 1, 20, 1), (25, 50, 2, 18, 1), (50, 25, 1, 16, 1), (28, 50, 6, 21, 1)))
+
+
+def test_upsample_block_as_one_launch_inside_the_nets():
+    C.check_upconv_node("cpu")

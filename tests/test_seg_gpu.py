@@ -413,3 +413,12 @@ def test_upsample_forward_is_exact():
 def test_remainder_column_classes_vs_padded_plan():
     """25 / 50-filter layers on the 16 + 3 x 4 / 3 x 16 + 4 column plan (v_mfma_f32_4x4x1 remainder blocks)."""
     C.check_remainder_columns("cuda")
+
+
+def test_upsample_block_as_one_launch_inside_the_nets():
+    C.check_upconv_node("cuda", hw=64, batch=4)
+
+
+def test_upsample_block_forward_in_one_pass_is_bit_identical():
+    C.check_upconv_fused_kernel("cuda")
+    C.check_upconv_fused_kernel("cuda", cases=((50, 25, 3, 512, 512, 0), (32, 16, 8, 256, 256, 0), (128, 64, 4, 64, 64, 1)))
