@@ -209,3 +209,10 @@ extern "C" int amx_upconv1x1_fwd(const float* x, const float* sc, const float* s
     AMX_CHECK_LAUNCH();
     return 0;
 }
+
+// Measured and NOT kept (round 5, profiles/r05_logs/r05_upconv_bwd_rejected.log): the backward data path in one pass —
+// amx_upsample2x_bwd's gather of the high-resolution gradient into an 8 x 16 low-res tile in LDS (also written out for the
+// weight gradient), multiplied by the LDS-resident W right away (the 1x1 data gradient, bit-identical on the emulator and
+// on the MI355X) — is SLOWER than the two kernels it replaces on every UpsampleBlock of the config-2 U-Net (137 vs 91 us,
+// 206 vs 155, 337 vs 323): the gather is the expensive part, and behind a barrier in a four-wave workgroup it loses more
+// than reading dv back costs.

@@ -759,3 +759,4 @@ def check_upconv_node(device, hw=32, batch=2):
         assert out[0][1]["amx_upsample2x_bwd"] == out[1 << 40][1]["amx_upsample2x_bwd"] == n_up
         for i, (a, b) in enumerate(zip(out[0][0], out[1 << 40][0])):
             assert torch.equal(a, b), (model, i, float((a - b).abs().max()))
+

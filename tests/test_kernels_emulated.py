@@ -216,3 +216,4 @@ def test_fit_with_compute_accuracy(tmp_path):
 def test_upsample_block_forward_in_one_pass_is_bit_identical():
     import _seg_checks as C
     C.check_upconv_fused_kernel("cpu")
+
