@@ -193,9 +193,14 @@ extern "C" int amx_upconv1x1_fwd(const float* x, const float* sc, const float* s
     a.tiles_x = amx_ceil_div(w_, UC_TX); a.tiles_y = amx_ceil_div(h, 4 * rw - 2);
     long blocks = (long)N * a.tiles_x * a.tiles_y;
     if (blocks >= 2147483647L) AMX_BADARG(4);
-    const long cap = 4L * amx_num_cus();                          // persistent workgroups: the weight image is staged once each
-    if (blocks > cap) blocks = cap;
     const size_t lds = upconv_lds(ntc, Cs_in, rw);
+    // persistent workgroups (the weight image is staged once each): as many as are RESIDENT — four per CU by registers,
+    // fewer where the LDS images allow fewer (a fifth of a second round of workgroups would run on an empty chip)
+    long per_cu = (long)(160 * 1024 / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const long cap = per_cu * amx_num_cus();
+    if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
 #define UC_GO(NTC_, RW_)                                                                                    \
     do {                                                                                                    \

@@ -642,8 +642,8 @@ class ConvNode(_Node):
 
 # UpsampleBlock forward in one pass (csrc/upconv.hip): AMX_FUSE_UPCONV=0 keeps the two launches (host-side switch, read once)
 FUSE_UPCONV = _os.environ.get("AMX_FUSE_UPCONV", "1") != "0"
-UPCONV_MIN_PIXELS = 1 << 20      # low-res pixels of the launch from which the one-pass kernel wins (profiles/r05_logs/r05_upconv_ab3.log:
-#                                  x16 512^2 926 -> 717 us, x32 256^2 238 -> 167 us; x32 128^2 120 vs 126, x32 64^2 69 vs 81)
+UPCONV_MIN_PIXELS = 1 << 19      # low-res pixels of the launch from which the one-pass kernel wins (profiles/r05_logs/r05_upconv_ab4.log:
+#                                  x16 512^2 949 -> 731 us, x32 256^2 253 -> 170, x32 128^2 122 -> 108; x32 64^2 69 vs 73: two kernels)
 
 
 def upconv_fusable(src: "Act", conv) -> bool:
