@@ -81,6 +81,9 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
                               // (5.553 -> 5.620 ms, profiles/r03_rvae_h0_ab.log): 16 more prefetch registers (spill 120 ->
                               // 184 B in the <128, 64, 2> class) and 1.07 GB more HBM traffic each way.
 #endif
+#ifndef RD_FWD_WPIPE
+#define RD_FWD_WPIPE 1        // forward kernel: the next layer's weight fragments are fetched behind the current layer's MFMAs (0 = at its start)
+#endif
 #define RD_PLANES(NL_) ((NL_) + (RD_SAVE_H0 ? 1 : 0))
 #define MAXL 32           // latent dimensions (content latents + one-hot classes) the kernels keep in LDS
 #define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
@@ -180,15 +183,34 @@ __device__ __forceinline__ void coord_xy(const RDecArgs& a, int bidx, int pix0, 
 }
 
 // One hidden layer on a tile: dst = tanh(W src + b) [+ res].  src/dst/res are KG-layout LDS images.
-template <int HID, int MT>
+// W fragments of one layer for this lane: rows 16 wave + p, k-groups 4 c + g
+template <int HID>
+__device__ __forceinline__ void load_wfrag(const float* Wl, int wave, int lane, float4* areg) {
+    const int p = lane & 15, g = lane >> 4;
+    #pragma unroll
+    for (int c = 0; c < HID / 16; ++c) areg[c] = amx_ld4(Wl + (size_t)(16 * wave + p) * HID + 16 * c + 4 * g);
+}
+
+template <int HID> struct WFrag { float4 v[HID / 16]; };
+
+// PIPE (round 5, forward kernel): the caller hands over this layer's weight fragments in `wio` — fetched while the PREVIOUS
+// layer ran its epilogue — and gets the NEXT layer's (`Wnext`) back in the same registers: the loads are issued right
+// after the last MFMA, when the fragments are dead, and fly during the tanh epilogue, the barrier and (for the wrap to the
+// next tile) the output / coordinate layers.  Without it every layer of every tile started with an L2 round trip that
+// nothing hid; keeping all layers' fragments resident instead costs 32 registers per layer and the second workgroup per CU.
+template <int HID, int MT, bool PIPE = false>
 __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, const float* src, float* dst,
                                              const float* res, int wave, int lane, float* gsave = nullptr,
-                                             int npad = 0) {
+                                             int npad = 0, WFrag<HID>* wio = nullptr, const float* Wnext = nullptr) {
     using G = Geo<HID, MT>;
     const int p = lane & 15, g = lane >> 4;
     float4 areg[HID / 16];
-    #pragma unroll
-    for (int c = 0; c < HID / 16; ++c) areg[c] = amx_ld4(Wl + (size_t)(16 * wave + p) * HID + 16 * c + 4 * g);
+    if constexpr (PIPE) {
+        #pragma unroll
+        for (int c = 0; c < HID / 16; ++c) areg[c] = wio->v[c];
+    } else {
+        load_wfrag<HID>(Wl, wave, lane, areg);
+    }
     f32x4 acc[G::PT];
     #pragma unroll
     for (int t = 0; t < G::PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -208,6 +230,7 @@ __device__ __forceinline__ void hidden_layer(const float* Wl, const float* bl, c
         #pragma unroll
         for (int t = 0; t < G::PT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c].w, bq[t].w, acc[t], 0, 0, 0);
     }
+    if constexpr (PIPE) load_wfrag<HID>(Wnext, wave, lane, wio->v);
     // D'[row = feature 16*wave + 4g + r][col = pixel 16t + p]
     const float4 bias = amx_ld4(bl + 16 * wave + 4 * g);
     #pragma unroll
@@ -291,6 +314,8 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     const int bidx = blockIdx.x;
     latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid, s_wc, s_wo);
     const float* th = a.theta ? s_th : nullptr;
+    WFrag<HID> wf;
+    if (RD_FWD_WPIPE) load_wfrag<HID>(a.W, wave, lane, wf.v);      // layer 0's fragments for the first tile
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         float* h0 = a.skip ? buf2 : buf0;
         coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid,
@@ -300,10 +325,13 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
         const float* src = h0;
         for (int l = 0; l < a.NL; ++l) {
             float* dst = (src == buf0) ? buf1 : buf0;
-            hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, src, dst,
-                                  a.skip ? h0 : nullptr, wave, lane,
-                                  a.hsave ? a.hsave + (((size_t)bidx * RD_PLANES(a.NL) + l + (RD_SAVE_H0 ? 1 : 0)) * G::KG * a.npad + pix0) * 4 : nullptr,
-                                  a.npad);
+            float* gs = a.hsave ? a.hsave + (((size_t)bidx * RD_PLANES(a.NL) + l + (RD_SAVE_H0 ? 1 : 0)) * G::KG * a.npad + pix0) * 4 : nullptr;
+            if (RD_FWD_WPIPE)
+                hidden_layer<HID, MT, true>(nullptr, a.b + (size_t)l * HID, src, dst, a.skip ? h0 : nullptr, wave, lane, gs,
+                                            a.npad, &wf, a.W + (size_t)(l + 1 < a.NL ? l + 1 : 0) * HID * HID);
+            else
+                hidden_layer<HID, MT>(a.W + (size_t)l * HID * HID, a.b + (size_t)l * HID, src, dst,
+                                      a.skip ? h0 : nullptr, wave, lane, gs, a.npad);
             __syncthreads();
             src = dst;
         }
@@ -478,7 +506,9 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
                 }
             }
             RD_TICK(3);
-            // dgrad: gh[k][pix] = sum_f W[f][k] ga[pix][f]  (A = W^T fragments, B = ga image)
+            // dgrad: gh[k][pix] = sum_f W[f][k] ga[pix][f]  (A = W^T fragments, B = ga image).  (Round 5: requesting the
+            // fragments inside the weight-gradient sweep, a quarter of it ahead, spills 136 B more at the 256-register limit:
+            // 5.39 vs 4.80 ms per step, profiles/r05_logs/r05_rvae_bwd_wpre_rejected.log.)
             float4 areg[HID / 16];
             const float* Wt = a.Wt + (size_t)l * HID * HID;
             #pragma unroll

@@ -48,7 +48,7 @@ for name, lib in libs.items():
 del m.reparameterize
 m.optim.zero_grad()
 res = {k: [] for k in libs}
-for rep in range(3):
+for rep in range(int(os.environ.get("AB_REPS", "3"))):
     for name, lib in libs.items():
         L._lib = lib
         for i in range(3): step(i)
