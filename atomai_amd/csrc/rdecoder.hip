@@ -81,6 +81,12 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
                               // (5.553 -> 5.620 ms, profiles/r03_rvae_h0_ab.log): 16 more prefetch registers (spill 120 ->
                               // 184 B in the <128, 64, 2> class) and 1.07 GB more HBM traffic each way.
 #endif
+#ifndef RD_COORD_PREFETCH
+#define RD_COORD_PREFETCH 1   // the next tile's raw coordinate pair is fetched at the start of the current tile (0 = at its own start)
+#endif
+#ifndef RD_COORD_PREFETCH_BWD
+#define RD_COORD_PREFETCH_BWD 1
+#endif
 #ifndef RD_FWD_WPIPE
 #define RD_FWD_WPIPE 1        // forward kernel: the next layer's weight fragments are fetched behind the current layer's MFMAs (0 = at its start)
 #endif
@@ -121,11 +127,25 @@ struct Geo {
     static constexpr int TPP = NT / MT;          // threads per pixel in the output stage
 };
 
+// Raw coordinate pair of this thread's pixel of the tile at pix0 (theta mode: the shared grid point, else the sample's own
+// transformed point); clamped to a valid pixel past the end.  Round 5: the kernels fetch the NEXT tile's pair at the start
+// of the current tile (RD_COORD_PREFETCH) — the coordinate layer is the first thing a tile does, and its two dependent
+// global loads were an exposed L2 round trip per tile.
+struct RawXY { float x, y; };
+template <int MT>
+__device__ __forceinline__ RawXY load_raw_xy(const RDecArgs& a, int bidx, int pix0, int tid, bool theta_mode) {
+    int q = pix0 + tid % MT;
+    q = q < a.n ? q : a.n - 1;
+    const float* c = theta_mode ? a.coords + (size_t)q * 2 : a.coords + ((size_t)bidx * a.n + q) * 2;
+    RawXY r; r.x = c[0]; r.y = c[1];
+    return r;
+}
+
 // h0 tile -> dst (KG layout).  Also stores x',y' per pixel when s_xy != nullptr.
 template <int HID, int MT>
 __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix0, const float* s_zc,
                                             float* dst, float* s_xy, const float* s_th, int tid,
-                                            float* gsave = nullptr, const float* wc = nullptr) {
+                                            float* gsave = nullptr, const float* wc = nullptr, const RawXY* pre = nullptr) {
     if (!wc) wc = a.Wc;                          // (the kernels pass their LDS copy: s_wc)
     using G = Geo<HID, MT>;
     static_assert(G::NT % MT == 0, "a thread's slots share one pixel");
@@ -134,12 +154,12 @@ __device__ __forceinline__ void coord_layer(const RDecArgs& a, int bidx, int pix
     float xx = 0.f, yy = 0.f;
     if (q < a.n) {
         if (s_th) {                                        // rotate + translate the shared grid point
-            const float gx = a.coords[(size_t)q * 2 + 0], gy = a.coords[(size_t)q * 2 + 1];
+            const float gx = pre ? pre->x : a.coords[(size_t)q * 2 + 0], gy = pre ? pre->y : a.coords[(size_t)q * 2 + 1];
             xx = gx * s_th[0] - gy * s_th[1] + s_th[2];
             yy = gx * s_th[1] + gy * s_th[0] + s_th[3];
         } else {
-            xx = a.coords[((size_t)bidx * a.n + q) * 2 + 0];
-            yy = a.coords[((size_t)bidx * a.n + q) * 2 + 1];
+            xx = pre ? pre->x : a.coords[((size_t)bidx * a.n + q) * 2 + 0];
+            yy = pre ? pre->y : a.coords[((size_t)bidx * a.n + q) * 2 + 1];
         }
     }
     #pragma unroll
@@ -316,11 +336,15 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     const float* th = a.theta ? s_th : nullptr;
     WFrag<HID> wf;
     if (RD_FWD_WPIPE) load_wfrag<HID>(a.W, wave, lane, wf.v);      // layer 0's fragments for the first tile
+    RawXY xy_cur = load_raw_xy<MT>(a, bidx, 0, tid, th != nullptr);
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         float* h0 = a.skip ? buf2 : buf0;
+        RawXY xy_nxt = xy_cur;
+        if (RD_COORD_PREFETCH && pix0 + MT < a.n) xy_nxt = load_raw_xy<MT>(a, bidx, pix0 + MT, tid, th != nullptr);
         coord_layer<HID, MT>(a, bidx, pix0, s_zc, h0, nullptr, th, tid,
                              (RD_SAVE_H0 && a.hsave) ? a.hsave + ((size_t)bidx * RD_PLANES(a.NL) * G::KG * a.npad + pix0) * 4 : nullptr,
-                             s_wc);
+                             s_wc, RD_COORD_PREFETCH ? &xy_cur : nullptr);
+        xy_cur = xy_nxt;
         __syncthreads();
         const float* src = h0;
         for (int l = 0; l < a.NL; ++l) {
@@ -409,10 +433,11 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
                 pre[l][i] = amx_ld4(hb + (size_t)(l * G::KG + i * (G::NT / MT)) * a.npad * 4);
     };
     if (SAVED) fetch(0);
+    RawXY bxy = load_raw_xy<MT>(a, bidx, 0, tid, th != nullptr);          // this tile's raw coordinate pair (prefetched below)
     for (int pix0 = 0; pix0 < a.n; pix0 += MT) {
         // ---- recompute forward for the tile
         if (SAVED && RD_SAVE_H0) coord_xy<MT>(a, bidx, pix0, s_xy, th, tid);
-        else coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid, nullptr, s_wc);
+        else coord_layer<HID, MT>(a, bidx, pix0, s_zc, H[0], s_xy, th, tid, nullptr, s_wc, RD_COORD_PREFETCH_BWD ? &bxy : nullptr);
         if (SAVED) {
             #pragma unroll
             for (int l = 0; l < NPL; ++l)
@@ -565,6 +590,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         // backward and the next tile's coordinate layer, i.e. while no MFMA operand / accumulator registers are live
         // (issued a whole tile ahead they cost 30 spilled registers in the <128, 64, 2> class)
         if (SAVED && pix0 + MT < a.n) fetch(pix0 + MT);
+        if (RD_COORD_PREFETCH_BWD && pix0 + MT < a.n) bxy = load_raw_xy<MT>(a, bidx, pix0 + MT, tid, th != nullptr);
         float* s_g = H[1];                       // scratch [KG][MT][2] (H[1] is free now; NL >= 1)
         #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
