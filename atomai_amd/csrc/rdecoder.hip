@@ -84,6 +84,9 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
 #ifndef RD_COORD_PREFETCH
 #define RD_COORD_PREFETCH 1   // the next tile's raw coordinate pair is fetched at the start of the current tile (0 = at its own start)
 #endif
+#ifndef RD_BWD_C1
+#define RD_BWD_C1 1           // one-channel instantiation of the backward kernel (0 = MAXC accumulators for every patch)
+#endif
 #ifndef RD_COORD_PREFETCH_BWD
 #define RD_COORD_PREFETCH_BWD 1
 #endif
@@ -369,7 +372,9 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------
-template <int HID, int MT, int NL, bool SAVED>
+// CM: compile-time bound of the per-channel register accumulators (1 for grey-scale patches, MAXC otherwise) — with MAXC for
+// everything the six unused accumulators of the one-channel case sat in registers of a kernel at its 256-register limit
+template <int HID, int MT, int NL, bool SAVED, int CM = MAXC>
 __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     using G = Geo<HID, MT>;
     AMX_DYN_SMEM(float, smem);
@@ -404,10 +409,10 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     }
     // per-feature accumulators: thread tid owns feature fq for the qq-th quarter of every tile's pixels
     const int fq = tid & (HID - 1), qq = tid / HID;
-    float aWo[MAXC], aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
-    float abo[MAXC];
+    float aWo[CM], aWc0 = 0.f, aWc1 = 0.f, aZc = 0.f;
+    float abo[CM];
     #pragma unroll
-    for (int c = 0; c < MAXC; ++c) { aWo[c] = 0.f; abo[c] = 0.f; }
+    for (int c = 0; c < CM; ++c) { aWo[c] = 0.f; abo[c] = 0.f; }
 
 #ifdef AMX_RDEC_PROFILE
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
             __syncthreads();
         }
         #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < CM; ++c) {
             if (c >= a.C) break;
             if (tid < MT) abo[c] += s_out[c * MT + tid];
             {                                    // dWo[c][f] += sum_p dout[p][c] * h_NL[p][f]: feature fq, the qq-th
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
         }
         __syncthreads();
         #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
+        for (int c = 0; c < CM; ++c) {
             if (c >= a.C) break;
             s_red[tid] = aWo[c];
             __syncthreads();
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_bwd_kernel(RDecArgs a) {
     // dbo
     __syncthreads();
     #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < CM; ++c) {
         if (c >= a.C) break;
         s_red[tid] = tid < MT ? abo[c] : 0.f;
         __syncthreads();
@@ -754,8 +759,13 @@ template <int HID, int MT, int NL, bool SAVED>
 static int launch_bwd_v(const RDecArgs& a, hipStream_t s) {
     const size_t lds = bwd_lds<HID, MT, NL>(a.skip);
     if (lds > 160 * 1024) AMX_BADARG(20);
-    AMX_ALLOW_160K_LDS(rdecoder_bwd_kernel<HID, MT, NL, SAVED>);
-    AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL, SAVED>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    if (a.C == 1 && RD_BWD_C1) {                     // grey-scale patches (the reference's default): one-channel accumulators
+        AMX_ALLOW_160K_LDS(rdecoder_bwd_kernel<HID, MT, NL, SAVED, 1>);
+        AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL, SAVED, 1>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    } else {
+        AMX_ALLOW_160K_LDS(rdecoder_bwd_kernel<HID, MT, NL, SAVED>);
+        AMX_LAUNCH((rdecoder_bwd_kernel<HID, MT, NL, SAVED>), dim3(a.B), dim3(4 * HID), lds, s, a);
+    }
     AMX_CHECK_LAUNCH();
     return 0;
 }
