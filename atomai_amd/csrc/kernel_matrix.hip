@@ -225,7 +225,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restrict__ X, const T* __restrict__ inv_ls,
                                                                 T s2, int kind, int N, int D,
                                                                 const T* __restrict__ G, T* __restrict__ dX,
-                                                                T* __restrict__ part) {
+                                                                T* __restrict__ part,
+                                                                const T* __restrict__ alpha, T gscale) {
+    // alpha != nullptr (amx_kernel_matrix_bwd_mll): G holds K^-1 and the upstream gradient of the exact marginal log
+    // likelihood, (alpha_i alpha_j - K^-1_ij) * gscale, is formed while reading it — no N x N temporary for
+    // alpha alpha^T, the difference or the scaling (nets/gp.py:_ExactMLLFn.backward)
     __shared__ T s_t[256];
     __shared__ T s_acc[4][KM_MAXD + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restr
     T ax[KM_MAXD], al[KM_MAXD], as2 = T(0);
     #pragma unroll
     for (int d = 0; d < KM_MAXD; ++d) { ax[d] = T(0); al[d] = T(0); }
+    const T ai = (alpha && gi < N) ? alpha[gi] : T(0);
     if (gi < N)
         for (int c = lane; c < N; c += 64) {
             T df[KM_MAXD];
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restr
             }
             T w;
             const T k = km_eval<T>(r2, s2, kind, &w);
-            const T g = G[(size_t)gi * N + c];
+            T g = G[(size_t)gi * N + c];
+            if (alpha) g = (ai * alpha[c] - g) * gscale;
             as2 += g * k;
             const T gw = g * w;
             #pragma unroll
@@ -284,9 +290,9 @@ __global__ __launch_bounds__(256) void kernel_matrix_bwd_kernel(const T* __restr
 
 template <typename T>
 static int launch_kb(const void* X, const void* inv_ls, double s2, int kind, int N, int D, const void* G, void* dX,
-                     void* part, hipStream_t st) {
+                     void* part, hipStream_t st, const void* alpha = nullptr, double gscale = 1.0) {
     AMX_LAUNCH(kernel_matrix_bwd_kernel<T>, dim3(amx_ceil_div(N, 4)), dim3(256), 0, st, (const T*)X,
-               (const T*)inv_ls, (T)s2, kind, N, D, (const T*)G, (T*)dX, (T*)part);
+               (const T*)inv_ls, (T)s2, kind, N, D, (const T*)G, (T*)dX, (T*)part, (const T*)alpha, (T)gscale);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -299,4 +305,17 @@ extern "C" int amx_kernel_matrix_bwd(const void* X, const void* inv_ls, double o
     hipStream_t st = (hipStream_t)stream;
     return is_double ? launch_kb<double>(X, inv_ls, outputscale, kind, N, D, G, dX, part, st)
                      : launch_kb<float>(X, inv_ls, outputscale, kind, N, D, G, dX, part, st);
+}
+
+// The same contraction with G = (alpha alpha^T - Kinv) * gscale formed on the fly from Kinv (symmetric, as
+// torch.cholesky_inverse returns it) and alpha = K^-1 (y - mean): the backward pass of the exact marginal log likelihood
+// (gscale = 0.5 / N) reads ONE N x N matrix instead of building three.
+extern "C" int amx_kernel_matrix_bwd_mll(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
+                                         int is_double, const void* Kinv, const void* alpha, double gscale, void* dX,
+                                         void* part, void* stream) {
+    if (!X || !inv_ls || !Kinv || !alpha || !dX || !part) AMX_BADARG(1);
+    if (N <= 0 || D <= 0 || D > KM_MAXD || (kind != 0 && kind != 1)) AMX_BADARG(2);
+    hipStream_t st = (hipStream_t)stream;
+    return is_double ? launch_kb<double>(X, inv_ls, outputscale, kind, N, D, Kinv, dX, part, st, alpha, gscale)
+                     : launch_kb<float>(X, inv_ls, outputscale, kind, N, D, Kinv, dX, part, st, alpha, gscale);
 }

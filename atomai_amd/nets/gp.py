@@ -70,8 +70,27 @@ class convFeatureExtractor(nn.Module):
         return linear(h.flatten(1).to(self.fc.weight.dtype), self.fc.weight, self.fc.bias).to(dt)
 
 
-def _kernel_call(name, *tensors_and_args):
-    L.call(name, *tensors_and_args)
+# Phase clock of the fit step (tools/bench_extra.py::bench_dkl_fit): None in product use; a dict name -> list of
+# (start, end) torch.cuda.Event pairs when a benchmark wants the breakdown (events only, no synchronisation here).
+PHASES = None
+
+
+class _phase:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PHASES is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PHASES is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PHASES.setdefault(self.name, []).append((self.e0, e1))
+        return False
 
 
 def kernel_matrix(X1, X2, lengthscale, outputscale: float, kind: int = 0, noise: float = 0.0) -> torch.Tensor:
@@ -106,12 +125,16 @@ class _ExactMLLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Z, y, lengthscale, outputscale, noise, mean, kind):
         N, D = Z.shape
-        K = kernel_matrix(Z, Z, lengthscale, float(outputscale), kind, float(noise))
-        Lc = torch.linalg.cholesky(K)
-        r = (y.detach() - mean.detach()).reshape(N, 1)
-        alpha = torch.cholesky_solve(r, Lc)
-        logdet = 2.0 * torch.log(torch.diagonal(Lc)).sum()
-        mll = (-0.5 * (r * alpha).sum() - 0.5 * logdet - 0.5 * N * math.log(2 * math.pi)) / N
+        with _phase("k_build"):
+            K = kernel_matrix(Z, Z, lengthscale, float(outputscale), kind, float(noise))
+        with _phase("potrf"):
+            Lc = torch.linalg.cholesky(K)
+        del K
+        with _phase("solve_logdet"):
+            r = (y.detach() - mean.detach()).reshape(N, 1)
+            alpha = torch.cholesky_solve(r, Lc)
+            logdet = 2.0 * torch.log(torch.diagonal(Lc)).sum()
+            mll = (-0.5 * (r * alpha).sum() - 0.5 * logdet - 0.5 * N * math.log(2 * math.pi)) / N
         ctx.save_for_backward(Z.detach(), lengthscale.detach(), Lc, alpha)
         ctx.meta = (float(outputscale), kind, N, D)
         return mll
@@ -120,19 +143,27 @@ class _ExactMLLFn(torch.autograd.Function):
     def backward(ctx, g):
         Z, ls, Lc, alpha = ctx.saved_tensors
         s2, kind, N, D = ctx.meta
-        Kinv = torch.cholesky_inverse(Lc)
-        G = ((alpha @ alpha.T) - Kinv) * (0.5 / N)
-        G = (0.5 * (G + G.T)).contiguous()
-        dZ = torch.empty_like(Z)
-        nblk = (N + 3) // 4
-        part = torch.empty(nblk, D + 1, dtype=Z.dtype, device=Z.device)
-        inv_ls = (1.0 / ls.reshape(-1)).to(Z.dtype).contiguous()
-        L.call("amx_kernel_matrix_bwd", L.ptr(Z.contiguous()), L.ptr(inv_ls), s2, kind, N, D,
-               int(Z.dtype == torch.float64), L.ptr(G), L.ptr(dZ), L.ptr(part), L.stream_ptr(Z))
-        tot = part.sum(0)                                   # (D+1)-vector: plumbing-size reduction
-        d_inv_ls, d_s2 = tot[:D], tot[D]
-        d_ls = (-d_inv_ls * inv_ls * inv_ls).reshape(ls.shape)
-        d_noise = torch.diagonal(G).sum()
+        # K^-1 from the factor (LAPACK potri through torch; the result is symmetric: torch mirrors the computed triangle).
+        # G = dMLL/dK = (alpha alpha^T - K^-1) / (2N) is NOT materialised: the HIP backward kernel forms it while it reads
+        # K^-1 (round 6: the dense alpha alpha^T, the difference, the scaling and a symmetrised copy were four N x N
+        # temporaries and ~10 N^2 memory passes per step)
+        with _phase("potri"):
+            Kinv = torch.cholesky_inverse(Lc)
+            if not Kinv.is_contiguous():        # LAPACK hands back column-major storage: K^-1 is symmetric, read it as it lies
+                Kinv = Kinv.T if Kinv.T.is_contiguous() else Kinv.contiguous()
+        with _phase("k_bwd"):
+            dZ = torch.empty_like(Z)
+            nblk = (N + 3) // 4
+            part = torch.empty(nblk, D + 1, dtype=Z.dtype, device=Z.device)
+            inv_ls = (1.0 / ls.reshape(-1)).to(Z.dtype).contiguous()
+            av = alpha.reshape(-1).contiguous()
+            L.call("amx_kernel_matrix_bwd_mll", L.ptr(Z.contiguous()), L.ptr(inv_ls), s2, kind, N, D,
+                   int(Z.dtype == torch.float64), L.ptr(Kinv), L.ptr(av), 0.5 / N, L.ptr(dZ), L.ptr(part),
+                   L.stream_ptr(Z))
+            tot = part.sum(0)                                   # (D+1)-vector: plumbing-size reduction
+            d_inv_ls, d_s2 = tot[:D], tot[D]
+            d_ls = (-d_inv_ls * inv_ls * inv_ls).reshape(ls.shape)
+            d_noise = ((av * av).sum() - torch.diagonal(Kinv).sum()) * (0.5 / N)      # trace(G)
         d_mean = alpha.sum() / N                             # d mll / d mean =  sum(alpha) / N
         d_y = -alpha.reshape(-1) / N                         # d mll / d y    = -alpha / N
         return g * dZ, g * d_y, g * d_ls, g * d_s2, g * d_noise, g * d_mean, None
@@ -185,7 +216,8 @@ class GPRegressionModel(nn.Module):
 
     def mll(self) -> torch.Tensor:
         """Sum over the q outputs of the per-datum exact marginal log likelihood of the training data."""
-        Z = self.embed(self.train_inputs[0])
+        with _phase("extractor_fwd"):
+            Z = self.embed(self.train_inputs[0])
         self._cache = None
         tot = 0
         for i in range(self.train_targets.shape[0]):

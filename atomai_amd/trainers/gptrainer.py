@@ -93,9 +93,22 @@ class dklGPTrainer:
             params += [m.raw_lengthscale, m.raw_outputscale, m.mean_constant, m.raw_noise]
             if not freeze:
                 params += list(m.feature_extractor.parameters())
-        self.optimizer = torch.optim.Adam(params, lr=0.01)
+        self.optimizer = self._make_optimizer([{'params': params}], 0.01)
         self.training_cycles = training_cycles
         self.compiled = True
+
+    def _make_optimizer(self, groups, lr: float):
+        """Adam over the reference's parameter groups (gptrainer.py:289-296: one learning rate for all of them).  In
+        single precision on the device the groups are ONE flat bucket of the fused optimizer (optim.FusedAdam: one HIP
+        launch per step, the convolutional extractor's weight gradients written straight into the bucket by the tape);
+        double precision — the reference's default — keeps torch.optim.Adam: adam.hip is an fp32 kernel."""
+        params = [p for g in groups for p in g['params']]
+        if self.dtype == torch.float32 and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            from ..optim import FusedAdam
+            opt = FusedAdam(params, lr=lr)
+            opt.prepare()
+            return opt
+        return torch.optim.Adam(groups, lr=lr)
 
     def compile_trainer(self, X, y, training_cycles: int = 1, **kwargs) -> None:
         """feature extractor NN + base kernel + Adam(lr=0.01) over kernel, mean, noise (+ NN) parameters."""
@@ -119,7 +132,7 @@ class dklGPTrainer:
                   {'params': [m.raw_noise]}]
         if not freeze:
             groups.append({'params': list(m.feature_extractor.parameters())})
-        self.optimizer = torch.optim.Adam(groups, lr=kwargs.get("lr", 0.01))
+        self.optimizer = self._make_optimizer(groups, kwargs.get("lr", 0.01))
         self.training_cycles = training_cycles
         self.compiled = True
 

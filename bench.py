@@ -293,7 +293,8 @@ def extra_configs():
     out = {}
     for key, fn, kw in (("config3_dilnet_predict_4096x1024", bx.bench_predict_full, dict(frames=4096)),
                         ("config4_rvae_bs512_64x64", bx.bench_rvae, dict(steps=20, warmup=3)),
-                        ("config5_dkl_rbf_n16384", bx.bench_dkl, dict())):
+                        ("config5_dkl_rbf_n16384", bx.bench_dkl, dict()),
+                        ("config5_dklgpr_fit_step", bx.bench_dkl_fit, dict())):
         t0 = time.perf_counter()
         try:
             r = fn(emit=False, **kw)

@@ -384,6 +384,10 @@ int amx_rvae_latent_bwd(const float* zlogsd, const float* eps, const float* dthe
                         int translation, float dx_prior, float* dmean, float* dlogsd, void* stream);
 
 
+/* The rDecoder kernels' activation function, element-wise: y[i] = tanh(x[i]) as the fused kernels evaluate it
+ * (hardware exp + reciprocal, absolute error <= 2e-7; nn.Tanh of atomai/nets/ed.py:613-616).  For tests of that bound. */
+int amx_rdec_tanh_probe(const float* x, float* y, long n, void* stream);
+
 /* ---- DKL covariance evaluation: ScaleKernel(RBFKernel(ard)) / MaternKernel(2.5) on the embeddings
  * (selected at atomai/nets/gp.py:41-46,95-106; arithmetic in gpytorch).  kind 0 = RBF, 1 = Matern-5/2;
  * inv_ls = 1/lengthscale per dim; is_double selects fp64 buffers. */
@@ -393,6 +397,12 @@ int amx_kernel_matvec(const void* X1, const void* X2, const void* inv_ls, double
                       int M, int D, int R, int is_double, const void* V, void* Y, void* stream);
 int amx_kernel_matrix_bwd(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
                           int is_double, const void* G, void* dX, void* part, void* stream);
+/* amx_kernel_matrix_bwd with G = (alpha alpha^T - Kinv) * gscale formed while Kinv is read (Kinv N x N symmetric,
+ * alpha N): the gradient of the exact marginal log likelihood that gpytorch's ExactMarginalLogLikelihood gives the
+ * reference's optimizer (atomai/trainers/gptrainer.py:126-137, 285-303), without the N x N temporaries. */
+int amx_kernel_matrix_bwd_mll(const void* X, const void* inv_ls, double outputscale, int kind, int N, int D,
+                              int is_double, const void* Kinv, const void* alpha, double gscale, void* dX, void* part,
+                              void* stream);
 
 /* ---- Locator: thresholded class maps -> blob centres (atomai/predictors/predictor.py:531-639 Locator.run /
  *      rem_edge_coord; atomai/utils/img.py:554-564 cv_thresh; atomai/utils/coords.py:21-34 find_com =

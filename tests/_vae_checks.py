@@ -209,3 +209,29 @@ def check_rvae_fused_latent_path(device):
         assert abs(res[0][0] - res[1][0]) < 1e-5 * abs(res[1][0])
         for a, b in zip(res[0][1], res[1][1]):
             assert float((a - b).abs().max()) <= 1e-5 * max(1e-6, float(b.abs().max()))
+
+
+def check_rd_tanh_bound(device, bound=2e-7):
+    """Element-wise ABSOLUTE error of the rDecoder kernels' activation function (csrc/rdecoder.hip `rd_tanh`: hardware
+    exp + reciprocal, 1 - 2 / (e^2x + 1)) against float64 tanh over [-20, 20] — a dense grid, a log grid down to the
+    smallest normal numbers on both sides of 0, subnormal inputs, +-0 and the saturation range — through
+    amx_rdec_tanh_probe.  The header comment of rd_tanh claims <= 2e-7 (VERDICT r05 weak #12: no test stated it)."""
+    from atomai_amd import _lib as L
+    tiny = np.float32(np.finfo(np.float32).tiny)
+    xs = np.concatenate([
+        np.linspace(-20, 20, 2_000_001, dtype=np.float64).astype(np.float32),
+        np.float32(10.0) ** np.linspace(-37.9, 1.3, 200_001, dtype=np.float64).astype(np.float32),
+        -(np.float32(10.0) ** np.linspace(-37.9, 1.3, 200_001, dtype=np.float64).astype(np.float32)),
+        np.array([0.0, -0.0, tiny, -tiny, tiny / 2, -tiny / 2, tiny * 1.5, 1e-45, -1e-45, 8.5, 9.0, 9.5, 10.0, 15.0, 20.0,
+                  -8.5, -9.0, -15.0, -20.0, 44.0, -44.0, 88.0, -88.0, 100.0, -100.0], dtype=np.float32)])
+    x = torch.from_numpy(xs).to(device)
+    y = torch.empty_like(x)
+    L.call("amx_rdec_tanh_probe", L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr(x))
+    ref = np.tanh(xs.astype(np.float64))
+    got = y.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    i = int(err.argmax())
+    assert err[i] <= bound, (xs[i], got[i], ref[i], err[i])
+    assert (np.abs(got) <= 1.0).all()                        # saturates to +-1, never beyond
+    return float(err[i]), float(xs[i])

@@ -137,6 +137,91 @@ def test_full_width_vs_oracle_on_device(model, ncls, B, H):
           f"floor {worst[3]:.2e}, kink sensitivity {worst[4]:.2e})")
 
 
+@pytest.mark.parametrize("model,ncls,B,H,seed", [("dilnet", 1, 1, 32, 71), ("dilnet", 1, 1, 32, 77),
+                                                 ("ResHedNet", 3, 1, 16, 113), ("ResHedNet", 3, 1, 16, 114)])
+def test_full_width_kink_free_vs_oracle(model, ncls, B, H, seed):
+    """VERDICT r05 weak #1: the full-size dilnet / ResHedNet gradient tests pass through a kink allowance (`sens`); is the
+    excess over the reference's fp32 floor really LeakyReLU branch flips, or an accumulation problem of the lattice / K-padded
+    weight gradients?  Default-WIDTH nets (25 / 50 and 64 / 128 / 256 filters) on an input whose every LeakyReLU
+    pre-activation is at least 2e-5 away from 0 (seeds found by drawing until `seg_oracle.min_abs_preactivation` says so
+    — a frame is small enough for such a draw to exist: the full-size frames hold ~7 pre-activations per million inside
+    1e-5 of the kink).  No branch can flip, so NO `sens` term: every gradient within max(1e-4, 2 x the floor the oracle's
+    own fp32 run shows against fp64), normalised globally as in the full-size test."""
+    import atomai_amd as aoi
+    from oracle import seg_oracle as so
+    torch.manual_seed(seed)
+    net, _ = aoi.nets.init_fcnn_model(model, ncls)
+    sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.rand(B, 1, H, H).astype(np.float32))
+    y = (torch.from_numpy(rs.randint(0, ncls, (B, H, H))) if ncls > 1
+         else torch.from_numpy((rs.rand(B, 1, H, H) > 0.5).astype(np.float32)))
+    assert so.min_abs_preactivation(model, sd, x) > 1e-5
+    net.cuda().train()
+    loss = aoi.losses_metrics.select_loss("ce", ncls)(net(x.cuda()), y.cuda())
+    loss.backward()
+    y64 = y if ncls > 1 else y.double()
+    l32, _, g32 = _oracle_on("cuda", sd, x, y, ncls, model)
+    l64, _, g64 = _oracle_on("cuda", so.cast(sd, torch.float64), x.double(), y64, ncls, model)
+    assert abs(loss.item() - float(l64)) / abs(float(l64)) < 1e-5
+    gmax = max(float(g.abs().max()) for g in g64.values())
+    report = []
+    for k, p in net.named_parameters():
+        err = float((p.grad.double() - g64[k]).abs().max()) / gmax
+        floor = float((g32[k].double() - g64[k]).abs().max()) / gmax
+        report.append((err / max(C.REL_TOL, 2 * floor), k, err, floor))
+        assert err < max(C.REL_TOL, 2 * floor), (k, err, floor)
+    worst = max(report)
+    print(f"{model} kink-free {B}x{H}^2 seed {seed}: worst gradient error {worst[2]:.2e} ({worst[1]}; reference-fp32 floor "
+          f"{worst[3]:.2e}); largest err / floor {max(r[2] / max(r[3], 1e-12) for r in report):.2f}")
+
+
+@pytest.mark.parametrize("C0,Co,dil", [(25, 50, 2), (50, 50, 4), (50, 50, 6), (50, 25, 1), (50, 50, 2)])
+def test_dilnet_layer_gradients_are_linear_exact_at_full_size(C0, Co, dil):
+    """The dilated (lattice-mode) and remainder-column weight / data gradients at dilnet's config-3 layer shapes
+    (512^2 pooled frames, 28 / 52 stored channels, split-K over 256 workgroups) WITHOUT an activation: conv -> BatchNorm
+    is differentiable everywhere, so the error against the fp64 torch graph is pure accumulation error.  Each tensor
+    within max(1e-5, 2 x the torch-fp32 floor) of its own largest entry — a 2x regression of the split-K reduction or of
+    the K-padded lattice weight gradient fails here (VERDICT r05 weak #1)."""
+    import torch.nn.functional as F
+    import torch.nn as nn
+    from atomai_amd.engine import Tape
+    torch.manual_seed(dil * 100 + C0)
+    B, H = 2, 512
+    conv = nn.Conv2d(C0, Co, 3, padding=dil, dilation=dil).cuda()
+    bn = nn.BatchNorm2d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+    x = torch.randn(B, C0, H, H, device="cuda", requires_grad=True)
+    tape = Tape(True, True)
+    n = tape.input(x)
+    o = tape.output(tape.conv([n.out], conv, bn, 1.0))
+    gy = torch.randn_like(o.value)
+    o.grad_out = gy
+    tape.backward()
+    got = [n.grad_nchw] + [tape.param_grads[id(p)][1] for p in (conv.weight, conv.bias, bn.weight, bn.bias)]
+
+    def torch_graph(dtype):
+        xr = x.detach().to(dtype).requires_grad_(True)
+        ps = [p.detach().to(dtype).requires_grad_(True) for p in (conv.weight, conv.bias, bn.weight, bn.bias)]
+        yy = F.batch_norm(F.conv2d(xr, ps[0], ps[1], padding=dil, dilation=dil), None, None, ps[2], ps[3], True)
+        return yy.detach(), torch.autograd.grad(yy, [xr] + ps, gy.to(dtype))
+    y64, g64 = torch_graph(torch.float64)
+    y32, g32 = torch_graph(torch.float32)
+    assert C.relmax(o.value.cpu().double().numpy(), y64.cpu().numpy()) < max(1e-5, 2 * C.relmax(y32.cpu().double().numpy(), y64.cpu().numpy()))
+    report = []
+    for nm, a, r64, r32 in zip(("dx", "dW", "db", "dgamma", "dbeta"), got, g64, g32):
+        # (db of conv -> BatchNorm is exactly 0 in exact arithmetic: judged on the scale of dbeta)
+        sc = max(float(r64.abs().max()), 1e-3 * float(g64[4].abs().max()))
+        err = float((a.view_as(r64).double() - r64).abs().max()) / sc
+        floor = float((r32.double() - r64).abs().max()) / sc
+        report.append((err / max(1e-5, 2 * floor), nm, err, floor))
+        assert err < max(1e-5, 2 * floor), (nm, err, floor)
+    worst = max(report)
+    print(f"dilnet layer {C0}->{Co} dilation {dil} @ {H}^2 x {B}, no activation: worst {worst[1]} error {worst[2]:.2e} "
+          f"(torch-fp32 floor {worst[3]:.2e}); dW error {report[1][2]:.2e} (floor {report[1][3]:.2e})")
+
+
 def test_config2_three_step_trajectory_vs_oracle_on_device():
     """BASELINE configs[1] at its FULL size — Segmentor U-Net nb_classes=3, 512x512, bs 32, three Adam steps — against
     oracle.seg_oracle.train_step (trainer.py:189-211 restated) executed with stock torch ops on the device (VERDICT r03

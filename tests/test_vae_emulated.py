@@ -1,9 +1,10 @@
 """`not gpu` tier for the VAE / rVAE path: kernel sources on the CPU SIMT emulator vs the reference goldens.
 
 Not executed here (device-only instruction paths; the `gpu` tier runs the same checks on them): the hardware
-exp / reciprocal form of tanh in csrc/rdecoder.hip (`rd_tanh`: the emulator build compiles the library tanhf) and the
-`v_exp_f32` form of the RBF kernel in csrc/kernel_matrix.hip (emulator: expf).  Index / layout / reduction logic is
-identical in both builds."""
+exp / reciprocal INSTRUCTIONS of tanh in csrc/rdecoder.hip (`rd_tanh`; the emulator build runs the library tanhf by
+default and, under amx_emu_set_fast_tanh(1), the same algebraic form 1 - 2 / (e^2x + 1) on expf / division —
+`test_fast_tanh_form_*` below) and the `v_exp_f32` form of the RBF kernel in csrc/kernel_matrix.hip (emulator: expf).
+Index / layout / reduction logic is identical in both builds."""
 import os
 import sys
 
@@ -86,3 +87,23 @@ def test_rdecoder_saved_activations_equal_recompute(hid, nl, skip, hw):
 
 def test_rvae_fused_latent_and_scalar_elbo_path():
     V.check_rvae_fused_latent_path("cpu")
+
+
+@pytest.fixture
+def fast_tanh():
+    import emu_backend
+    lib = emu_backend.use_emulator()
+    lib.amx_emu_set_fast_tanh(1)
+    yield
+    lib.amx_emu_set_fast_tanh(0)
+
+
+def test_fast_tanh_form_elementwise_bound(fast_tanh):
+    """The cancellation structure of the device's rd_tanh (1 - 2 / (e^2x + 1)) on the CPU tier: absolute error <= 2e-7
+    with a correctly rounded exp (the device's v_exp_f32 adds ~1 ulp of e^2x: the gpu tier holds it to the same bound)."""
+    V.check_rd_tanh_bound("cpu", 2e-7)
+
+
+@pytest.mark.parametrize("name", ["rvae16", "rvae12_rgb"])
+def test_fast_tanh_form_goldens(name, fast_tanh):
+    V.check_vae_case(name, "cpu")
