@@ -112,6 +112,15 @@ struct ConvFwdArgs {
 #ifndef AMX_CONV_GLDS
 #define AMX_CONV_GLDS 0
 #endif
+// AMX_CONV_STAGE_MAP (experiment switch, round 6): which (pixel slot, 4-channel group) a thread loads and stages.
+//   0: channel group fastest (tid & 3 = group, tid >> 2 = slot): 4 consecutive lanes read one pixel's 64 contiguous bytes; the
+//      ds_write_b128 of 8 consecutive lanes then lands on 2 slots x 4 planes whose strides are == 0 mod 32 banks — a 4-way
+//      conflict (30.5 instead of 8 LDS cycles per wave instruction, profiles/r06_lds_conflicts.md `stage_write<192, 0>`);
+//   1: 8 consecutive lanes take 8 consecutive slots of ONE group (conflict-free store; the wave still covers 16 pixels x 4
+//      groups = the same 16 cache lines per load instruction).
+#ifndef AMX_CONV_STAGE_MAP
+#define AMX_CONV_STAGE_MAP 0
+#endif
 #ifndef AMX_CONV_EPI_PAD
 #define AMX_CONV_EPI_PAD 0          // floats of padding per pixel row of the epilogue's transposition buffer; 4 removes the
                                     // 4-way bank conflict of the scalar stores but measured SLOWER in the step (18.56 ->
@@ -232,13 +241,14 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
 
     AMX_TICK(14);
     // ---- per-thread load descriptors (constant over chunks: kg = tid&3) ----
-    const int my_kg = tid & (KG - 1);
+    const int my_kg = AMX_CONV_STAGE_MAP ? ((tid >> 3) & (KG - 1)) : (tid & (KG - 1));
+    auto slot_of = [&](int i) { return AMX_CONV_STAGE_MAP ? ((tid & 7) + 8 * (tid >> 5) + 64 * i) : ((tid + i * 256) >> 2); };
     const int nslots = IH * IW;
     constexpr bool UNCOND = AMX_CONV_UNCOND_LOADS && NT <= 2;
     int x_off[XLD];                                              // pixel offset ((n*H+y)*W+x) or -1
     #pragma unroll
     for (int i = 0; i < XLD; ++i) {
-        const int pix = (tid + i * 256) >> 2;
+        const int pix = slot_of(i);
         int off = -1;
         if (pix < nslots) {
             const int iy = pix / IW, ix = pix - iy * IW;
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
         float* s_w = s_in + KG * plane * 4;
         #pragma unroll
         for (int i = 0; i < XLD; ++i) {
-            const int pix = (tid + i * 256) >> 2;
+            const int pix = slot_of(i);
             if (pix < nslots) {
                 float4 v = xr[i];
                 if (UNCOND && x_off[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -55,6 +55,9 @@ static __device__ __forceinline__ int amx_wave_uniform(int v) {
 #ifndef AMX_WS_PRODUCER_PRIO
 #define AMX_WS_PRODUCER_PRIO 3   // s_setprio of the producer waves (0 = leave the default; experiment switch)
 #endif
+#ifndef AMX_WS_STAGE_MAP
+#define AMX_WS_STAGE_MAP 0
+#endif
 #define WS_IW 18                 // input image: (16 + 2) x (16 + 2) pixel slots
 #define WS_SLOTS 324
 #define WS_CONS 8                // consumer waves (2 image rows each); as many producer waves
@@ -159,8 +162,16 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
         __builtin_amdgcn_s_setprio(AMX_WS_PRODUCER_PRIO);
 #endif
         const int ptid = tid - 64 * WS_CONS, pw = wave - WS_CONS;
+        // AMX_WS_STAGE_MAP (experiment switch, round 6): 0 = channel group fastest — 8 consecutive lanes stage 8 / G slots of
+        // G planes, a 2-way conflict of the ds_write_b128 (15 instead of 8 LDS cycles per wave instruction,
+        // profiles/r06_lds_conflicts.md `ws_stage_write`); 1 = 8 consecutive lanes take 8 consecutive slots of one plane
+#if AMX_WS_STAGE_MAP
+        const int c8 = (ptid >> 3) % G;
+        const int slot0 = (ptid & 7) + 8 * (ptid / (8 * G));
+#else
         const int c8 = ptid % G;                                  // this thread's 4-channel group (512 % G == 0)
         const int slot0 = ptid / G;                               // its slots: slot0 + i * (512 / G)
+#endif
         const int ch = c8 * 4;
         const char* src; unsigned cs_bytes;                       // this thread's source (bytes) at its channel group
         float4 r_sc = make_float4(1.f, 1.f, 1.f, 1.f), r_sh = make_float4(0.f, 0.f, 0.f, 0.f);

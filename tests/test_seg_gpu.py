@@ -137,26 +137,35 @@ def test_full_width_vs_oracle_on_device(model, ncls, B, H):
           f"floor {worst[3]:.2e}, kink sensitivity {worst[4]:.2e})")
 
 
-@pytest.mark.parametrize("model,ncls,B,H,seed", [("dilnet", 1, 1, 32, 71), ("dilnet", 1, 1, 32, 77),
-                                                 ("ResHedNet", 3, 1, 16, 113), ("ResHedNet", 3, 1, 16, 114)])
-def test_full_width_kink_free_vs_oracle(model, ncls, B, H, seed):
+@pytest.mark.parametrize("model,ncls,B,H,seed0", [("dilnet", 1, 1, 32, 71), ("dilnet", 1, 1, 32, 77),
+                                                  ("ResHedNet", 3, 1, 16, 113), ("ResHedNet", 3, 1, 16, 200)])
+def test_full_width_kink_free_vs_oracle(model, ncls, B, H, seed0):
     """the full-size dilnet / ResHedNet gradient tests pass through a kink allowance (`sens`); is the
     excess over the reference's fp32 floor really LeakyReLU branch flips, or an accumulation problem of the lattice / K-padded
     weight gradients?  Default-WIDTH nets (25 / 50 and 64 / 128 / 256 filters) on an input whose every LeakyReLU
-    pre-activation is at least 2e-5 away from 0 (seeds found by drawing until `seg_oracle.min_abs_preactivation` says so
-    — a frame is small enough for such a draw to exist: the full-size frames hold ~7 pre-activations per million inside
-    1e-5 of the kink).  No branch can flip, so NO `sens` term: every gradient within max(1e-4, 2 x the floor the oracle's
-    own fp32 run shows against fp64), normalised globally as in the full-size test."""
+    pre-activation is at least 2e-5 away from 0: seeds are drawn from `seed0` on until the oracle's forward pass ON THIS
+    DEVICE says so (`seg_oracle.min_abs_preactivation`; the smallest pre-activation of a deep net moves by ~1e-5 between
+    hosts, so the seed is found where the test runs — a frame is small enough for such a draw to exist: the full-size
+    frames hold ~7 pre-activations per million inside 1e-5 of the kink).  No branch can flip, so NO `sens` term: every
+    gradient within max(1e-4, 2 x the floor the oracle's own fp32 run shows against fp64), normalised globally as in the
+    full-size test.  Measured (profiles/r06_fullsize_parity_probe.log): dilnet 7.6e-7 against a floor of 6.5e-7 — the
+    full-size excess is branch flips, not accumulation."""
     import atomai_amd as aoi
     from oracle import seg_oracle as so
-    torch.manual_seed(seed)
-    net, _ = aoi.nets.init_fcnn_model(model, ncls)
-    sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
-    rs = np.random.RandomState(seed)
-    x = torch.from_numpy(rs.rand(B, 1, H, H).astype(np.float32))
-    y = (torch.from_numpy(rs.randint(0, ncls, (B, H, H))) if ncls > 1
-         else torch.from_numpy((rs.rand(B, 1, H, H) > 0.5).astype(np.float32)))
-    assert so.min_abs_preactivation(model, sd, x) > 1e-5
+    for seed in range(seed0, seed0 + 400):
+        torch.manual_seed(seed)
+        net, _ = aoi.nets.init_fcnn_model(model, ncls)
+        sd = OrderedDict((k, v.clone()) for k, v in net.state_dict().items())
+        rs = np.random.RandomState(seed)
+        x = torch.from_numpy(rs.rand(B, 1, H, H).astype(np.float32))
+        y = (torch.from_numpy(rs.randint(0, ncls, (B, H, H))) if ncls > 1
+             else torch.from_numpy((rs.rand(B, 1, H, H) > 0.5).astype(np.float32)))
+        sdc = OrderedDict((k, v.cuda()) for k, v in sd.items())
+        if so.min_abs_preactivation(model, sdc, x.cuda()) > 2e-5 and \
+                so.min_abs_preactivation(model, so.cast(sdc, torch.float64), x.double().cuda()) > 2e-5:
+            break
+    else:
+        pytest.fail("no kink-free draw in 400 seeds")
     net.cuda().train()
     loss = aoi.losses_metrics.select_loss("ce", ncls)(net(x.cuda()), y.cuda())
     loss.backward()

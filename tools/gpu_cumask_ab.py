@@ -3,9 +3,13 @@
 hipExtStreamCreateWithCUMask (k CUs, two bit layouts), the persistent weight-gradient grids sized to the mask
 (AMX_WGRAD_WGS = k), and optionally the whole main chain on the complementary mask.
 
-  python tools/gpu_cumask_ab.py [variant ...]     variant = side:<layout><k>[,wgs:<n>][,main:comp|<layout><k>]
+  python tools/gpu_cumask_ab.py [variant ...]     variant = side:<layout><k>[,wgs:<n>][,main:t|comp|<layout><k>]
      layout `f` = the first k mask bits (k / 8 CUs of every XCD — the KFD deals mask bits round-robin over the XCDs,
-     tools/micro/cumask_probe.hip), layout `x` = k / 32 whole XCDs;  `base` = the product (unmasked side stream).
+     tools/micro/cumask_probe.hip: honoured), layout `x` = k / 32 whole XCDs (the probe shows such a mask is IGNORED:
+     all 256 CUs);  `base` = the product (torch's default stream + an unmasked non-blocking side stream).
+     main:t = the whole step on a non-blocking torch stream.  hipExtStreamCreateWithCUMask makes a BLOCKING stream
+     (it synchronises with the legacy null stream, which is torch's default stream), so every masked variant must keep the
+     main chain off the null stream — the first run of this tool did not and measured 28.7 ms for a FULL mask.
 """
 import ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,9 +37,10 @@ def masked_stream(bits):
     return torch.cuda.ExternalStream(s.value)
 
 
-DEFAULT = ["base", "side:f64,wgs:64", "side:f96,wgs:96", "side:f128,wgs:128", "side:f192,wgs:192", "side:x64,wgs:64",
-           "side:x128,wgs:128", "side:f128,wgs:256", "side:f128,wgs:128,main:comp", "side:f96,wgs:96,main:comp",
-           "side:f64,wgs:64,main:comp", "side:f256,wgs:256"]
+DEFAULT = ["base", "main:t", "main:t,side:f256,wgs:256", "main:t,side:f224,wgs:224", "main:t,side:f192,wgs:192",
+           "main:t,side:f128,wgs:128", "main:t,side:f96,wgs:96", "main:t,side:f64,wgs:64", "main:t,side:f128,wgs:256",
+           "main:t,side:f192,wgs:256", "main:comp,side:f128,wgs:128", "main:comp,side:f96,wgs:96", "main:comp,side:f64,wgs:64",
+           "main:f224,side:f256,wgs:256"]
 variants = sys.argv[1:] or DEFAULT
 rs = np.random.RandomState(0)
 X = rs.rand(64, 512, 512).astype(np.float32); y = rs.randint(0, 3, (64, 512, 512))
@@ -58,10 +63,13 @@ def configure(v):
     engine._SIDE_STREAMS[(dev.index, 0)] = side
     main = None
     if "main" in kv:
-        key = ("m", kv["main"], kv.get("side"))
+        key = ("m", kv["main"], kv.get("side") if kv["main"] == "comp" else None)
         if key not in streams:
-            bits = [not b for b in mask_bits(kv["side"])] if kv["main"] == "comp" else mask_bits(kv["main"])
-            streams[key] = masked_stream(bits)
+            if kv["main"] == "t":
+                streams[key] = torch.cuda.Stream()
+            else:
+                bits = [not b for b in mask_bits(kv["side"])] if kv["main"] == "comp" else mask_bits(kv["main"])
+                streams[key] = masked_stream(bits)
         main = streams[key]
     return main
 

@@ -14,7 +14,7 @@
 //   ws_stage_write<G,PLANE> conv_ws.hip producers: c8 = tid % G, slot = tid / G
 //   epi_store<NBE>          epilogue transpose, scalar ds_write_b32 at ((4 g + r) * NBE + q * 16 + p) * 4 B; NBE = 32, 36
 //   epi_read<NBE>           its b128 read-back: consecutive lanes, consecutive 16-B groups
-//   hand_store              conv_ws.hip hand-over: ds_write_b128 at ((q * 16 + p) * 260 + row * 16 + 4 g) * 4 B
+//   hand_store<PS>          conv_ws.hip hand-over: ds_write_b128 at ((q * 16 + p) * PS + row * 16 + 4 g) * 4 B (product: PS = 260)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define ITER 4096
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void epi_read(float* out) {
     if (acc == 1.2345f) out[0] = acc;
 }
 
+template <int PS>
 __global__ __launch_bounds__(512) void hand_store(float* out) {
     extern __shared__ float s1[];
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(512) void hand_store(float* out) {
         for (int m = 0; m < 2; ++m)
             #pragma unroll
             for (int q = 0; q < 2; ++q)
-                *reinterpret_cast<float4*>(s1 + (q * 16 + p) * 260 + (wave * 2 + m) * 16 + 4 * g) = make_float4(it, m, q, 0);
+                *reinterpret_cast<float4*>(s1 + (q * 16 + p) * PS + (wave * 2 + m) * 16 + 4 * g) = make_float4(it, m, q, 0);
         asm volatile("" ::: "memory");
     }
     __syncthreads();
@@ -177,6 +178,11 @@ int main() {
     RUN((epi_store<36>), 256, 4 * 2 * 16 * 36 * 4);
     RUN((epi_read<32>), 256, 4 * 2 * 16 * 36 * 4);
     RUN((epi_read<36>), 256, 4 * 2 * 16 * 36 * 4);
-    RUN(hand_store, 512, 32 * 260 * 4);
+    RUN((hand_store<260>), 512, 32 * 288 * 4);
+    RUN((hand_store<264>), 512, 32 * 288 * 4);
+    RUN((hand_store<268>), 512, 32 * 288 * 4);
+    RUN((hand_store<272>), 512, 32 * 288 * 4);
+    RUN((hand_store<276>), 512, 32 * 288 * 4);
+    RUN((hand_store<288>), 512, 32 * 288 * 4);
     return 0;
 }
