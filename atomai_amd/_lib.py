@@ -93,13 +93,21 @@ def is_test_backend() -> bool:
 # ---- launch-plan switches (csrc/knobs.hip): the library resolves its AMX_* environment variables ONCE; the host side
 # reads the same resolved table, so a switch has one value per process no matter who asks.
 _knob_cache = {}
+_knob_generation = [-1]
 
 
 def knob(name: str) -> int:
-    """Resolved value of the library switch ``name`` (an AMX_* environment name of csrc/knobs.hip)."""
+    """Resolved value of the library switch ``name`` (an AMX_* environment name of csrc/knobs.hip).  Values are cached
+    per GENERATION of the library's table (amx_knobs_generation): a reload through any handle of the library — not only
+    ``reload_knobs`` below — invalidates the cache, so host and library cannot disagree about a switch."""
+    lib = load()
+    gen = lib.amx_knobs_generation()
+    if gen != _knob_generation[0]:
+        _knob_cache.clear()
+        _knob_generation[0] = gen
     v = _knob_cache.get(name)
     if v is None:
-        v = load().amx_knob(name.encode())
+        v = lib.amx_knob(name.encode())
         if v == -2 ** 31:
             raise AmxError(f"{name} is not a switch of libatomai_amd (see amx_knob_name / DESIGN.md §4)")
         _knob_cache[name] = v

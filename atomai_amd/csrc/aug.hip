@@ -398,7 +398,7 @@ __global__ void aug_onehot_kernel(const long long* __restrict__ t, float* __rest
     }
 }
 extern "C" int amx_aug_onehot(const long long* t, float* masks, int N, int K, long HW, void* stream) {
-    if (!t || !masks || N <= 0 || K < 2 || K > 8 || HW <= 0) AMX_BADARG(1);
+    if (!t || !masks || N <= 0 || K < 2 || K > 32 || HW <= 0) AMX_BADARG(1);   // (the class-presence word of amx_aug_squeeze has 32 bits)
     long nb = ((long)N * K * HW + 255) / 256;
     if (nb > 16384) nb = 16384;
     AMX_LAUNCH(aug_onehot_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, t, masks, N, K, HW);
@@ -419,7 +419,7 @@ __global__ void aug_squeeze_kernel(const float* __restrict__ m, long long* __res
     }
 }
 extern "C" int amx_aug_squeeze(const float* masks, long long* out, int* values, int N, int K, long HW, void* stream) {
-    if (!masks || !out || N <= 0 || K < 2 || K > 8 || HW <= 0) AMX_BADARG(1);
+    if (!masks || !out || N <= 0 || K < 2 || K > 32 || HW <= 0) AMX_BADARG(1);   // (the class-presence word of amx_aug_squeeze has 32 bits)
     long nb = ((long)N * HW + 255) / 256;
     if (nb > 16384) nb = 16384;
     AMX_LAUNCH(aug_squeeze_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, masks, out, values, N, K, HW);

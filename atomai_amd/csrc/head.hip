@@ -514,7 +514,12 @@ __global__ __launch_bounds__(256) void iou_hist_generic_kernel(const float* __re
                                                                const float* __restrict__ tf, int* __restrict__ hist,
                                                                long HW, int K, float thresh, int blocks_per_img,
                                                                int activation) {
+    // K <= 32: the block's K x K counts are privatised in LDS (integer atomics: exact, order independent) and reach the
+    // global histogram once per block and bin — one global atomic per PIXEL contended on a few hot bins
+    __shared__ int s_hist[32 * 32];
     const int tid = threadIdx.x;
+    const bool priv = K <= 32;
+    if (priv) { for (int i = tid; i < K * K; i += 256) s_hist[i] = 0; __syncthreads(); }
     const int n = blockIdx.x / blocks_per_img, b = blockIdx.x - n * blocks_per_img;
     for (long hw = (long)b * 256 + tid; hw < HW; hw += (long)blocks_per_img * 256) {
         const float* xp = x + (size_t)n * K * HW + hw;
@@ -531,7 +536,15 @@ __global__ __launch_bounds__(256) void iou_hist_generic_kernel(const float* __re
         }
         if (pred > K - 1) pred = 0;
         const long t = ti ? (long)ti[(size_t)n * HW + hw] : (long)tf[(size_t)n * HW + hw];
-        if (t >= 0 && t < K) atomicAdd(&hist[((size_t)n * K + (int)t) * K + pred], 1);
+        if (t >= 0 && t < K) {
+            if (priv) atomicAdd(&s_hist[(int)t * K + pred], 1);
+            else atomicAdd(&hist[((size_t)n * K + (int)t) * K + pred], 1);
+        }
+    }
+    if (priv) {
+        __syncthreads();
+        for (int i = tid; i < K * K; i += 256)
+            if (s_hist[i]) atomicAdd(&hist[(size_t)n * K * K + i], s_hist[i]);
     }
 }
 

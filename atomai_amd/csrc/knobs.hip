@@ -32,6 +32,7 @@ constexpr int kNumRows = (int)(sizeof(kRows) / sizeof(kRows[0]));
 
 std::mutex g_mu;
 std::atomic<const AmxKnobs*> g_knobs{nullptr};
+std::atomic<long> g_generation{0};       // bumped by every (re-)resolution: host-side caches of amx_knob values key on it
 
 const AmxKnobs* resolve_locked() {
     AmxKnobs* k = new AmxKnobs();          // immutable once published; a reload leaks the previous few dozen bytes on
@@ -40,6 +41,7 @@ const AmxKnobs* resolve_locked() {
         k->*(r.field) = (e && *e) ? atoi(e) : r.def;
     }
     g_knobs.store(k, std::memory_order_release);
+    g_generation.fetch_add(1, std::memory_order_release);
     return k;
 }
 }  // namespace
@@ -60,6 +62,11 @@ extern "C" int amx_knobs_reload(void) {
     resolve_locked();
     return 0;
 }
+
+// Number of times the table has been resolved (1 after the first launch; +1 per amx_knobs_reload, whoever called it): a
+// host-side cache of amx_knob values is valid for one generation (atomai_amd/_lib.py kept a cache that a
+// reload through another handle of this library left stale).
+extern "C" long amx_knobs_generation(void) { amx_knobs(); return g_generation.load(std::memory_order_acquire); }
 
 // Value of one resolved switch by its environment name; INT_MIN for a name the library does not know.
 extern "C" int amx_knob(const char* name) {

@@ -683,6 +683,9 @@ class UpConvNode(ConvNode):
         if g is None:
             return
         s0 = self.srcs[0]
+        # the stand-in below carries a GRADIENT where ConvNode.backward expects an activation: safe only because a linear
+        # convolution (no BatchNorm, no LeakyReLU, no dropout) never reads its own output in backward
+        assert self.bn is None and self.slope == 1.0 and self.post_slope == 1.0 and self.mask is None
         dv = _empty((s0.N, s0.H, s0.W, hi.Cs), g)
         L.call("amx_upsample2x_bwd", L.ptr(g), L.ptr(dv), s0.N, s0.H, s0.W, hi.Cs, self.up_mode, _sp(g))
         lo = Act(dv, self.cout, needs_grad=True)             # the low-resolution convolution output's stand-in: only its

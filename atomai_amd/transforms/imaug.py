@@ -67,6 +67,9 @@ class datatransform:
             raise NotImplementedError(f"augmentation {bad} is not available on the device path (host-code "
                                       "transforms, see atomai_amd/transforms/imaug.py)")
         self.ch = n_channels
+        if n_channels is not None and n_channels > 31:
+            # the label kernels keep one presence bit per class in a 32-bit word (csrc/aug.hip: amx_aug_labels / _squeeze)
+            raise NotImplementedError(f"datatransform on the device supports up to 31 classes (n_channels={n_channels})")
         self.custom_transform = kwargs.get("custom_transform")
         if self.custom_transform is not None and not callable(self.custom_transform):
             raise TypeError("custom_transform must be a callable (images, targets) -> (images, targets)")

@@ -11,7 +11,11 @@ def img_resize(image_data: np.ndarray, rs: Tuple[int], round_: bool = False) -> 
     against cv2 itself — absent from this image; oracle/aug_oracle.py:img_resize is the checker).  Reference quirks kept:
     ``rs`` is swapped when its entries differ (img.py:36-37); a stack that already has the target shape is copied; per
     image INTER_AREA is chosen when the height is below the target's second entry, INTER_CUBIC otherwise (img.py:63-64);
-    float64 result.  True area averaging (INTER_AREA with both axes shrunk: non-square targets only) is not provided."""
+    float64 result.  True area averaging (INTER_AREA with both axes shrunk: non-square targets only) is not provided.
+    Precision: the stack is resampled in fp32 on the device whatever its dtype (cv2 keeps CV_64F data in double), so a
+    float64 input agrees with a double-precision evaluation of the same arithmetic to ~1e-6 of the data range — a
+    TOLERANCE, not bit-level parity (tests/test_oracle_aug_resize.py states it); there is no cv2 in this image to
+    generate a golden from."""
     import torch
     from .. import _lib as L
     rs = tuple(int(v) for v in rs)

@@ -34,8 +34,12 @@ int amx_clear_error(void);
  * every launch reads afterwards — no getenv on the launch path, the same plan on every host thread / stream.
  *   amx_knob(name)      value of the resolved switch `name` ("AMX_CONV_WS", ...); INT_MIN for an unknown name
  *   amx_knob_count()    number of rows;  amx_knob_name(i)  environment name of row i (NULL out of range)
- *   amx_knobs_reload()  re-reads the environment: the hook of in-process A/B scripts and plan-comparison tests */
+ *   amx_knobs_reload()  re-reads the environment: the hook of in-process A/B scripts and plan-comparison tests
+ *   amx_knobs_generation()  how often the table has been resolved so far (a cache of amx_knob values holds for one value)
+ * Parsing: a variable that is unset OR empty takes the row's default; anything else goes through atoi (so "0" is a value,
+ * "" is not — rounds 1-4 read "" as 0). */
 int amx_knob(const char* name);
+long amx_knobs_generation(void);
 int amx_knob_count(void);
 const char* amx_knob_name(int i);
 int amx_knobs_reload(void);

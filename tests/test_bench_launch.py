@@ -70,6 +70,11 @@ def test_plain_command_self_launches_eight_ranks():
     # whole-job value = 8 ranks x bs 2 x steps / the slowest rank's region
     assert abs(out["value"] - 8 * 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-3 * out["value"] + 0.006
     assert max(out["per_rank_ms_per_step"]) <= out["ms_per_step"] * 1.001 + 1e-3
+    # first-contact fields (how to read them: DESIGN.md section 4 "First 8-GPU run")
+    assert set(out["allreduce_ms_percentiles"]) == {"p50", "p90", "p99", "max"}
+    assert out["allreduce_ms_percentiles"]["p50"] <= out["allreduce_ms_percentiles"]["max"]
+    assert len(out["host_enqueue_ms_per_step_per_rank"]) == 8 and all(v > 0 for v in out["host_enqueue_ms_per_step_per_rank"])
+    assert "xgmi_seen" in out and "sclk_mhz_per_rank_min_median_max" in out and out["per_rank_spread_rel"] >= 0
 
 
 @pytest.mark.timeout(600)
