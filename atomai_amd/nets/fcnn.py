@@ -27,10 +27,32 @@ class _HipNet(nn.Module):
                 _warned_modular = True
                 import warnings
                 warnings.warn("a forward hook is attached to a block of this network: the forward pass runs block by block "
-                              "(each block on its HIP kernels, pooling / concatenation through ATen) instead of the fused "
-                              "single-tape path, so that the hook sees its block's input and output", RuntimeWarning)
+                              "(every block, pooling and the final 1x1 convolution on their HIP kernels; torch.cat only moves "
+                              "data) instead of the fused single-tape path, so that the hook sees its block's input and "
+                              "output", RuntimeWarning)
             return self._modular(x)
         return run_tape(self._build, x, list(self.parameters()), self.training)
+
+
+def _hip_pool(x: torch.Tensor, training: bool) -> torch.Tensor:
+    """2x2 max-pooling of an NCHW tensor on the HIP pooling kernels (the glue of the block-by-block path)."""
+    def build(tape, xin):
+        node = tape.input(xin)
+        return node, tape.output(tape.pool(node.out))
+    return run_tape(build, x, [], training)
+
+
+def _hip_px(x: torch.Tensor, px: nn.Conv2d, training: bool) -> torch.Tensor:
+    """The final 1x1 convolution to class logits on the HIP px kernel (not nn.Conv2d -> MIOpen), invoked through the
+    module's own ``__call__`` so that hooks attached to it (get_downsample_factor hooks every top-level child) still fire."""
+    def build(tape, xin):
+        node = tape.input(xin)
+        return node, tape.px(node.out, px, 0)
+    px.forward = lambda xin: run_tape(build, xin, list(px.parameters()), training)     # instance attribute, for one call
+    try:
+        return px(x)
+    finally:
+        del px.forward
 
 
 class Unet(_HipNet):
@@ -84,18 +106,17 @@ class Unet(_HipNet):
         return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
 
     def _modular(self, x):
-        import torch.nn.functional as F   # only glue between separately-emitted HIP blocks
         c1 = self.c1(x)
-        d1 = F.max_pool2d(c1, 2, 2)
+        d1 = _hip_pool(c1, self.training)
         c2 = self.c2(d1)
-        d2 = F.max_pool2d(c2, 2, 2)
+        d2 = _hip_pool(c2, self.training)
         c3 = self.c3(d2)
-        d3 = F.max_pool2d(c3, 2, 2)
+        d3 = _hip_pool(c3, self.training)
         bn = self.bn(d3)
         u3 = self.c4(torch.cat([c3, self.upsample_block1(bn)], dim=1))
         u2 = self.c5(torch.cat([c2, self.upsample_block2(u3)], dim=1))
         u1 = self.c6(torch.cat([c1, self.upsample_block3(u2)], dim=1))
-        return self.px(u1)
+        return _hip_px(u1, self.px, self.training)
 
 
 class dilnet(_HipNet):
@@ -133,11 +154,10 @@ class dilnet(_HipNet):
         return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
 
     def _modular(self, x):
-        import torch.nn.functional as F
         c1 = self.c1(x)
-        d1 = F.max_pool2d(c1, 2, 2)
+        d1 = _hip_pool(c1, self.training)
         u1 = self.up1(self.at2(self.at1(d1)))
-        return self.px(self.c2(torch.cat([c1, u1], dim=1)))
+        return _hip_px(self.c2(torch.cat([c1, u1], dim=1)), self.px, self.training)
 
 
 class ResHedNet(_HipNet):
@@ -172,6 +192,9 @@ class ResHedNet(_HipNet):
         return node, tape.px(cat, self.out, px_mode)
 
     def _modular(self, x):
+        # (hook path only: the side-output heads — pooling inside net2 / net3, three 1x1 convolutions on nb_classes channels,
+        #  their interpolation and the fusing 1x1 convolution — are stock torch modules here; the residual modules, which
+        #  hold the work, run on their HIP kernels.  The product path is _build.)
         import torch.nn.functional as F
         h, w = x.shape[2:4]
         n1 = self.net1(x)
@@ -216,13 +239,12 @@ class SegResNet(_HipNet):
         return node, tape.px(u1, self.px, px_mode)
 
     def _modular(self, x):
-        import torch.nn.functional as F
         c1 = self.c1(x)
-        c2 = self.c2(F.max_pool2d(c1, 2, 2))
-        bn = self.bn(F.max_pool2d(c2, 2, 2))
+        c2 = self.c2(_hip_pool(c1, self.training))
+        bn = self.bn(_hip_pool(c2, self.training))
         u2 = self.c3(torch.cat([c2, self.upsample_block1(bn)], dim=1))
         u1 = self.c4(torch.cat([c1, self.upsample_block2(u2)], dim=1))
-        return self.px(u1)
+        return _hip_px(u1, self.px, self.training)
 
 
 def init_fcnn_model(model: Union[Type[nn.Module], str], nb_classes: int, **kwargs):

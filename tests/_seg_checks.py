@@ -760,3 +760,33 @@ def check_upconv_node(device, hw=32, batch=2):
         for i, (a, b) in enumerate(zip(out[0][0], out[1 << 40][0])):
             assert torch.equal(a, b), (model, i, float((a - b).abs().max()))
 
+
+
+def check_hooked_forward_equals_fused(device, models=(("Unet", 3), ("dilnet", 1), ("SegResNet", 3), ("ResHedNet", 1))):
+    """A forward hook on any block switches the nets to the block-by-block path (utils/nn.py get_downsample_factor relies on
+    it); pooling and the final 1x1 convolution of that path run on the HIP nodes as well.  Same logits as
+    the fused single-tape path, and gradients reach every parameter."""
+    import warnings
+    from atomai_amd.nets import init_fcnn_model
+    for model, ncls in models:
+        torch.manual_seed(3)
+        net, _ = init_fcnn_model(model, ncls, nb_filters=4)
+        net.to(device).train()
+        x = torch.from_numpy(np.random.RandomState(3).rand(2, 1, 16, 16).astype(np.float32)).to(device)
+        ref = net(x)
+        seen = []
+        first = next(iter(net.children()))
+        h = first.register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for m in net.modules():                       # same batch statistics again: running stats do not matter
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        m.momentum = 0.0
+                out = net(x)
+        finally:
+            h.remove()
+        assert seen, model
+        assert float((out - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), model
+        out.sum().backward()
+        assert all(p.grad is not None for p in net.parameters()), model

@@ -213,3 +213,7 @@ def test_remainder_column_classes_vs_padded_plan():
 
 def test_upsample_block_as_one_launch_inside_the_nets():
     C.check_upconv_node("cpu")
+
+
+def test_hooked_block_by_block_forward_equals_fused():
+    C.check_hooked_forward_equals_fused("cpu")

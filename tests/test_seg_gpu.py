@@ -519,3 +519,7 @@ def test_upsample_block_as_one_launch_inside_the_nets():
 def test_upsample_block_forward_in_one_pass_is_bit_identical():
     C.check_upconv_fused_kernel("cuda")
     C.check_upconv_fused_kernel("cuda", cases=((50, 25, 3, 512, 512, 0), (32, 16, 8, 256, 256, 0), (128, 64, 4, 64, 64, 1)))
+
+
+def test_hooked_block_by_block_forward_equals_fused():
+    C.check_hooked_forward_equals_fused("cuda")
