@@ -22,6 +22,16 @@ bool amx_lattice_mode(int taps, int dil) {
     return amx_knobs().conv_lattice != 0;
 }
 
+// Stride of the x-packed lattice tiles for an image width and dilation (conv_kernel.h, ConvFwdArgs::xpack), 0 when the
+// launch keeps one sub-image per tile axis: packing must save tile columns, and launches that write batch statistics
+// keep the residue-class row order the merge kernels expect.
+static int lattice_xpack(int W, int dil, bool has_stats) {
+    if (!amx_knobs().conv_xpack || has_stats || !amx_lattice_mode(9, dil)) return 0;
+    const int P = amx_ceil_div(W, dil) + 1, packed = amx_ceil_div(dil * P - 1, TILE);
+    return (packed < dil * amx_ceil_div(amx_ceil_div(W, dil), TILE) && (long)dil * P < 65536L) ? P : 0;
+}
+extern "C" int amx_conv2d_lattice_xpack(int W, int dil, int has_stats) { return lattice_xpack(W, dil, has_stats != 0); }
+
 static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H, bool allow_rem = true) {
     ConvPlan pl;
     pl.rem = 0;
@@ -127,6 +137,7 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     // 1.282 -> 1.257 ms; plain 3x3 layers do not care (U-Net step 17.92 vs 17.93 ms, profiles/r03_conv_xcd_ab.log).
     const int xm = amx_knobs().conv_xcd;
     a.xcd = xm == 1 || (xm == 2 && amx_round_up(cout, 16) > 32) || (xm == 3 && dil > 1);
+    a.xpack = 0; a.xmagic = 0;
     a.N = N; a.H = H; a.W = W;
     a.cout = cout;
     a.cop = amx_round_up(cout, 16);
@@ -145,6 +156,12 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);
         a.dil = 1;
+        // x-packed tiles (conv_kernel.h, ConvFwdArgs::xpack): whenever they are fewer than dil tile columns per sub-image
+        // and no batch statistics are asked for (their rows are ordered by residue class) — every eval-mode launch and
+        // every data gradient of a dilated layer whose sub-image width is not a multiple of 16 (dilation 6 at 512: 33 vs 36)
+        if (const int P = lattice_xpack(W, dil, stats != nullptr)) {
+            a.xpack = P; a.xmagic = (unsigned)((4294967296ULL + P - 1) / P); a.tiles_x = amx_ceil_div(dil * P - 1, TILE);
+        }
         if (nds) {                                          // fused DilatedBlock sum: the 32-couts-per-block 8-row class only
             if (!dsum_supported(C0s + C1s, cout, taps, dil, H) || nds > 3 || stats || addend || y1 || hout) AMX_BADARG(13);
             for (int l = 0; l < nds; ++l) if (!a.ds_a[l]) AMX_BADARG(13);

@@ -92,7 +92,23 @@ struct ConvFwdArgs {
     int tiles_x, tiles_y;
     int th;              // tile height in pixels (16 or 32)
     int xcd;             // 1: XCD-aware tile order (neighbouring tiles share an L2)
+    // lattice mode, x-packed (round 6): the LAT sub-images of one residue row ry lie SIDE BY SIDE on one tile axis, stride
+    // xpack = widest sub-image + 1 (one never-stored gap column between neighbours keeps their halos apart), so a tile
+    // column no longer ends at every sub-image: dilation 6 at 512 columns = 6 x 86 -> 33 instead of 6 x 6 = 36 tile columns
+    // (12.5 % -> 3 % of the tiles' MFMA work was ragged padding).  0 = one sub-image per tile axis.  xmagic = ceil(2^32 / xpack).
+    int xpack; unsigned xmagic;
 };
+
+static __device__ __forceinline__ unsigned amx_umulhi(unsigned a, unsigned b) {
+    return (unsigned)(((unsigned long long)a * b) >> 32);
+}
+// packed lattice coordinate u -> image column (or W = "not a pixel": gap column / beyond the last sub-image)
+template <int LS>
+static __device__ __forceinline__ int amx_xpack_col(int u, int xpack, unsigned xmagic, int W) {
+    if (u < 0) return -1;
+    const int q = (int)amx_umulhi((unsigned)u, xmagic), l = u - q * xpack;
+    return (q < LS && l < (W - q + LS - 1) / LS) ? q + l * LS : W;
+}
 
 // TAIL: compiled-in support for a partial last chunk (compute_tail).  It is a separate instantiation because the
 // extra unrolled tap loop costs code and registers that the layers with channel counts in multiples of 16 need not pay.
@@ -233,7 +249,11 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
     // all tile coordinates below are then LATTICE coordinates: image (y, x) = (ry + ly*LAT, rx + lx*LAT)
     constexpr int LS = LAT ? LAT : 1;
     int ry = 0, rx = 0;
-    if (LAT) { const int rr = t % (LS * LS); t /= (LS * LS); ry = rr / LS; rx = rr - ry * LS; }
+    const int xp = LAT ? a.xpack : 0;                             // x-packed lattice tiles (ConvFwdArgs::xpack)
+    if (LAT) {
+        if (xp) { ry = t % LS; t /= LS; }
+        else { const int rr = t % (LS * LS); t /= (LS * LS); ry = rr / LS; rx = rr - ry * LS; }
+    }
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
     const int n0 = ob * NB;                                      // first cout of this workgroup
@@ -252,7 +272,8 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
         int off = -1;
         if (pix < nslots) {
             const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = ry + (gy0 + iy) * LS, gx = rx + (gx0 + ix) * LS;      // (< 0 exactly when the lattice index is)
+            const int gy = ry + (gy0 + iy) * LS;                                // (< 0 exactly when the lattice index is)
+            const int gx = (LAT && xp) ? amx_xpack_col<LS>(gx0 + ix, xp, a.xmagic, a.W) : rx + (gx0 + ix) * LS;
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) off = (n * a.H + gy) * a.W + gx;
         }
         x_off[i] = off;
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
             for (int r = 0; r < 4; ++r) {
                 float v = acc[m][q][r] + b;
                 v = v > 0.f ? v : v * a.slope;
-                const bool ok = (ry + (oy0 + m) * LS < a.H) && (rx + (ox0 + r) * LS < a.W) && co < ctot;
+                const bool ok = (ry + (oy0 + m) * LS < a.H) && ((LAT && xp) || rx + (ox0 + r) * LS < a.W) && co < ctot;
                 v = ok ? v : 0.f;
                 lsum[q] += v;
                 acc[m][q][r] = v;
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
                     v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
                     v += bias_r[q];
                     v = v > 0.f ? v : v * a.slope;
-                    const bool ok = (ry + (oy0 + m) * LS < a.H) && (rx + (tx * TILE + 4 * (p >> 2) + r) * LS < a.W) && co < ctot;
+                    const bool ok = (ry + (oy0 + m) * LS < a.H) && ((LAT && xp) || rx + (tx * TILE + 4 * (p >> 2) + r) * LS < a.W) && co < ctot;
                     v = ok ? v : 0.f;
                     lsum_r[q] += v;
                     accr[m][q][r] = v;
@@ -645,7 +666,8 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
             if ((MH * TILE * CGX) % 64 && e >= MH * TILE * CGX) continue;    // (REM: CG = 7 / 13 float4 groups per pixel)
             const int pix = e / CGX, cgp = e - pix * CGX;
             const int mm = pix / TILE, x = pix - mm * TILE;
-            const int oy = ry + (oy0 + m0 + mm) * LS, ox = rx + (tx * TILE + x) * LS;
+            const int oy = ry + (oy0 + m0 + mm) * LS;
+            const int ox = (LAT && xp) ? amx_xpack_col<LS>(tx * TILE + x, xp, a.xmagic, a.W) : rx + (tx * TILE + x) * LS;
             const int co = n0 + cgp * 4;
             if (HEAD) {
                 // the final 1x1 convolution (own BatchNorm affine folded in) on the transposed tile: each of the CG
@@ -727,7 +749,7 @@ static int launch_conv_fwd(const ConvFwdArgs& a, hipStream_t stream) {
         if (lds < epi) lds = epi;
     }
     // (REM: one cout block covers every stored channel)
-    dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? LAT * LAT : 1), REM ? 1 : amx_ceil_div(a.cop, NT * 16));
+    dim3 grid(a.tiles_x * a.tiles_y * a.N * (LAT ? (a.xpack ? LAT : LAT * LAT) : 1), REM ? 1 : amx_ceil_div(a.cop, NT * 16));
     AMX_ALLOW_160K_LDS(conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>);
     AMX_LAUNCH((conv_fwd_kernel<TAPS, NT, MAXHALO, EXACT, MTW, EPI, TAIL, LAT, REM>), grid, dim3(256), lds, stream, a);
     AMX_CHECK_LAUNCH();

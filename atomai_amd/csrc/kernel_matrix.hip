@@ -26,6 +26,9 @@ template <> struct Vec16<double> { static constexpr int N = 2; };
 template <typename T> __device__ __forceinline__ T km_exp(T x);
 template <> __device__ __forceinline__ float km_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double km_exp<double>(double x) { return exp(x); }
+template <typename T> __device__ __forceinline__ T km_fma(T a, T b, T c);
+template <> __device__ __forceinline__ float km_fma<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double km_fma<double>(double a, double b, double c) { return fma(a, b, c); }
 template <typename T> __device__ __forceinline__ T km_sqrt(T x);
 template <> __device__ __forceinline__ float km_sqrt<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double km_sqrt<double>(double x) { return sqrt(x); }
@@ -57,22 +60,36 @@ __device__ __forceinline__ T km_eval(T r2, T s2, int kind, T* w) {
 }
 
 // ------------------------------------------------------------------ K = k(X1, X2) [+ noise * I]
-// DR: register-resident embedding dimensions of a thread's columns (4, 8 or 16 >= D)
-template <typename T, int DR>
+// DR: register-resident embedding dimensions of a thread's columns (4, 8 or 16 >= D).
+// Round 6 (D = 8 ran at 0.40 of the HBM peak, VALU-bound): the dimension loop is BRANCH-FREE — both
+// coordinate images are zero-padded to DR, so the DR - D extra terms add exact zeros instead of costing a scalar
+// compare-and-branch per dimension and column (the D = 8 instantiation had 246 basic blocks) —, the squared distance is an
+// fma chain (d ascending, as before: at most one rounding per term less), the kernel family and the exp flavour are
+// template parameters, and in fp32 a thread's four columns are two PAIRS held in <2 x float> registers so that the
+// subtraction and the fma of two columns are ONE packed instruction each (v_pk_add_f32 / v_pk_fma_f32: 2 instead of 4 VALU
+// operations per dimension and column pair); a row's coordinates come from LDS as broadcast 16-byte reads.
+#ifndef AMX_EMU
+typedef float km_f2 __attribute__((ext_vector_type(2)));
+#define KM_PACKED 1
+#else
+#define KM_PACKED 0        // (the CPU emulator build is plain g++: same fma chain per column, unpacked)
+#endif
+
+template <typename T, int DR, int KIND, bool FAST>
 __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict__ X1, const T* __restrict__ X2,
-                                                            const T* __restrict__ inv_ls, T s2, int kind,
+                                                            const T* __restrict__ inv_ls, T s2,
                                                             T noise, int N, int M, int D, T* __restrict__ K,
-                                                            int km_mode) {
+                                                            int stream_stores) {
     constexpr int V = Vec16<T>::N;
     constexpr int COLS = 64 * V;                         // columns per workgroup
     constexpr int KM_ROWS = KmRows<T>::value;
-    __shared__ T s_x1[KM_ROWS * KM_MAXD];
-    __shared__ T s_x2[KM_MAXD * COLS];                   // [d][col]
+    __shared__ __attribute__((aligned(16))) T s_x1[KM_ROWS * DR];    // [row][DR], zero beyond D
+    __shared__ T s_x2[DR * COLS];                        // [d][col]
     const int tid = threadIdx.x;
     const int row0 = blockIdx.y * KM_ROWS, col0 = blockIdx.x * COLS;
-    for (int i = tid; i < KM_ROWS * D; i += 256) {
-        const int r = i / D, d = i - r * D;
-        s_x1[i] = row0 + r < N ? X1[(size_t)(row0 + r) * D + d] * inv_ls[d] : T(0);
+    for (int i = tid; i < KM_ROWS * DR; i += 256) {
+        const int r = i / DR, d = i - r * DR;
+        s_x1[i] = (d < D && row0 + r < N) ? X1[(size_t)(row0 + r) * D + d] * inv_ls[d] : T(0);
     }
     for (int i = tid; i < COLS * D; i += 256) {
         const int c = i / D, d = i - c * D;
@@ -80,46 +97,64 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
     }
     __syncthreads();
     const int cg = tid & 63, rg = tid >> 6;              // 64 column groups x 4 row groups
-    // a thread's V columns are the same for every row it writes: their scaled coordinates live in registers (DR >= D
-    // of them: 4 for dklGPR's default embedding of 2, 8 / 16 for wider ones — round 4: D = 8 ran 3x slower than D = 2
-    // through the LDS fallback, 1.7 TB/s) and the row loop only reads the row's coordinates (one broadcast LDS read per
-    // dimension) — the [d][col] reads were 8-way bank-conflicted (stride-V lanes)
+    // a thread's V columns are the same for every row it writes: their scaled coordinates live in registers
     T x2r[V][DR];
     #pragma unroll
     for (int v = 0; v < V; ++v)
         #pragma unroll
         for (int d = 0; d < DR; ++d) x2r[v][d] = d < D ? s_x2[d * COLS + cg * V + v] : T(0);
+    const int gc = col0 + cg * V;
+    const bool vec_ok = gc + V <= M && ((M * sizeof(T)) % 16 == 0);
     #pragma unroll 2
     for (int rr = 0; rr < KM_ROWS / 4; ++rr) {
         const int r = rg * (KM_ROWS / 4) + rr;
         const int gi = row0 + r;
         if (gi >= N) break;
+        T x1[DR];
+        #pragma unroll
+        for (int d = 0; d < DR; ++d) x1[d] = s_x1[r * DR + d];              // (broadcast reads, merged to b128 / b64)
+        T r2[V];
+#if KM_PACKED
+        if constexpr (sizeof(T) == 4) {
+            #pragma unroll
+            for (int j = 0; j < V / 2; ++j) {
+                km_f2 acc = {0.f, 0.f};
+                #pragma unroll
+                for (int d = 0; d < DR; ++d) {
+                    const km_f2 xc = {(float)x2r[2 * j][d], (float)x2r[2 * j + 1][d]};
+                    const km_f2 xr = {(float)x1[d], (float)x1[d]};
+                    const km_f2 df = xr - xc;
+                    acc = __builtin_elementwise_fma(df, df, acc);
+                }
+                r2[2 * j] = acc.x; r2[2 * j + 1] = acc.y;
+            }
+        } else
+#endif
+        {
+            #pragma unroll
+            for (int v = 0; v < V; ++v) {
+                T acc = T(0);
+                #pragma unroll
+                for (int d = 0; d < DR; ++d) { const T df = x1[d] - x2r[v][d]; acc = km_fma<T>(df, df, acc); }
+                r2[v] = acc;
+            }
+        }
         T out[V];
         #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const int c = cg * V + v;
-            T r2 = T(0);
-            #pragma unroll
-            for (int d = 0; d < DR; ++d) {
-                if (d >= D) break;
-                const T df = s_x1[r * D + d] - x2r[v][d];
-                r2 += df * df;
-            }
             T w;
             T k;
-            if (sizeof(T) == 4 && kind == 0 && (km_mode & 2)) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2));
-            else k = km_eval<T>(r2, s2, kind, &w);
-            if (gi == col0 + c) k += noise;
+            if constexpr (sizeof(T) == 4 && KIND == 0 && FAST) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2[v]));
+            else k = km_eval<T>(r2[v], s2, KIND, &w);
+            if (gi == gc + v) k += noise;
             out[v] = k;
         }
-        const int gc = col0 + cg * V;
         T* dst = K + (size_t)gi * M + gc;
-        if (gc + V <= M && ((M * sizeof(T)) % 16 == 0)) {
-            if (V == 4) {
-                if (km_mode & 1) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
+        if (vec_ok) {
+            if constexpr (V == 4) {
+                if (stream_stores) amx_st4_stream(reinterpret_cast<float*>(dst), *reinterpret_cast<float4*>(out));
                 else *reinterpret_cast<float4*>(dst) = *reinterpret_cast<float4*>(out);
-            }
-            else { dst[0] = out[0]; dst[1] = out[1]; }
+            } else { dst[0] = out[0]; dst[1] = out[1]; }
         } else {
             #pragma unroll
             for (int v = 0; v < V; ++v) if (gc + v < M) dst[v] = out[v];
@@ -127,24 +162,29 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
     }
 }
 
-template <typename T>
-static int launch_km(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, double noise,
-                     int N, int M, int D, void* K, hipStream_t st) {
+template <typename T, int DR>
+static int launch_km_dr(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, double noise,
+                        int N, int M, int D, void* K, hipStream_t st) {
     constexpr int COLS = 64 * Vec16<T>::N;
     dim3 grid(amx_ceil_div(M, COLS), amx_ceil_div(N, KmRows<T>::value));
-    constexpr int nt = 3;   // bit 0 streaming stores (+6..9 %), bit 1 hardware exp (profiles/r02_logs/r02w_km_ab.log)
-    if (D <= 4) {
-        AMX_LAUNCH((kernel_matrix_kernel<T, 4>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
-                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
-    } else if (D <= 8) {
-        AMX_LAUNCH((kernel_matrix_kernel<T, 8>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
-                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
+    // streaming stores (+6..9 %) and the hardware exp of the fp32 RBF builder: profiles/r02_logs/r02w_km_ab.log
+    if (kind == 0) {
+        AMX_LAUNCH((kernel_matrix_kernel<T, DR, 0, true>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2,
+                   (const T*)inv_ls, (T)s2, (T)noise, N, M, D, (T*)K, 1);
     } else {
-        AMX_LAUNCH((kernel_matrix_kernel<T, 16>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2, (const T*)inv_ls,
-                   (T)s2, kind, (T)noise, N, M, D, (T*)K, nt);
+        AMX_LAUNCH((kernel_matrix_kernel<T, DR, 1, false>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2,
+                   (const T*)inv_ls, (T)s2, (T)noise, N, M, D, (T*)K, 1);
     }
     AMX_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename T>
+static int launch_km(const void* X1, const void* X2, const void* inv_ls, double s2, int kind, double noise,
+                     int N, int M, int D, void* K, hipStream_t st) {
+    if (D <= 4) return launch_km_dr<T, 4>(X1, X2, inv_ls, s2, kind, noise, N, M, D, K, st);
+    if (D <= 8) return launch_km_dr<T, 8>(X1, X2, inv_ls, s2, kind, noise, N, M, D, K, st);
+    return launch_km_dr<T, 16>(X1, X2, inv_ls, s2, kind, noise, N, M, D, K, st);
 }
 
 extern "C" int amx_kernel_matrix(const void* X1, const void* X2, const void* inv_ls, double outputscale,

@@ -93,6 +93,10 @@ int amx_conv2d_num_tiles(int N, int H, int W, int th);
 /* Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images x[ry::d, rx::d]; their
  * statistics rows are ordered [n][ry][rx][strip][tx].  amx_conv2d_stats_lattice: d for such a layer, else 0;
  * amx_conv2d_stats_rows: the number of rows amx_conv2d_fwd writes (== amx_conv2d_num_tiles(N,H,W,tile_h) when 0). */
+/* Stride of the x-packed lattice tiles a dilated launch of this width uses (0: one residue-class sub-image per tile axis):
+ * the `dil` sub-images of a residue row share one tile axis when that saves tile columns and no statistics are written
+ * (AMX_CONV_XPACK, default 1; results are bit-identical either way). */
+int amx_conv2d_lattice_xpack(int W, int dil, int has_stats);
 int amx_conv2d_stats_lattice(int taps, int dil);
 int amx_conv2d_stats_rows(int Cin_s, int cout, int taps, int dil, int N, int H, int W);
 /* Diagnostic: launches of amx_conv2d_fwd / amx_conv2d_dgrad that the wave-specialised kernel of the thin plain-3x3

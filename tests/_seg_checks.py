@@ -790,3 +790,39 @@ def check_hooked_forward_equals_fused(device, models=(("Unet", 3), ("dilnet", 1)
         assert float((out - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), model
         out.sum().backward()
         assert all(p.grad is not None for p in net.parameters()), model
+
+
+def check_lattice_xpack_bit_identical(device, monkeypatch, cases=((52, 50, 44, 70, 2, 6), (28, 50, 37, 29, 1, 4), (52, 50, 64, 512, 1, 6))):
+    """x-packed lattice tiles (conv_kernel.h, ConvFwdArgs::xpack: the sub-images of a residue row side by side on one tile
+    axis) against one sub-image per tile axis: the eval-mode forward of a dilated layer and its data gradient — the launches
+    that write no batch statistics — must be BIT-IDENTICAL, and the packed plan must actually be the one taken."""
+    import torch.nn as nn
+    from atomai_amd import _lib as L
+    from atomai_amd.engine import Tape
+    for cin, cout, H, W, N, dil in cases:
+        assert L.load().amx_conv2d_lattice_xpack(W, dil, 0) > 0, (W, dil)
+        assert L.load().amx_conv2d_lattice_xpack(W, dil, 1) == 0
+        torch.manual_seed(W)
+        conv = nn.Conv2d(cin, cout, 3, padding=dil, dilation=dil).to(device)
+        bn = nn.BatchNorm2d(cout).to(device)
+        with torch.no_grad():
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 1.5)
+        x = torch.randn(N, cin, H, W, device=device)
+        gy = torch.randn(N, cout, H, W, device=device)
+        ys, gs = [], []
+        for knob in ("0", "1"):
+            L.set_knob("AMX_CONV_XPACK", knob)
+            tape = Tape(False, False)                            # eval forward: no statistics
+            ys.append(tape.output(tape.conv([tape.input(x).out], conv, bn, 0.01)).value.clone())
+        for knob in ("0", "1"):                                  # (after the eval passes: training updates the running statistics)
+            L.set_knob("AMX_CONV_XPACK", knob)
+            xg = x.clone().requires_grad_(True)
+            tape = Tape(True, True)                              # training: the data gradient has no statistics either
+            n = tape.input(xg)
+            o = tape.output(tape.conv([n.out], conv, None, 0.01))
+            o.grad_out = gy
+            tape.backward()
+            gs.append(n.grad_nchw.clone())
+        L.set_knob("AMX_CONV_XPACK", None)
+        assert torch.equal(ys[0], ys[1]), (cin, cout, H, W, dil, "forward")
+        assert torch.equal(gs[0], gs[1]), (cin, cout, H, W, dil, "dgrad")

@@ -217,3 +217,7 @@ def test_upsample_block_as_one_launch_inside_the_nets():
 
 def test_hooked_block_by_block_forward_equals_fused():
     C.check_hooked_forward_equals_fused("cpu")
+
+
+def test_lattice_xpack_is_bit_identical(monkeypatch):
+    C.check_lattice_xpack_bit_identical("cpu", monkeypatch, cases=((52, 50, 20, 70, 1, 6), (28, 50, 13, 29, 1, 4)))

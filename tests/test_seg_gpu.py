@@ -523,3 +523,7 @@ def test_upsample_block_forward_in_one_pass_is_bit_identical():
 
 def test_hooked_block_by_block_forward_equals_fused():
     C.check_hooked_forward_equals_fused("cuda")
+
+
+def test_lattice_xpack_is_bit_identical(monkeypatch):
+    C.check_lattice_xpack_bit_identical("cuda", monkeypatch)
