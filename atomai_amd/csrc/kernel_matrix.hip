@@ -45,6 +45,32 @@ static __device__ __forceinline__ float km_fast_exp(float x) {
 #endif
 }
 
+// exp(x) for the fp64 builder, x <= 0 (the RBF / Matern arguments): k = round(x log2 e), r = x - k ln 2 in two pieces
+// (|r| <= 0.347), a degree-13 Taylor polynomial in Horner form (remainder r^14 / 14! < 5e-18: below half an ulp), scaled by
+// 2^k with v_ldexp_f64 (denormal results and the underflow to 0 below x = -745 come out of the instruction).  ~20 fp64
+// instructions and no branches; the device library's exp was ~2/3 of the instructions of an fp64 covariance element
+// (round 6: 0.613 -> see profiles/r06_bench_extra.log).  Relative error <= 2 ulp (tests/_gp_checks.py compares the
+// builder with numpy's exp in fp64 at 1e-14).
+static __device__ __forceinline__ double km_exp_neg(double x) {
+#ifdef AMX_EMU
+    return exp(x);
+#else
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);          // ln2 high part (32 trailing zero bits)
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);                   // ln2 low part
+    // Horner steps as v_fma_f64 with the coefficient in an SGPR pair: the compiler's choice, v_fmac_f64 (d += a * b), needs a
+    // v_mov_b64 of the coefficient into the destination before every step — 13 moves per element
+    double p = 1.0 / 6227020800.0;                                          // 1/13!
+#define KM_HORNER(c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"((double)(c)))
+    KM_HORNER(1.0 / 479001600.0); KM_HORNER(1.0 / 39916800.0); KM_HORNER(1.0 / 3628800.0); KM_HORNER(1.0 / 362880.0);
+    KM_HORNER(1.0 / 40320.0); KM_HORNER(1.0 / 5040.0); KM_HORNER(1.0 / 720.0); KM_HORNER(1.0 / 120.0);
+    KM_HORNER(1.0 / 24.0); KM_HORNER(1.0 / 6.0); KM_HORNER(0.5); KM_HORNER(1.0); KM_HORNER(1.0);
+#undef KM_HORNER
+    const double kk = k < -2000.0 ? -2000.0 : k;                            // (the int conversion must not overflow)
+    return __builtin_amdgcn_ldexp(p, (int)kk);
+#endif
+}
+
 template <typename T>
 __device__ __forceinline__ T km_eval(T r2, T s2, int kind, T* w) {
     if (kind == 0) {
@@ -145,6 +171,11 @@ __global__ __launch_bounds__(256) void kernel_matrix_kernel(const T* __restrict_
             T w;
             T k;
             if constexpr (sizeof(T) == 4 && KIND == 0 && FAST) k = (T)((float)s2 * km_fast_exp(-0.5f * (float)r2[v]));
+            else if constexpr (sizeof(T) == 8 && KIND == 0 && FAST) k = (T)((double)s2 * km_exp_neg(-0.5 * (double)r2[v]));
+            else if constexpr (sizeof(T) == 8 && KIND == 1 && FAST) {
+                const double sq5 = 2.23606797749978969641, r = sqrt((double)r2[v]);
+                k = (T)((double)s2 * (1.0 + sq5 * r + (5.0 / 3.0) * (double)r2[v]) * km_exp_neg(-sq5 * r));
+            }
             else k = km_eval<T>(r2[v], s2, KIND, &w);
             if (gi == gc + v) k += noise;
             out[v] = k;
@@ -172,7 +203,7 @@ static int launch_km_dr(const void* X1, const void* X2, const void* inv_ls, doub
         AMX_LAUNCH((kernel_matrix_kernel<T, DR, 0, true>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2,
                    (const T*)inv_ls, (T)s2, (T)noise, N, M, D, (T*)K, 1);
     } else {
-        AMX_LAUNCH((kernel_matrix_kernel<T, DR, 1, false>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2,
+        AMX_LAUNCH((kernel_matrix_kernel<T, DR, 1, sizeof(T) == 8>), grid, dim3(256), 0, st, (const T*)X1, (const T*)X2,
                    (const T*)inv_ls, (T)s2, (T)noise, N, M, D, (T*)K, 1);
     }
     AMX_CHECK_LAUNCH();

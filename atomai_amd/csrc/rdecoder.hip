@@ -93,6 +93,9 @@ extern "C" int amx_rdec_set_profile_buffer(void* buf) { amx_rdec_profile_buffer 
 #ifndef RD_FWD_WPIPE
 #define RD_FWD_WPIPE 1        // forward kernel: the next layer's weight fragments are fetched behind the current layer's MFMAs (0 = at its start)
 #endif
+#ifndef RD_FWD_ASYM
+#define RD_FWD_ASYM 0         // experiment switch (round 6): asymmetric pair of co-resident forward workgroups, see the kernel
+#endif
 #define RD_PLANES(NL_) ((NL_) + (RD_SAVE_H0 ? 1 : 0))
 #define MAXL 32           // latent dimensions (content latents + one-hot classes) the kernels keep in LDS
 #define MAXC 4            // output channels the kernels are written for (grey-scale and RGB(A) patches)
@@ -362,6 +365,22 @@ __global__ __launch_bounds__(4 * HID) void rdecoder_fwd_kernel(RDecArgs a) {
     float* s_wo = s_wc + 2 * HID;                     // [MAXC][HID]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bidx = blockIdx.x;
+#if RD_FWD_ASYM && !defined(AMX_EMU)
+    // Two workgroups share a CU (106 registers, 75 KB of LDS each) and run the SAME phase sequence from the same start: their
+    // VALU phases (coordinate layer, tanh epilogues, output layer) coincide and the matrix pipe idles under both, then both
+    // want it at once.  Lock step is an attractor with fair arbitration (the workgroup that falls behind gets the pipe to
+    // itself and catches up).  RD_FWD_ASYM makes the pair asymmetric — the workgroup in the CU's SECOND LDS slot (non-zero
+    // LDS base in HW_REG_LDS_ALLOC) either runs at raised wave priority (1: it takes the pipe whenever it wants it, the other
+    // one fills its VALU gaps) or starts half a tile late (2) — so that one's matrix phase falls into the other's VALU phase.
+    {
+        unsigned la;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
+        if ((la & 0xfffu) != 0) {
+            if (RD_FWD_ASYM == 1) __builtin_amdgcn_s_setprio(2);
+            else for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(100);
+        }
+    }
+#endif
     latent_bias<HID>(a, bidx, s_zc, s_z, s_th, tid, s_wc, s_wo);
     const float* th = a.theta ? s_th : nullptr;
     WFrag<HID> wf;
