@@ -8,6 +8,7 @@ extern "C" int amx_conv_set_profile_buffer(void* buf) { amx_conv_profile_buffer 
 #endif
 
 struct ConvPlan { int nt, th, rem; };
+extern "C" int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil);
 
 // Tile plan, from the per-shape measurements in profiles/r01_conv_variants.md: this kernel is fastest with MANY
 // small co-resident workgroups (they hide each other's prologue / staging / epilogue), so the default tile is
@@ -91,7 +92,9 @@ struct ConvEpi {
 };
 
 // loader extras of the data gradient that forms dpre from (dy, a) on the fly (conv_kernel.h: ConvFwdArgs::bw_*)
-struct ConvBwdLoad { const float* aux; const float* k1; const float* k2; const float* k3; float slope; };
+struct ConvBwdLoad { const float* aux; const float* k1; const float* k2; const float* k3; float slope;
+                     const float* bs_a = nullptr; float* bs_part = nullptr; };
+int amx_conv_ws_bsum_rows(int N, int H, int W, int cout);      // conv_ws.hip
 
 // C ABI — see include/atomai_amd.h for the contract.
 static int conv2d_common(const float* x0, const float* sc0, const float* sh0, int C0s,
@@ -125,6 +128,8 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     for (int l = 0; l < 4; ++l) { a.ds_sc[l] = (epi && l <= nds) ? epi->ds_sc[l] : nullptr; a.ds_sh[l] = (epi && l <= nds) ? epi->ds_sh[l] : nullptr; }
     a.bw_aux = bw ? bw->aux : nullptr; a.bw_k1 = bw ? bw->k1 : nullptr; a.bw_k2 = bw ? bw->k2 : nullptr;
     a.bw_k3 = bw ? bw->k3 : nullptr; a.bw_slope = bw ? bw->slope : 1.f;
+    a.bs_a = bw ? bw->bs_a : nullptr; a.bs_part = bw ? bw->bs_part : nullptr;
+    if ((a.bs_a == nullptr) != (a.bs_part == nullptr) || (a.bs_a && (y1 || addend))) AMX_BADARG(17);
     a.prof = nullptr;
 #ifdef AMX_CONV_PROFILE
     a.prof = (unsigned long long*)amx_conv_profile_buffer;               // dev build: per-wave phase timestamps
@@ -267,6 +272,25 @@ extern "C" int amx_conv2d_dgrad_fused(const float* dy, const float* aux, const f
     return conv2d_common(dy, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, nullptr, y, Y0s, y1,
                          Y1s, nullptr, N, H, W, Y0s + Y1s, taps, dil, 1.f, stream, 1.f, 1.f, nullptr, &bw);
 }
+// amx_conv2d_dgrad_fused for a launch with ONE output that is the complete gradient of a conv -> LeakyReLU -> BatchNorm
+// layer's output: bs_a = that layer's saved activation (shape of y); bs_part receives amx_conv2d_dgrad_bsum_rows rows of
+// (sum dy, sum dy * a) per channel — the input of amx_bn_bwd_finalize (stride Y0s), replacing amx_bn_bwd_reduce.
+extern "C" int amx_conv2d_dgrad_fused_bsum(const float* dy, const float* aux, const float* k1, const float* k2,
+                                           const float* k3, float bslope, int Cs, const float* wpk, float* y, int Y0s,
+                                           int N, int H, int W, int taps, int dil, const float* bs_a, float* bs_part,
+                                           void* stream) {
+    if (!aux || !bs_a || !bs_part) AMX_BADARG(14);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(15);
+    ConvBwdLoad bw{aux, k1, k2, k3, bslope, bs_a, bs_part};
+    return conv2d_common(dy, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, nullptr, y, Y0s, nullptr,
+                         0, nullptr, N, H, W, Y0s, taps, dil, 1.f, stream, 1.f, 1.f, nullptr, &bw);
+}
+// rows of bs_part, 0 when the launch is not one the wave-specialised kernel takes (or AMX_BWD_SUMS=0)
+extern "C" int amx_conv2d_dgrad_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, int dil) {
+    if (!amx_knobs().bwd_sums || !amx_conv2d_dgrad_fused_supported(Cs, Y0s, 0, N, H, W, taps, dil)) return 0;
+    return amx_conv_ws_bsum_rows(N, H, W, Y0s);
+}
+
 extern "C" int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil) {
     if (Cs <= 0 || Y0s <= 0 || (taps != 1 && taps != 9)) return 0;
     if (!amx_knobs().bwd_fuse) return 0;

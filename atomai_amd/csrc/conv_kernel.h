@@ -81,6 +81,11 @@ struct ConvFwdArgs {
     const float* bw_aux;                   // the layer's saved activation a (shape of x0), or nullptr
     const float* bw_k1; const float* bw_k2; const float* bw_k3;      // per-channel constants (all three or none)
     float bw_slope;
+    // ---- BatchNorm-backward sums of the layer that PRODUCED this launch's output position (round 6, conv_ws.hip BWD
+    // launches with one output): the data gradient written to y is the complete dy of a conv -> LeakyReLU -> BatchNorm layer
+    // whose saved activation is bs_a (shape of y); the epilogue adds up (sum dy, sum dy * a) per channel into
+    // bs_part [amx_conv2d_dgrad_bsum_rows][2][Y0s] — what amx_bn_bwd_reduce would compute in a pass of its own over both tensors
+    const float* bs_a; float* bs_part;
     unsigned long long* prof;   // AMX_CONV_PROFILE builds: per-wave phase clocks (or nullptr)
     int N, H, W;
     int cout;            // real number of output channels

@@ -73,7 +73,16 @@ template <int NCH> struct WsPlane { static constexpr int value = NCH == 2 ? 338 
 // arithmetic of amx_bn_bwd_apply, so the input image — and hence the result — is bit-identical to the two-pass form).
 // The separate amx_bn_bwd_apply pass (read dy, read a, write dpre: 0.16-0.32 ms per thin layer, on the critical path of
 // the backward pass) disappears; the producers' second load stream costs registers only they need.
-template <int NCH, int NT, bool BWD>
+// BSUM (round 6, data-gradient launches with ONE output whose position is the output of a conv -> LeakyReLU -> BatchNorm
+// layer): the accumulators a CONSUMER wave hands over are that layer's dy (a data gradient has no bias and no activation), so
+// the consumer also keeps per-lane running sums of dy and dy * a over all tiles of the workgroup — the saved activation a of
+// the tile's pixels is requested at the start of the sweep, in the C/D fragment layout (lane = cout, four consecutive
+// pixels), and lands behind the MFMAs; the adds / fmas fill issue slots in the shadow of the matrix pipe — and one row of
+// (sum dy, sum dy * a) per consumer wave leaves at the end (a.bs_part).  amx_bn_bwd_reduce — a pass over both tensors on
+// the critical chain of the backward pass — is not launched for that layer.  The producers could not carry it: four more
+// float4 in flight next to their two register images of tile k + 2 spilled ~30 registers.  Fixed tile -> workgroup -> wave
+// -> lane assignment: deterministic.
+template <int NCH, int NT, bool BWD, bool BSUM = false>
 __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
     constexpr int COP = 16 * NT;
     constexpr int G = KG * NCH;                                   // 4-channel groups of the concatenated input
@@ -106,8 +115,25 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
         const int p = lane & 15, g = lane >> 4;
         __syncthreads();                                          // weights + image of the first tile are in LDS
         WS_TICK(3);
+        float bs1[NT], bs2[NT];                                   // BSUM: running sum dy, sum dy * a of cout q * 16 + p
+        #pragma unroll
+        for (int q = 0; q < NT; ++q) { bs1[q] = 0.f; bs2[q] = 0.f; }
         for (int k = 0; k < my_tiles; ++k) {
             const float* in = s_in + (k & 1) * IN_FLOATS;
+            float av[BSUM ? 2 : 1][NT][4];
+            if (BSUM) {
+                // saved activation of this wave's 2 rows x 16 pixels x COP couts, element (row m, pixel 4g + r, cout q*16 + p)
+                int t = first + k * step;
+                const int tx = t % a.tiles_x; t /= a.tiles_x;
+                const int ty = t % a.tiles_y; const int n = t / a.tiles_y;
+                const float* ab = a.bs_a + ((size_t)(n * a.H + ty * TILE + wave * 2) * a.W + tx * TILE + 4 * g) * COP + p;
+                #pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    #pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) av[m][q][r] = ab[((size_t)m * a.W + r) * COP + q * 16];
+            }
             f32x4 acc[2][NT];
             #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -133,6 +159,14 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
                     #undef WS_MFMA
                 }
             }
+            if (BSUM) {
+                #pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    #pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) { bs1[q] += acc[m][q][r]; bs2[q] = fmaf(acc[m][q][r], av[m][q][r], bs2[q]); }
+            }
             WS_TICK(0);
             __syncthreads();                                      // A: the hand-over buffer is drained
             WS_TICK(1);
@@ -147,6 +181,19 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
             WS_TICK(2);
             __syncthreads();                                      // B: handed over
             WS_TICK(3);
+        }
+        if (BSUM) {
+            // the four lane groups g hold partial sums of the same cout p: butterfly, then one row per consumer wave
+            #pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                bs1[q] += __shfl_xor(bs1[q], 16); bs1[q] += __shfl_xor(bs1[q], 32);
+                bs2[q] += __shfl_xor(bs2[q], 16); bs2[q] += __shfl_xor(bs2[q], 32);
+                if (g == 0) {
+                    const size_t row = (size_t)blockIdx.x * WS_CONS + wave;
+                    a.bs_part[(row * 2) * COP + q * 16 + p] = bs1[q];
+                    a.bs_part[(row * 2 + 1) * COP + q * 16 + p] = bs2[q];
+                }
+            }
         }
     } else {
         // ------------------------------------------------------------------ producers: loads, staging, epilogue
@@ -334,15 +381,15 @@ __global__ __launch_bounds__(1024) void conv_ws_kernel(ConvFwdArgs a) {
 #endif
 }
 
-template <int NCH, int NT, bool BWD>
+template <int NCH, int NT, bool BWD, bool BSUM = false>
 static int launch_conv_ws(const ConvFwdArgs& a, hipStream_t stream) {
     constexpr int COP = 16 * NT;
     const size_t lds = ((size_t)NCH * 9 * KG * COP * 4 + 2 * (size_t)KG * NCH * WsPlane<NCH>::value * 4 + (size_t)COP * WS_PS) * sizeof(float);
     const int ntiles = a.tiles_x * a.tiles_y * a.N;
     int wgs = amx_num_cus();
     if (wgs > ntiles) wgs = ntiles;
-    AMX_ALLOW_160K_LDS(conv_ws_kernel<NCH, NT, BWD>);
-    AMX_LAUNCH((conv_ws_kernel<NCH, NT, BWD>), dim3(wgs), dim3(1024), lds, stream, a);
+    AMX_ALLOW_160K_LDS(conv_ws_kernel<NCH, NT, BWD, BSUM>);
+    AMX_LAUNCH((conv_ws_kernel<NCH, NT, BWD, BSUM>), dim3(wgs), dim3(1024), lds, stream, a);
     AMX_CHECK_LAUNCH();
     return 0;
 }
@@ -383,6 +430,13 @@ bool amx_conv_ws_supported(const ConvFwdArgs& a, int taps, int dil, int strip, f
     return true;
 }
 
+// rows of the BatchNorm-backward partial sums a BSUM launch writes: one per workgroup and consumer wave
+int amx_conv_ws_bsum_rows(int N, int H, int W, int cout) {
+    const long ntiles = (long)(H / TILE) * (W / TILE) * N;
+    const int wgs = (int)(ntiles < amx_num_cus() ? ntiles : amx_num_cus());
+    return wgs * WS_CONS;
+}
+
 static std::atomic<long> ws_launches{0};
 extern "C" long amx_conv2d_ws_launches(void) { return ws_launches.load(std::memory_order_relaxed); }
 
@@ -390,6 +444,10 @@ int amx_conv_launch_ws(ConvFwdArgs& a, hipStream_t s) {
     ws_launches.fetch_add(1, std::memory_order_relaxed);
     a.tiles_x = a.W / TILE; a.tiles_y = a.H / TILE;
     const int nch = (a.C0s + a.C1s) / 16;
+    if (a.bw_aux && a.bs_a) {                  // + BatchNorm-backward sums of the output position's layer (one output)
+        if (nch == 1) return a.cout == 16 ? launch_conv_ws<1, 1, true, true>(a, s) : launch_conv_ws<1, 2, true, true>(a, s);
+        return a.cout == 16 ? launch_conv_ws<2, 1, true, true>(a, s) : launch_conv_ws<2, 2, true, true>(a, s);
+    }
     if (a.bw_aux) {
         if (nch == 1) return a.cout == 16 ? launch_conv_ws<1, 1, true>(a, s) : launch_conv_ws<1, 2, true>(a, s);
         return a.cout == 16 ? launch_conv_ws<2, 1, true>(a, s) : launch_conv_ws<2, 2, true>(a, s);

@@ -99,6 +99,13 @@ class Act:
         return (bool(FUSE & 2) and training and self.producer and self.gx is None
                 and self.needs_grad and self.first_consumer == id(node))
 
+    def wants_bsum_from_dgrad(self, node, training: bool) -> bool:
+        """True if the data gradient `node` is about to write is the COMPLETE gradient of this activation (sole writer)
+        and its producer owns a BatchNorm: the wave-specialised data-gradient kernel can then emit the BatchNorm-backward
+        sums of that producer in its epilogue (round 6, amx_conv2d_dgrad_fused_bsum)."""
+        return (bool(FUSE & 2) and training and self.producer and self.gx is None and self.grad is None
+                and self.needs_grad and self.first_consumer == id(node))
+
     @property
     def npix(self) -> int:
         return self.N * self.H * self.W
@@ -611,6 +618,7 @@ class ConvNode(_Node):
         if not (need0 or need1):
             return
         wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 1)
+        bsum_src = s1 is None and s0.wants_bsum_from_dgrad(self, tape.training)      # (asked before s0.grad is allocated)
         tgt = []
         for s in (s0, s1):
             if s is None:
@@ -631,6 +639,17 @@ class ConvNode(_Node):
         if aux is not None:
             # dpre is formed by the loader of the wave-specialised kernel from (dy, a) (_bwd_fusable guarantees support)
             assert add0 is None and scratch is None
+            if s1 is None and bsum_src:
+                # the gradient written here is the whole dy of the source layer: its BatchNorm-backward sums come out of
+                # this kernel's epilogue, amx_bn_bwd_reduce is not launched for it (ConvNode.backward reads s0.bstats)
+                rows = L.load().amx_conv2d_dgrad_bsum_rows(cos, C0s, N, H, W, self.taps, self.dil)
+                if rows > 0:
+                    part = _empty((rows, 2, C0s), s0.t)
+                    L.call("amx_conv2d_dgrad_fused_bsum", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
+                           self.slope, cos, L.ptr(wpk), L.ptr(tgt[0][0]), C0s, N, H, W, self.taps, self.dil, L.ptr(s0.t),
+                           L.ptr(part), sp)
+                    s0.bstats = (part, rows, C0s, 0)
+                    return
             L.call("amx_conv2d_dgrad_fused", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope, cos,
                    L.ptr(wpk), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, N, H, W, self.taps, self.dil, sp)
             return

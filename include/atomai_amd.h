@@ -88,6 +88,16 @@ int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int
 int amx_conv2d_dgrad_fused(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
                            float bslope, int Cs, const float* wpk, float* y, int Y0s, float* y1, int Y1s,
                            int N, int H, int W, int taps, int dil, void* stream);
+/* amx_conv2d_dgrad_fused for a launch with ONE output that is the complete gradient dy of a conv -> LeakyReLU -> BatchNorm
+ * layer's output: the epilogue also reads that layer's saved activation bs_a (shape of y) and writes
+ * amx_conv2d_dgrad_bsum_rows rows of (sum dy, sum dy * a) per channel to bs_part [rows][2][Y0s] — the input of
+ * amx_bn_bwd_finalize, so amx_bn_bwd_reduce (a pass over both tensors) is not launched for that layer (autograd of
+ * nn.BatchNorm2d, blocks.py:71-75).  amx_conv2d_dgrad_bsum_rows returns 0 where the form does not exist (AMX_BWD_SUMS=0,
+ * or a launch the wave-specialised kernel does not take). */
+int amx_conv2d_dgrad_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, int dil);
+int amx_conv2d_dgrad_fused_bsum(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
+                                float bslope, int Cs, const float* wpk, float* y, int Y0s, int N, int H, int W, int taps,
+                                int dil, const float* bs_a, float* bs_part, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
 /* Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images x[ry::d, rx::d]; their

@@ -584,8 +584,11 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
     set_knob(monkeypatch, "AMX_CONV_WS_DGRAD", "7")
     out, calls = {}, {}
     real_call = L.call
-    for mode in ("1", "0"):
-        set_knob(monkeypatch, "AMX_BWD_FUSE", mode)
+    # "1" / "0": loaders vs two-pass form with the BatchNorm-backward sums from amx_bn_bwd_reduce in both (bit-identity);
+    # "s": the loaders AND the sums of the source layer from the data-gradient kernel's epilogue (round 6, the default)
+    for mode in ("1", "0", "s"):
+        set_knob(monkeypatch, "AMX_BWD_FUSE", "0" if mode == "0" else "1")
+        set_knob(monkeypatch, "AMX_BWD_SUMS", "1" if mode == "s" else "0")
         cnt = {}
 
         def counting(name, *a, _c=cnt):
@@ -633,6 +636,18 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
         out[mode], calls[mode] = grads, cnt
     nf = calls["1"].get("amx_conv2d_dgrad_fused", 0)
     assert nf >= 1 and calls["0"].get("amx_conv2d_dgrad_fused", 0) == 0, calls
+    # sums in the epilogue: every such launch replaces one amx_bn_bwd_reduce, results agree to rounding (another summation
+    # order of ~1e3..1e6 products per channel), and the same launches stay loader-fused
+    nb = calls["s"].get("amx_conv2d_dgrad_fused_bsum", 0)
+    assert calls["1"].get("amx_conv2d_dgrad_fused_bsum", 0) == 0
+    assert nb + calls["s"].get("amx_conv2d_dgrad_fused", 0) == nf, calls
+    assert calls["1"]["amx_bn_bwd_reduce"] - calls["s"].get("amx_bn_bwd_reduce", 0) == nb, calls
+    if not res:
+        assert nb >= 1, calls
+    for k in out["1"]:
+        a, b = out["s"][k], out["1"][k]
+        tol = 2e-5 * max(1e-3, float(b.abs().max())) + 3e-6 * float(batch * hw * hw) ** 0.5 * (0.0 if a.ndim == 4 else 1.0)
+        assert float((a - b).abs().max()) <= tol, ("sums in the data-gradient epilogue", k, float((a - b).abs().max()), tol)
     # (+ the net's first layer, whose BatchNorm backward is formed by amx_conv1_wgrad_fused: it has no data gradient)
     per_run = repeats if res else 1
     assert (calls["0"]["amx_bn_bwd_apply"] - calls["1"].get("amx_bn_bwd_apply", 0)
