@@ -57,17 +57,6 @@ static ConvPlan plan_conv(int Cin_s, int cout, int taps, int dil, int H, bool al
     return pl;
 }
 
-// Data gradients on conv_kernel.h that can add up the BatchNorm-backward sums of the layer at their output position
-// (EPI = 3): whole 16-channel chunks in, plain 3x3 on the 8-row x 32-cout or 16-row x 64-cout plan, or 1x1 with 32 / 64 couts
-// per workgroup; stored output channels == couts.
-static bool plain_bsum_class(int Cin_s, int cout, int taps, int dil, int H) {
-    if ((Cin_s & 15) || (cout & 3) || (taps == 9 && dil != 1)) return false;
-    const ConvPlan pl = plan_conv(Cin_s, cout, taps, dil, H, false);
-    if (pl.rem) return false;
-    if (taps == 1) return pl.nt == 2 || pl.nt == 4;
-    return (pl.th == 8 && pl.nt == 2) || (pl.th == 16 && pl.nt == 4);
-}
-
 // The classification head can be fused into a plain 3x3 layer whose plan is one of the two thin classes with ONE cout
 // block: 16 couts x 16-row tiles (U-Net's last layer) or <= 32 couts x 8-row tiles (dilnet's).
 static bool head_supported(int Cin_s, int cout, int taps, int dil, int H) {
@@ -168,12 +157,6 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
     const bool tail = a.tail_kg < KG;                       // partial last chunk: cheaper tail path
     if (amx_conv_ws_supported(a, taps, dil, pl.th / 4, in_slope0, in_slope1)) return amx_conv_launch_ws(a, s);
     if (a.bw_aux) AMX_BADARG(14);                           // the on-load BatchNorm backward exists in conv_ws.hip only
-    if (a.bs_a) {                                           // BatchNorm-backward sums in the epilogue: the plain classes
-        if (!plain_bsum_class(C0s, cout, taps, dil, H) || C1s || stats || hout || nds || addend || y1 || Y0s != cout) AMX_BADARG(17);
-        const int rc = taps == 1 ? amx_conv_launch_1x1_bsum(a, pl.nt, s) : amx_conv_launch_3x3_bsum(a, pl.nt, pl.th, s);
-        if (rc < 0) AMX_BADARG(17);
-        return rc;
-    }
     if (amx_lattice_mode(taps, dil)) {                          // tiles of the (largest) residue-class sub-image
         a.tiles_x = amx_ceil_div(amx_ceil_div(W, dil), TILE); a.tiles_y = amx_ceil_div(amx_ceil_div(H, dil), pl.th);
         if ((long)a.tiles_x * a.tiles_y * N * dil * dil >= 2147483647L) AMX_BADARG(2);
@@ -304,28 +287,8 @@ extern "C" int amx_conv2d_dgrad_fused_bsum(const float* dy, const float* aux, co
 }
 // rows of bs_part, 0 when the launch is not one the wave-specialised kernel takes (or AMX_BWD_SUMS=0)
 extern "C" int amx_conv2d_dgrad_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, int dil) {
-    if (!(amx_knobs().bwd_sums & 1) || !amx_conv2d_dgrad_fused_supported(Cs, Y0s, 0, N, H, W, taps, dil)) return 0;
+    if (!amx_knobs().bwd_sums || !amx_conv2d_dgrad_fused_supported(Cs, Y0s, 0, N, H, W, taps, dil)) return 0;
     return amx_conv_ws_bsum_rows(N, H, W, Y0s);
-}
-
-// The same for the data gradient of a MATERIALISED dpre (amx_conv2d_dgrad: the >= 64-channel plain 3x3 layers and the 1x1
-// convolutions of UpsampleBlock, on conv_kernel.h): one output without addend that is the complete dy of a
-// conv -> LeakyReLU -> BatchNorm layer with saved activation bs_a; bs_part [amx_conv2d_dgrad_plain_bsum_rows][2][Y0s].
-extern "C" int amx_conv2d_dgrad_plain_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, int dil) {
-    if (!(amx_knobs().bwd_sums & 2) || Cs <= 0 || Y0s <= 0 || (taps != 1 && taps != 9)) return 0;
-    if (!plain_bsum_class(Cs, Y0s, taps, dil, H)) return 0;
-    ConvFwdArgs a = {};
-    a.C0s = Cs; a.Y0s = Y0s; a.cout = Y0s; a.N = N; a.H = H; a.W = W;
-    const ConvPlan pl = plan_conv(Cs, Y0s, taps, dil, H, false);
-    if (amx_conv_ws_supported(a, taps, dil, pl.th / 4, 1.f, 1.f)) return 0;      // (that launch would go to conv_ws.hip)
-    return amx_ceil_div(W, TILE) * amx_ceil_div(H, pl.th) * N * 4;
-}
-extern "C" int amx_conv2d_dgrad_bsum(const float* dpre, int Cs, const float* wpk, float* y, int Y0s, int N, int H, int W,
-                                     int taps, int dil, const float* bs_a, float* bs_part, void* stream) {
-    if (!bs_a || !bs_part) AMX_BADARG(17);
-    ConvBwdLoad bw{nullptr, nullptr, nullptr, nullptr, 1.f, bs_a, bs_part};
-    return conv2d_common(dpre, nullptr, nullptr, Cs, nullptr, nullptr, nullptr, 0, wpk, nullptr, nullptr, y, Y0s, nullptr,
-                         0, nullptr, N, H, W, Y0s, taps, dil, 1.f, stream, 1.f, 1.f, nullptr, &bw);
 }
 
 extern "C" int amx_conv2d_dgrad_fused_supported(int Cs, int Y0s, int Y1s, int N, int H, int W, int taps, int dil) {

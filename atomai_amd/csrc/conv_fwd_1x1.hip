@@ -10,10 +10,3 @@ int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
     GO(4);
 #undef GO
 }
-
-// 1x1 data gradients with the BatchNorm-backward sums of the layer at their output position (EPI = 3); -1 = no such class
-int amx_conv_launch_1x1_bsum(ConvFwdArgs& a, int nt, hipStream_t s) {
-    if (nt == 2) return launch_conv_fwd<1, 2, 0, true, 4, 3, false>(a, s);
-    if (nt == 4) return launch_conv_fwd<1, 4, 0, true, 4, 3, false>(a, s);
-    return -1;
-}

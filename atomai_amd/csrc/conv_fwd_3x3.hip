@@ -26,11 +26,3 @@ int amx_conv_launch_3x3_head(ConvFwdArgs& a, int nt, bool tail, hipStream_t s) {
 #undef GO
 }
 
-
-// data gradients that also add up the BatchNorm-backward sums of the layer at their output position (EPI = 3): the two
-// plans the >= 64-channel plain 3x3 layers take (8-row x 32-cout and 16-row x 64-cout tiles); -1 = no such class
-int amx_conv_launch_3x3_bsum(ConvFwdArgs& a, int nt, int th, hipStream_t s) {
-    if (th == 8 && nt == 2) return launch_conv_fwd<9, 2, 1, true, 2, 3, false>(a, s);
-    if (th == 16 && nt == 4) return launch_conv_fwd<9, 4, 1, true, 4, 3, false>(a, s);
-    return -1;
-}

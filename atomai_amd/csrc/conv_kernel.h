@@ -212,13 +212,8 @@ struct ConvWaves {
 template <int TAPS, int NT, int MAXHALO, bool EXACT, int MTW, int EPI, bool TAIL = false, int LAT = 0, int REM = 0>
 __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>::value)) void conv_fwd_kernel(ConvFwdArgs a) {
     static_assert(LAT == 0 || (TAPS == 9 && MAXHALO == 1 && EXACT), "lattice mode runs the plain 3x3 geometry");
-    // EPI: 0 = store the activation; 1 = classification head fused in (eval); 2 = sum of a DilatedBlock fused in (eval);
-    // 3 = data gradient whose output is the complete dy of a conv -> LeakyReLU -> BatchNorm layer: store it AND add up that
-    //     layer's BatchNorm-backward sums (sum dy, sum dy * a) from the transposed tile and the saved activation a.bs_a, read
-    //     with the same 16-byte accesses as the stores (round 6; conv_ws.hip does the same in its consumer waves): one row
-    //     per wave in a.bs_part [tile][wave][2][cop], amx_bn_bwd_reduce is not launched for that layer
-    constexpr bool HEAD = EPI == 1, DSUM = EPI == 2, BSUM = EPI == 3;
-    static_assert(!BSUM || (LAT == 0 && REM == 0 && !TAIL), "the sums exist for the plain classes");
+    // EPI: 0 = store the activation; 1 = classification head fused in (eval); 2 = sum of a DilatedBlock fused in (eval)
+    constexpr bool HEAD = EPI == 1, DSUM = EPI == 2;
     constexpr int TH = 4 * MTW;                                  // tile rows (MTW image rows per wave)
     constexpr int NB = NT * 16 + REM * 4;                        // columns (couts) of this workgroup
     constexpr int RQ = REM ? REM : 1;
@@ -651,7 +646,6 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
         for (int k = 0; k < 3; ++k)
             hwq[k] = (k < a.hK && lane % CGH < CG) ? amx_ld4(a.hw + (size_t)k * a.cop + (lane % CGH) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    float4 bs1 = make_float4(0.f, 0.f, 0.f, 0.f), bs2 = bs1;      // BSUM: this lane's 4 couts (lane % CG), all its pixels
     #pragma unroll
     for (int m0 = 0; m0 < MTW; m0 += MH) {
         #pragma unroll
@@ -739,30 +733,9 @@ __global__ __launch_bounds__(256, (ConvWaves<TAPS, NT, MAXHALO, MTW, TAIL, REM>:
                 const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * Cd + cd;
                 if (a.addend && dst == a.y) { const float4 ad = amx_ld4(a.addend + o); v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w; }
                 amx_st4(dst + o, v);
-                if (BSUM) {
-                    const float4 av = amx_ld4(a.bs_a + o);
-                    bs1.x += v.x; bs1.y += v.y; bs1.z += v.z; bs1.w += v.w;
-                    bs2.x = fmaf(v.x, av.x, bs2.x); bs2.y = fmaf(v.y, av.y, bs2.y);
-                    bs2.z = fmaf(v.z, av.z, bs2.z); bs2.w = fmaf(v.w, av.w, bs2.w);
-                }
             }
         }
         if (m0 + MH < MTW) amx_wave_sync();                      // the region is rewritten by the next pair of rows
-    }
-    if (BSUM) {
-        // lanes with equal lane % CG hold partial sums of the same 4 couts: butterfly over the others, one row per wave
-        // (rows [tile][wave]: EVERY wave writes its row — zeros where its strip lies outside the image)
-        #pragma unroll
-        for (int o = CG; o < 64; o <<= 1) {
-            bs1.x += __shfl_xor(bs1.x, o); bs1.y += __shfl_xor(bs1.y, o); bs1.z += __shfl_xor(bs1.z, o); bs1.w += __shfl_xor(bs1.w, o);
-            bs2.x += __shfl_xor(bs2.x, o); bs2.y += __shfl_xor(bs2.y, o); bs2.z += __shfl_xor(bs2.z, o); bs2.w += __shfl_xor(bs2.w, o);
-        }
-        const int co = n0 + lane * 4;
-        if (lane < CG && co < a.Y0s) {
-            const size_t row = ((size_t)(n * a.tiles_y + ty) * a.tiles_x + tx) * 4 + wave;
-            amx_st4(a.bs_part + (row * 2) * a.Y0s + co, bs1);
-            amx_st4(a.bs_part + (row * 2 + 1) * a.Y0s + co, bs2);
-        }
     }
     AMX_TICK(13);
 }
@@ -795,8 +768,6 @@ int amx_conv_launch_ws(ConvFwdArgs& a, hipStream_t s);
 int amx_conv_launch_1x1(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_3x3(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);
 int amx_conv_launch_3x3_head(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
-int amx_conv_launch_3x3_bsum(ConvFwdArgs& a, int nt, int th, hipStream_t s);      // EPI = 3 (BatchNorm-backward sums), plain classes
-int amx_conv_launch_1x1_bsum(ConvFwdArgs& a, int nt, hipStream_t s);
 int amx_conv_launch_dil(ConvFwdArgs& a, int nt, bool tail, hipStream_t s);
 int amx_conv_launch_lat2(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);   // lattice mode, dilation 2 / 4 / 6
 int amx_conv_launch_lat4(ConvFwdArgs& a, int nt, int th, bool tail, hipStream_t s);

@@ -15,7 +15,7 @@ struct AmxKnobs {
     int conv_xcd;         // AMX_CONV_XCD        0 off, 1 all, 2 launches with > 1 cout block, 3 dilated launches only
     int conv_xpack;       // AMX_CONV_XPACK      1: lattice sub-images of one residue row share a tile axis when that saves tiles
     int bwd_fuse;         // AMX_BWD_FUSE        1: BatchNorm / LeakyReLU backward inside the consumers' loaders
-    int bwd_sums;         // AMX_BWD_SUMS        BatchNorm-backward sums of the source layer out of the data gradient: 1 conv_ws.hip, 2 conv_kernel.h
+    int bwd_sums;         // AMX_BWD_SUMS        1: BatchNorm-backward sums of the source layer in the data-gradient epilogue
     int conv_ws;          // AMX_CONV_WS         0 off, 1 default classes, 2 forward only, 3 data gradients only
     int conv_ws_dgrad;    // AMX_CONV_WS_DGRAD   bit mask of data-gradient classes on the wave-specialised kernel
     int wgrad_th;         // AMX_WGRAD_TH        0: plan_wgrad's choice; 4|8: tile rows

@@ -18,7 +18,7 @@ const KnobRow kRows[] = {
     {"AMX_CONV_XCD", &AmxKnobs::conv_xcd, 3},
     {"AMX_CONV_XPACK", &AmxKnobs::conv_xpack, 1},
     {"AMX_BWD_FUSE", &AmxKnobs::bwd_fuse, 1},
-    {"AMX_BWD_SUMS", &AmxKnobs::bwd_sums, 3},
+    {"AMX_BWD_SUMS", &AmxKnobs::bwd_sums, 1},
     {"AMX_CONV_WS", &AmxKnobs::conv_ws, 1},
     {"AMX_CONV_WS_DGRAD", &AmxKnobs::conv_ws_dgrad, 7},
     {"AMX_WGRAD_TH", &AmxKnobs::wgrad_th, 0},

@@ -653,22 +653,6 @@ class ConvNode(_Node):
             L.call("amx_conv2d_dgrad_fused", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope, cos,
                    L.ptr(wpk), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s, N, H, W, self.taps, self.dil, sp)
             return
-        if s1 is None and add0 is None and bsum_src:
-            # (round 6) the same on the general kernel — the >= 64-channel plain 3x3 layers and the 1x1 convolutions of
-            # UpsampleBlock: the gradient written here is the whole dy of the source layer, whose BatchNorm-backward sums
-            # come out of this launch's epilogue (thousands of per-wave rows: chunk sums first, as for the weight gradients)
-            rows = L.load().amx_conv2d_dgrad_plain_bsum_rows(cos, C0s, N, H, W, self.taps, self.dil)
-            if rows > 0:
-                part = _empty((rows, 2, C0s), s0.t)
-                L.call("amx_conv2d_dgrad_bsum", L.ptr(dpre), cos, L.ptr(wpk), L.ptr(tgt[0][0]), C0s, N, H, W, self.taps,
-                       self.dil, L.ptr(s0.t), L.ptr(part), sp)
-                if rows > 2048:
-                    nch = 128
-                    part2 = _empty((nch, 2, C0s), s0.t)
-                    L.call("amx_reduce_rows_chunked", L.ptr(part), rows, 2 * C0s, nch, L.ptr(part2), sp)
-                    part, rows = part2, -(-rows // -(-rows // nch))
-                s0.bstats = (part, rows, C0s, 0)
-                return
         L.call("amx_conv2d_dgrad", L.ptr(dpre), cos, L.ptr(wpk), L.ptr(add0), L.ptr(tgt[0][0]), C0s, L.ptr(y1), C1s,
                N, H, W, self.taps, self.dil, sp)
         if scratch is not None:

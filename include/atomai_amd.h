@@ -98,12 +98,6 @@ int amx_conv2d_dgrad_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, i
 int amx_conv2d_dgrad_fused_bsum(const float* dy, const float* aux, const float* k1, const float* k2, const float* k3,
                                 float bslope, int Cs, const float* wpk, float* y, int Y0s, int N, int H, int W, int taps,
                                 int dil, const float* bs_a, float* bs_part, void* stream);
-/* The same sums out of the data gradient of a MATERIALISED dpre (amx_conv2d_dgrad on the general kernel: the >= 64-channel
- * plain 3x3 layers and the 1x1 convolutions of UpsampleBlock): one output, no addend.  AMX_BWD_SUMS is a bit mask: 1 = the
- * wave-specialised launches above, 2 = these (default 3). */
-int amx_conv2d_dgrad_plain_bsum_rows(int Cs, int Y0s, int N, int H, int W, int taps, int dil);
-int amx_conv2d_dgrad_bsum(const float* dpre, int Cs, const float* wpk, float* y, int Y0s, int N, int H, int W, int taps,
-                          int dil, const float* bs_a, float* bs_part, void* stream);
 int amx_conv2d_tile_h(int Cin_s, int cout, int taps, int dil, int H);
 int amx_conv2d_num_tiles(int N, int H, int W, int th);
 /* Dilations 2 / 4 / 6 run as d*d plain 3x3 convolutions on the residue-class sub-images x[ry::d, rx::d]; their
