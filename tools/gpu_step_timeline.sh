@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace of the U-Net training step (bs 32, 512^2): per-kernel start / end of ONE steady step with its
 # hardware queue, so that the overlap of the side stream (weight gradients) with the main stream is visible.
-#   usage: tools/gpu_step_timeline.sh <tag> [ENV=VAL ...]      -> gpurun_out/r05_step_timeline_<tag>.txt
+#   usage: tools/gpu_step_timeline.sh <tag> [ENV=VAL ...]      -> gpurun_out/r06_step_timeline_<tag>.txt
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=$1; shift
 for kv in "$@"; do export "$kv"; done
@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 PY
 rm -rf gpurun_out/prof_tl
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/prof_tl -o tl -- python /tmp/step.py ) > gpurun_out/prof_tl.log 2>&1
-python - "$TAG" "$*" <<'PY' > gpurun_out/r05_step_timeline_$TAG.txt
+python - "$TAG" "$*" <<'PY' > gpurun_out/r06_step_timeline_$TAG.txt
 import csv, glob, sys
 f = glob.glob('/root/repo/gpurun_out/prof_tl/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -36,4 +36,4 @@ for s, e, n, q in step:
 print("# busy per queue (us):", {q: round(v / 1e3, 1) for q, v in busy.items()})
 PY
 rm -rf gpurun_out/prof_tl
-tail -3 gpurun_out/r05_step_timeline_$TAG.txt
+tail -3 gpurun_out/r06_step_timeline_$TAG.txt
