@@ -102,6 +102,9 @@ class KernelTimer:
             elif name == "amx_conv2d_dgrad_fused":   # (dy,aux,k1,k2,k3,bslope,Cs@6,wpk,y,Y0s@9,y1,Y1s@11,N@12,H@13,W@14,taps@15,dil,stream)
                 fl = 2.0 * args[6] * (args[9] + args[11]) * args[15] * args[12] * args[13] * args[14]
                 name = "amx_conv2d_fwd"       # conv_ws_kernel<.., BWD>: the data gradient with the BatchNorm backward in its loader
+            elif name == "amx_conv2d_dgrad_fused_bsum":   # (dy,aux,k1,k2,k3,bslope,Cs@6,wpk,y,Y0s@9,N@10,H@11,W@12,taps@13,dil,bs_a,bs_part,stream)
+                fl = 2.0 * args[6] * args[9] * args[13] * args[10] * args[11] * args[12]
+                name = "amx_conv2d_fwd"       # conv_ws_kernel<.., BWD, BSUM>: + the BatchNorm-backward sums of the source layer
             elif name == "amx_conv2d_wgrad":  # (.., C0s@3, .., C1s@7, dpre@8, Dos@9, part@10, N@11,H,W,cout@14,taps@15)
                 fl = 2.0 * (args[3] + args[7]) * args[14] * args[15] * args[11] * args[12] * args[13]
             elif name == "amx_conv2d_wgrad_fused":  # (.., C0s@3, .., C1s@7, dy@8, .., Dos@14, part, bpart, N@17,H,W,cout@20,taps@21)
@@ -513,7 +516,8 @@ def main(argv=None, backend=None):
     if world > 1 or force_dp:
         model.dp.timing = True                               # HIP events around the gradient all-reduce of every step
     timer = None if (args.no_kernel_timing or not be.product) else KernelTimer(
-        ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_dgrad_fused", "amx_conv2d_wgrad", "amx_conv2d_wgrad_fused"])
+        ["amx_conv2d_fwd", "amx_conv2d_dgrad", "amx_conv2d_dgrad_fused", "amx_conv2d_dgrad_fused_bsum", "amx_conv2d_wgrad",
+         "amx_conv2d_wgrad_fused"])
     from atomai_amd.engine import Tape
     if args.serial:
         Tape.use_side_stream = False
@@ -693,8 +697,8 @@ def main(argv=None, backend=None):
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_F32,
                                "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic,
                                "traffic_source": tsrc,
-                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> + conv_ws_kernel<NCH,NT,BWD> (amx_conv2d_fwd / "
-                                         "amx_conv2d_dgrad / amx_conv2d_dgrad_fused: all forward + dgrad launches of the step)",
+                               "kernel": "conv_fwd_kernel<TAPS,NT,HALO> + conv_ws_kernel<NCH,NT,BWD,BSUM> (amx_conv2d_fwd / amx_conv2d_dgrad / "
+                                         "amx_conv2d_dgrad_fused[_bsum]: all forward + dgrad launches of the step)",
                                "launches_per_step": conv["calls"] // ksteps,
                                "ms_per_step": round(conv["total_ms"] / ksteps, 3),
                                "avg_launch_ms": round(conv["total_ms"] / conv["calls"], 4),

@@ -51,6 +51,8 @@ def test_launched_conv_flops_match_the_table():
             flops[0] += 2.0 * a[1] * (a[5] + a[7]) * a[11] * a[8] * a[9] * a[10]
         elif name == "amx_conv2d_dgrad_fused":        # (the wave-specialised data gradient of large thin layers)
             flops[0] += 2.0 * a[6] * (a[9] + a[11]) * a[15] * a[12] * a[13] * a[14]
+        elif name == "amx_conv2d_dgrad_fused_bsum":   # (the same + BatchNorm-backward sums of the source layer, round 6)
+            flops[0] += 2.0 * a[6] * a[9] * a[13] * a[10] * a[11] * a[12]
         elif name == "amx_conv2d_wgrad_fused":
             flops[0] += 2.0 * (a[3] + a[7]) * a[20] * a[21] * a[17] * a[18] * a[19]
         return orig(name, *a)

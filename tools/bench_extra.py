@@ -251,6 +251,7 @@ def bench_dkl_fit(N=16384, patch=16, steps=3, warmup=1, precisions=("single", "d
     out = {}
     for prec in precisions:
         torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        mem0 = torch.cuda.memory_allocated()          # (tensors of earlier bench legs may still be resident: report the delta)
         m = aoi.models.dklGPR(patch * patch, embedim=2, precision=prec, seed=1)
         m.compile_trainer(X, y, training_cycles=1, feature_extractor=convFeatureExtractor)
         ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -291,7 +292,7 @@ def bench_dkl_fit(N=16384, patch=16, steps=3, warmup=1, precisions=("single", "d
             del K, Ki
         out[prec] = {"ms_per_fit_step": round(step, 2), "phases_ms": ph, "library_ms": round(lib, 2),
                      "library_frac": round(lib / step, 4), "optimizer": type(m.optimizer).__name__,
-                     "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "loss": round(lv, 6),
+                     "peak_mem_GB": round((torch.cuda.max_memory_allocated() - mem0) / 1e9, 2), "loss": round(lv, 6),
                      "potrf_tflops": round(N ** 3 / 3 / (ph["potrf"] * 1e-3) / 1e12, 2) if ph.get("potrf") else None,
                      "potri_tflops": round(2 * N ** 3 / 3 / (ph["potri"] * 1e-3) / 1e12, 2) if ph.get("potri") else None,
                      "kinv_rel_asymmetry": float(f"{asym:.2e}")}
@@ -318,6 +319,8 @@ def _conv_flops(name, a):
         return 2.0 * a[1] * (a[5] + a[7]) * a[11] * a[8] * a[9] * a[10]
     if name == "amx_conv2d_dgrad_fused":
         return 2.0 * a[6] * (a[9] + a[11]) * a[15] * a[12] * a[13] * a[14]
+    if name == "amx_conv2d_dgrad_fused_bsum":
+        return 2.0 * a[6] * a[9] * a[13] * a[10] * a[11] * a[12]
     if name == "amx_conv2d_wgrad_fused":
         return 2.0 * (a[3] + a[7]) * a[20] * a[21] * a[17] * a[18] * a[19]
     if name == "amx_conv2d_wgrad_act":
