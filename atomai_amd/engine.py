@@ -34,6 +34,8 @@ import os as _os
 #    fewer co-resident workgroups, exposed load latency) than the removed passes save.  Bits 1 and 8 (fusion into the
 #    data-gradient kernel) were removed in round 2 together with their register cost in the convolution kernel.
 FUSE = int(_os.environ.get("AMX_FUSE", "2")) & 6
+# first-layer weight gradient on the main stream (host-side switch, read once; tools/gpu_step_ab.py re-reads it for A/B)
+FIRST_WGRAD_MAIN = _os.environ.get("AMX_FIRST_WGRAD_MAIN", "1") != "0"
 
 
 def bwd_fuse_enabled() -> bool:
@@ -497,6 +499,12 @@ class ConvNode(_Node):
         d_in = (dpre, aux, kptr) if dpre_mat is None else (dpre_mat, None, (None, None, None))
         # (enqueued BEFORE the layer's data gradient; after it, or on the main stream, measured no different / slower:
         #  profiles/r04_wgrad_ws.md.  Tape.use_side_stream = False serialises everything for the per-kernel timing pass.)
+        if self.x_plain is not None and FIRST_WGRAD_MAIN:
+            # The net's first layer is the LAST node of backward: nothing follows on the main stream, while the side stream
+            # still drains its backlog of weight gradients — this one runs on the (idle) main stream beside them (round 6:
+            # the step used to end with conv1_wgrad queued behind c2.0's weight gradient, profiles/r06_step_timeline_final.txt)
+            self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
+            return
         with tape.side(a, keep=(dpre, dy, a, k, dpre_mat)):
             self._wgrad(tape, w_in[0], w_in[1], w_in[2], dw, a, want_bias)
         if self.x_plain is not None:
