@@ -57,6 +57,28 @@ extern "C" int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C
     return 0;
 }
 
+// Image of a convolution restricted to ONE of its sources' input channels [ci_off, ci_off + Cn) of cin_total (round 6: the
+// data gradient of a layer that read a concatenation of two 32-channel sources runs as two launches of the wave-specialised
+// kernel, one per source, each with the weight image of its half — engine.ConvNode._dgrad).  Same layout as
+// amx_pack_weights(w, dst, cout, Cn, Cns, 0, 0, taps, mode) of the sliced tensor w[:, ci_off : ci_off + Cn].
+extern "C" int amx_pack_weights_range(const float* w_oihw, float* dst, int cout, int cin_total, int ci_off, int Cn,
+                                      int Cns, int taps, int mode, void* stream) {
+    if (!w_oihw || !dst) AMX_BADARG(1);
+    if (cout <= 0 || Cn <= 0 || Cns < Cn || (Cns & 3) || ci_off < 0 || ci_off + Cn > cin_total) AMX_BADARG(2);
+    if (taps != 1 && taps != 9) AMX_BADARG(3);
+    const int kspace = mode == 0 ? Cns : amx_round_up(cout, 4);
+    const int nspace = mode == 0 ? cout : Cns;
+    const int nchunk = amx_ceil_div(kspace, 16);
+    const int nop = amx_round_up(nspace, 16);
+    const int total = nchunk * taps * 4 * nop * 4;
+    // (the kernel addresses w[(co * cin + ci) * taps + tap]: the row stride stays cin_total, the base moves by ci_off)
+    AMX_LAUNCH(pack_weights_kernel, dim3(amx_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
+               w_oihw + (size_t)ci_off * taps, dst, cout, cin_total, Cn, Cns, 0, 0, taps, mode, nop, total,
+               (kspace & 15) ? nchunk - 1 : -1);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
 // Every layer's image in one launch (blockIdx.y = job): the per-layer launches sat between the convolutions of the
 // forward / backward chains, 30 five-microsecond kernels per training step.
 #define PACK_BATCH 8

@@ -36,6 +36,8 @@ import os as _os
 FUSE = int(_os.environ.get("AMX_FUSE", "2")) & 6
 # first-layer weight gradient on the main stream (host-side switch, read once; tools/gpu_step_ab.py re-reads it for A/B)
 FIRST_WGRAD_MAIN = _os.environ.get("AMX_FIRST_WGRAD_MAIN", "1") != "0"
+# data gradient of a two-source layer as one wave-specialised launch per source where the kernel takes them singly (host-side)
+DGRAD_SPLIT = _os.environ.get("AMX_DGRAD_SPLIT", "1") != "0"
 
 
 def bwd_fuse_enabled() -> bool:
@@ -232,6 +234,17 @@ def pack_weights(w: torch.Tensor, C0, C0s, C1, C1s, taps, mode) -> torch.Tensor:
                mode, _sp(w))
         return dst
     return _pack_cache.get(w, (C0, C0s, C1, C1s, taps, mode), build, meta=(C0, C0s, C1, C1s, taps, mode))
+
+
+def pack_weights_range(w: torch.Tensor, ci_off: int, Cn: int, Cns: int, taps: int, mode: int) -> torch.Tensor:
+    """Image of the convolution over the input channels [ci_off, ci_off + Cn) of `w` alone (amx_pack_weights_range)."""
+    def build():
+        n = L.load().amx_pack_weights_size(w.shape[0], Cns, 0, taps, mode)
+        dst = _empty((n,), w)
+        L.call("amx_pack_weights_range", L.ptr(w.detach()), L.ptr(dst), w.shape[0], w.shape[1], ci_off, Cn, Cns, taps,
+               mode, _sp(w))
+        return dst
+    return _pack_cache.get(w, ("range", ci_off, Cn, Cns, taps, mode), build)
 
 
 def padded_vec(v: torch.Tensor, n: int) -> torch.Tensor:
@@ -531,8 +544,19 @@ class ConvNode(_Node):
         for s in (s0, s1):
             if s is not None and (not s.needs_grad or s.grad is not None or s.gx is not None):
                 return False
-        return bool(L.load().amx_conv2d_dgrad_fused_supported(out.Cs, s0.Cs, s1.Cs if s1 else 0, s0.N, s0.H, s0.W,
-                                                              self.taps, self.dil))
+        lib = L.load()
+        self._dgrad_split = False
+        if lib.amx_conv2d_dgrad_fused_supported(out.Cs, s0.Cs, s1.Cs if s1 else 0, s0.N, s0.H, s0.W, self.taps, self.dil):
+            return True
+        # Round 6: a layer that read a CONCATENATION of two sources the kernel takes one at a time (U-Net c5.0: 32 -> 32 + 32)
+        # runs its data gradient as TWO launches, one per source, each on the weight image of its half of the input
+        # channels — the layer's amx_bn_bwd_apply pass goes, as for the single-launch classes
+        if (s1 is not None and DGRAD_SPLIT and s0.C == s0.Cs and s1.C == s1.Cs
+                and lib.amx_conv2d_dgrad_fused_supported(out.Cs, s0.Cs, 0, s0.N, s0.H, s0.W, self.taps, self.dil)
+                and lib.amx_conv2d_dgrad_fused_supported(out.Cs, s1.Cs, 0, s0.N, s0.H, s0.W, self.taps, self.dil)):
+            self._dgrad_split = True
+            return True
+        return False
 
     def _wgrad(self, tape, dpre, aux, kptr, dw, a, want_bias) -> None:
         w = self.conv.weight
@@ -625,7 +649,8 @@ class ConvNode(_Node):
         need1 = bool(s1 and s1.needs_grad)
         if not (need0 or need1):
             return
-        wpk = pack_weights(w, C0, C0s, C1, C1s, self.taps, 1)
+        split = aux is not None and s1 is not None and getattr(self, "_dgrad_split", False)
+        wpk = None if split else pack_weights(w, C0, C0s, C1, C1s, self.taps, 1)
         bsum_src = s1 is None and s0.wants_bsum_from_dgrad(self, tape.training)      # (asked before s0.grad is allocated)
         tgt = []
         for s in (s0, s1):
@@ -647,6 +672,12 @@ class ConvNode(_Node):
         if aux is not None:
             # dpre is formed by the loader of the wave-specialised kernel from (dy, a) (_bwd_fusable guarantees support)
             assert add0 is None and scratch is None
+            if split:
+                for s, off in ((s0, 0), (s1, C0)):
+                    wh = pack_weights_range(w, off, s.C, s.Cs, self.taps, 1)
+                    L.call("amx_conv2d_dgrad_fused", L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3), self.slope,
+                           cos, L.ptr(wh), L.ptr(s.grad), s.Cs, None, 0, N, H, W, self.taps, self.dil, sp)
+                return
             if s1 is None and bsum_src:
                 # the gradient written here is the whole dy of the source layer: its BatchNorm-backward sums come out of
                 # this kernel's epilogue, amx_bn_bwd_reduce is not launched for it (ConvNode.backward reads s0.bstats)

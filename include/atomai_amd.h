@@ -187,6 +187,10 @@ int amx_conv1_wgrad_fused(const float* x, const float* dy, const float* aux, con
 int amx_pack_weights(const float* w_oihw, float* dst, int cout, int C0, int C0s, int C1, int C1s,
                      int taps, int mode, void* stream);
 long amx_pack_weights_size(int cout, int C0s, int C1s, int taps, int mode);
+/* amx_pack_weights of the sliced weight w[:, ci_off : ci_off + Cn] (one source of a concatenation), without the slice:
+ * the image of a convolution over that source alone (size amx_pack_weights_size(cout, Cns, 0, taps, mode)). */
+int amx_pack_weights_range(const float* w_oihw, float* dst, int cout, int cin_total, int ci_off, int Cn, int Cns,
+                           int taps, int mode, void* stream);
 /* n images in one launch per 8 jobs; w / dst: host arrays of n device pointers, desc: n x (cout, C0, C0s, C1, C1s, taps,
  * mode) */
 int amx_pack_weights_batch(const void* const* w, void* const* dst, const int* desc, int n, void* stream);

@@ -582,6 +582,9 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
     from atomai_amd.nets import ConvBlock, ResModule
     set_knob(monkeypatch, "AMX_CONV_WS", "1")
     set_knob(monkeypatch, "AMX_CONV_WS_DGRAD", "7")
+    import atomai_amd.engine as eng
+    monkeypatch.setattr(eng, "DGRAD_SPLIT", False)       # (one launch per fused layer here; the two-launch form of a two-source
+    #                                                       layer has its own test: check_split_two_source_dgrad)
     out, calls = {}, {}
     real_call = L.call
     # "1" / "0": loaders vs two-pass form with the BatchNorm-backward sums from amx_bn_bwd_reduce in both (bit-identity);
@@ -841,3 +844,46 @@ def check_lattice_xpack_bit_identical(device, monkeypatch, cases=((52, 50, 44, 7
         L.set_knob("AMX_CONV_XPACK", None)
         assert torch.equal(ys[0], ys[1]), (cin, cout, H, W, dil, "forward")
         assert torch.equal(gs[0], gs[1]), (cin, cout, H, W, dil, "dgrad")
+
+
+def check_split_two_source_dgrad(device, monkeypatch, hw=32, batch=2):
+    """Round 6: the data gradient of a layer that read a concatenation of two 32-channel sources (U-Net c5.0) runs as two
+    launches of the wave-specialised kernel, one per source, each with the BatchNorm / LeakyReLU backward formed by its
+    loader and the weight image of its half (amx_pack_weights_range) — against the single general-kernel launch behind
+    amx_bn_bwd_apply: both source gradients and the weight gradient BIT-IDENTICAL (same MFMA order per output, same
+    dpre arithmetic), the layer's amx_bn_bwd_apply pass gone."""
+    import atomai_amd.engine as eng
+    from atomai_amd import _lib as L
+    import torch.nn as nn
+    from atomai_amd.engine import Tape
+    set_knob(monkeypatch, "AMX_CONV_WS", "1")
+    set_knob(monkeypatch, "AMX_CONV_WS_DGRAD", "7")
+    set_knob(monkeypatch, "AMX_BWD_FUSE", "1")
+    torch.manual_seed(11)
+    conv = nn.Conv2d(64, 32, 3, padding=1).to(device)
+    bn = nn.BatchNorm2d(32).to(device)
+    xs = [torch.randn(batch, 32, hw, hw, device=device) for _ in range(2)]
+    gy = torch.randn(batch, 32, hw, hw, device=device)
+    res, calls = {}, {}
+    real_call = L.call
+    for split in (True, False):
+        monkeypatch.setattr(eng, "DGRAD_SPLIT", split)
+        cnt = {}
+
+        def counting(name, *a, _c=cnt):
+            _c[name] = _c.get(name, 0) + 1
+            return real_call(name, *a)
+        monkeypatch.setattr(L, "call", counting)
+        xin = [x.clone().requires_grad_(True) for x in xs]
+        tape = Tape(True, True)
+        ins = [tape.input(x) for x in xin]
+        o = tape.output(tape.conv([n.out for n in ins], conv, bn, 0.01))
+        o.grad_out = gy
+        tape.backward()
+        monkeypatch.setattr(L, "call", real_call)
+        res[split] = [n.grad_nchw.clone() for n in ins] + [tape.param_grads[id(conv.weight)][1].clone()]
+        calls[split] = cnt
+    assert calls[True].get("amx_conv2d_dgrad_fused", 0) == 2 and calls[True].get("amx_bn_bwd_apply", 0) == 0, calls
+    assert calls[False].get("amx_conv2d_dgrad_fused", 0) == 0 and calls[False].get("amx_bn_bwd_apply", 0) == 1, calls
+    for a, b, nm in zip(res[True], res[False], ("dx0", "dx1", "dW")):
+        assert torch.equal(a, b), nm

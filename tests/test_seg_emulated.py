@@ -221,3 +221,7 @@ def test_hooked_block_by_block_forward_equals_fused():
 
 def test_lattice_xpack_is_bit_identical(monkeypatch):
     C.check_lattice_xpack_bit_identical("cpu", monkeypatch, cases=((52, 50, 20, 70, 1, 6), (28, 50, 13, 29, 1, 4)))
+
+
+def test_two_source_data_gradient_as_two_wave_specialised_launches(monkeypatch):
+    C.check_split_two_source_dgrad("cpu", monkeypatch)

@@ -527,3 +527,7 @@ def test_hooked_block_by_block_forward_equals_fused():
 
 def test_lattice_xpack_is_bit_identical(monkeypatch):
     C.check_lattice_xpack_bit_identical("cuda", monkeypatch)
+
+
+def test_two_source_data_gradient_as_two_wave_specialised_launches(monkeypatch):
+    C.check_split_two_source_dgrad("cuda", monkeypatch)

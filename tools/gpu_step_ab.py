@@ -31,6 +31,7 @@ def setenv(v):
     engine.FUSE_POOL = os.environ.get("AMX_FUSE_POOL", "1") != "0"
     engine.FUSE_UPCONV = os.environ.get("AMX_FUSE_UPCONV", "1") != "0"
     engine.FIRST_WGRAD_MAIN = os.environ.get("AMX_FIRST_WGRAD_MAIN", "1") != "0"
+    engine.DGRAD_SPLIT = os.environ.get("AMX_DGRAD_SPLIT", "1") != "0"
     from atomai_amd.losses_metrics import losses
     losses.LOSS_BLOCKS[0] = int(os.environ.get("AMX_LOSS_BLOCKS", "4096"))
 
