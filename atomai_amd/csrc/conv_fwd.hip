@@ -136,10 +136,12 @@ static int conv2d_common(const float* x0, const float* sc0, const float* sh0, in
 #endif
     // XCD-aware block order (conv_kernel.h): the cout blocks of a tile — and, in lattice mode, the d*d residue classes of
     // a tile position, which share cache lines — become neighbours on ONE XCD's L2 instead of being dealt round-robin
-    // over the eight XCDs.  AMX_CONV_XCD: 0 off, 1 every launch, 2 launches with more than one cout block, 3 (default)
-    // dilated launches only.  The counters showed the dilated layers of dilnet fetching 3.3x (dilation 2 / 4) and 7.9x
+    // over the eight XCDs.  AMX_CONV_XCD: 0 off, 1 every launch (default since round 6), 2 launches with more than one cout
+    // block, 3 dilated launches only.  The counters showed the dilated layers of dilnet fetching 3.3x (dilation 2 / 4) and 7.9x
     // (dilation 6) their input from HBM (profiles/r03_pmc_hbm_extra.md); with the XCD-aware order a dilnet frame goes
-    // 1.282 -> 1.257 ms; plain 3x3 layers do not care (U-Net step 17.92 vs 17.93 ms, profiles/r03_conv_xcd_ab.log).
+    // 1.282 -> 1.257 ms; plain 3x3 layers did not care in round 3 (U-Net step 17.92 vs 17.93 ms, profiles/r03_conv_xcd_ab.log); on
+    // the round-6 step the order on EVERY launch is worth 0.1 ms (16.97 -> 16.86 ms, three interleaved repetitions all the same
+    // sign, profiles/r06_logs/r06_xcd_default_ab.log) and cuts the conv family's HBM fetch by 22 % (r05_pmc_hbm_traffic.json).
     const int xm = amx_knobs().conv_xcd;
     a.xcd = xm == 1 || (xm == 2 && amx_round_up(cout, 16) > 32) || (xm == 3 && dil > 1);
     a.xpack = 0; a.xmagic = 0;

@@ -12,7 +12,7 @@ struct AmxKnobs {
     int conv_nt;          // AMX_CONV_NT         0: plan_conv's choice; 1|2|4: cout tiles of 16 per workgroup
     int conv_th;          // AMX_CONV_TH         0: plan_conv's choice; 8|16: tile rows
     int conv_rem;         // AMX_CONV_REM        1: 28 / 52 stored channels as 16+3x4 / 3x16+4 columns; 0: padded 32 / 2x32
-    int conv_xcd;         // AMX_CONV_XCD        0 off, 1 all, 2 launches with > 1 cout block, 3 dilated launches only
+    int conv_xcd;         // AMX_CONV_XCD        0 off, 1 all (default), 2 launches with > 1 cout block, 3 dilated launches only
     int conv_xpack;       // AMX_CONV_XPACK      1: lattice sub-images of one residue row share a tile axis when that saves tiles
     int bwd_fuse;         // AMX_BWD_FUSE        1: BatchNorm / LeakyReLU backward inside the consumers' loaders
     int bwd_sums;         // AMX_BWD_SUMS        1: BatchNorm-backward sums of the source layer in the data-gradient epilogue

@@ -15,7 +15,7 @@ const KnobRow kRows[] = {
     {"AMX_CONV_NT", &AmxKnobs::conv_nt, 0},
     {"AMX_CONV_TH", &AmxKnobs::conv_th, 0},
     {"AMX_CONV_REM", &AmxKnobs::conv_rem, 1},
-    {"AMX_CONV_XCD", &AmxKnobs::conv_xcd, 3},
+    {"AMX_CONV_XCD", &AmxKnobs::conv_xcd, 1},
     {"AMX_CONV_XPACK", &AmxKnobs::conv_xpack, 1},
     {"AMX_BWD_FUSE", &AmxKnobs::bwd_fuse, 1},
     {"AMX_BWD_SUMS", &AmxKnobs::bwd_sums, 1},

@@ -10,21 +10,20 @@ from ...trainers.gptrainer import dklGPTrainer
 class dklGPR(dklGPTrainer):
     """``dklGPR(indim, embedim=2, shared_embedding_space=True, precision='double', ...)``"""
 
-    _noted_exact_gp = False
+    _noted_gp = False
 
     def __init__(self, indim: int, embedim: int = 2, shared_embedding_space: bool = True, **kwargs) -> None:
         super().__init__(indim, embedim, shared_embedding_space, **kwargs)
-        if not dklGPR._noted_exact_gp:
-            dklGPR._noted_exact_gp = True
-            # Stated once per process (SURVEY.md section 8 rows C2-C4, "parity unpinned"): the GP on top of the feature
-            # extractor is NOT the reference's model.
+        if not dklGPR._noted_gp:
+            dklGPR._noted_gp = True
+            # Stated once per process (SURVEY.md section 8 rows C2-C4, "parity unpinned")
             import warnings
-            warnings.warn("atomai_amd.dklGPR evaluates an EXACT dense GP (tiled RBF / Matern covariance on the MI355X, "
-                          "Cholesky solve) on the embedded points; the reference wraps the same base kernel in gpytorch's "
-                          "KISS-GP approximation (GridInterpolationKernel, grid_size=50 — atomai/nets/gp.py:41-46) and "
-                          "trains through gpytorch's CG / Lanczos estimators, so posteriors and hyper-parameter "
-                          "trajectories agree with the reference only up to that approximation; there is no gpytorch in "
-                          "this build to pin them against (oracle/gp_oracle.py)", UserWarning, stacklevel=2)
+            warnings.warn("atomai_amd.dklGPR: the GP layer is the reference's KISS-GP model (GridInterpolationKernel, "
+                          "grid_size=50 - atomai/nets/gp.py:41-46) with its marginal likelihood and posterior evaluated "
+                          "EXACTLY on the grid (csrc/ski.hip + dense m x m algebra), where gpytorch uses CG / Lanczos / "
+                          "LOVE estimators: results agree with the reference up to gpytorch's solver tolerances; embedim > 2 "
+                          "and gp='exact' run a dense exact GP instead.  There is no gpytorch in this build to pin either "
+                          "against (oracle/gp_oracle.py)", UserWarning, stacklevel=2)
 
     def fit(self, X, y, training_cycles: int = 1, **kwargs) -> None:
         _ = self.run(X, y, training_cycles, **kwargs)

@@ -1,11 +1,19 @@
 """Deep-kernel GP modules (reference: atomai/nets/gp.py:14-60).
 
-``fcFeatureExtractor`` keeps the reference's module tree (linear1, relu1, linear2, ...).  The GP layer is an
-EXACT Gaussian process on the embeddings whose covariance (and its gradient) is evaluated by the tiled HIP
-kernels of csrc/kernel_matrix.hip; Cholesky factorisation / triangular solves are library calls
-(torch.linalg -> rocSOLVER), as a GP's dense linear algebra is not part of the hot path named by the
-north_star.  The reference wraps the same base kernel in gpytorch's KISS-GP grid interpolation; gpytorch is
-not vendored, so this layer follows gpytorch's documented closed forms (oracle/gp_oracle.py).
+``fcFeatureExtractor`` keeps the reference's module tree (linear1, relu1, linear2, ...).  The GP layer on the embeddings
+comes in two forms, both around the tiled HIP covariance builder of csrc/kernel_matrix.hip:
+
+* ``gp="kissgp"`` (default, embedim <= 2): the reference's model — gpytorch's ``GridInterpolationKernel(base_kernel,
+  num_dims=embedim, grid_size=50)`` (gp.py:41-46): K = W K_UU W^T with K_UU the base kernel on a regular grid and W cubic
+  interpolation weights (csrc/ski.hip).  The marginal log likelihood and the posterior of THAT model are evaluated exactly
+  through the matrix-inversion / determinant lemmas on the m = grid_size^embedim grid nodes (O(N + m^3) per step instead of
+  the dense O(N^3)); gpytorch reaches the same quantities with CG / stochastic Lanczos estimators (training) and LOVE
+  (``fast_pred_var``), i.e. up to ITS solver tolerances.
+* ``gp="exact"``: a dense exact GP (Cholesky through torch.linalg -> rocSOLVER); also the fallback for embedim > 2, where
+  the dense m x m grid algebra does not fit (gpytorch uses Kronecker / Toeplitz structure there).
+
+gpytorch is not vendored and not installed: both forms follow its published conventions (oracle/gp_oracle.py) and stay
+PARITY-UNPINNED.
 """
 import math
 from typing import Type
@@ -169,14 +177,238 @@ class _ExactMLLFn(torch.autograd.Function):
         return g * dZ, g * d_y, g * d_ls, g * d_s2, g * d_noise, g * d_mean, None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# KISS-GP (csrc/ski.hip)
+class SkiGrid:
+    """The interpolation grid of gpytorch's GridInterpolationKernel when no ``grid_bounds`` are passed (the reference passes
+    none, gp.py:45-46): DYNAMIC — (re)built from the per-dimension range of the inputs whenever it has never been built
+    or an input falls outside the current 'tight' bounds (GridInterpolationKernel.forward / _tight_grid_bounds):
+        spacing = (max - min) / (G - 4.02);   bounds = (min - 2.01 spacing, max + 2.01 spacing)
+        tight bounds = (lo + 2.01 (hi - lo) / G, hi - 2.01 (hi - lo) / G)
+    and the nodes are gpytorch.utils.grid.create_grid(extend=True): linspace(lo - d, hi + d, G), d = (hi - lo) / (G - 2)."""
+
+    def __init__(self, D: int, G: int):
+        self.D, self.G = D, G
+        self.bounds = None                   # [(lo, hi)] per dimension
+        self.version = 0
+        self._dev = {}
+
+    @property
+    def m(self) -> int:
+        return self.G ** self.D
+
+    def tight_bounds(self):
+        return [(lo + 2.01 * (hi - lo) / self.G, hi - 2.01 * (hi - lo) / self.G) for lo, hi in self.bounds]
+
+    def update(self, *Zs) -> bool:
+        """gpytorch's rule on the union of the given point sets; True when the grid was rebuilt."""
+        mins = torch.stack([Z.detach().min(0)[0] for Z in Zs]).min(0)[0].double().tolist()
+        maxs = torch.stack([Z.detach().max(0)[0] for Z in Zs]).max(0)[0].double().tolist()
+        if self.bounds is not None and not any(mn < lo or mx > hi for mn, mx, (lo, hi) in zip(mins, maxs, self.tight_bounds())):
+            return False
+        sp = [(mx - mn) / (self.G - 4.02) for mn, mx in zip(mins, maxs)]
+        sp = [v if v > 0 else 1.0 for v in sp]                  # (a degenerate dimension: any spacing covers it)
+        bounds = [(mn - 2.01 * v, mx + 2.01 * v) for mn, mx, v in zip(mins, maxs, sp)]
+        if bounds == self.bounds:            # (the tight bounds re-derive min / max with rounding: the same data can land a
+            return False                     # few ulps outside them, and gpytorch then rebuilds the IDENTICAL grid)
+        self.bounds = bounds
+        self.version += 1
+        self._dev = {}
+        return True
+
+    def nodes_1d(self):
+        out = []
+        for lo, hi in self.bounds:
+            d = (hi - lo) / (self.G - 2)
+            out.append((lo - d, (hi - lo + 2 * d) / (self.G - 1)))          # (first node, node spacing)
+        return out
+
+    def tensors(self, dtype, device):
+        """(g0 [D], inv_delta [D], U [m][D]) on the device; U in node order i0 * G + i1."""
+        key = (dtype, str(device))
+        if key not in self._dev:
+            nd = self.nodes_1d()
+            g0 = torch.tensor([a for a, _ in nd], dtype=torch.float64)
+            dl = torch.tensor([b for _, b in nd], dtype=torch.float64)
+            ax = [g0[d] + dl[d] * torch.arange(self.G, dtype=torch.float64) for d in range(self.D)]
+            U = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, self.D)
+            self._dev[key] = (g0.to(dtype).to(device), (1.0 / dl).to(dtype).to(device), U.to(dtype).to(device).contiguous())
+        return self._dev[key]
+
+
+def ski_weights(Z: torch.Tensor, grid: SkiGrid):
+    """(base [N][D] int32, w [N][D][4], dw [N][D][4]) of the points Z on the grid (amx_ski_weights)."""
+    Z = Z.detach().contiguous()
+    N, D = Z.shape
+    g0, inv_delta, _ = grid.tensors(Z.dtype, Z.device)
+    base = torch.empty(N, D, dtype=torch.int32, device=Z.device)
+    w = torch.empty(N, D, 4, dtype=Z.dtype, device=Z.device)
+    dw = torch.empty_like(w)
+    L.call("amx_ski_weights", L.ptr(Z), L.ptr(g0), L.ptr(inv_delta), N, D, grid.G, int(Z.dtype == torch.float64),
+           L.ptr(base), L.ptr(w), L.ptr(dw), L.stream_ptr(Z))
+    return base, w, dw
+
+
+def _ski_cells(base: torch.Tensor, G: int):
+    """Point indices sorted by grid cell and the first position of every cell (plumbing-size integer work in torch)."""
+    D = base.shape[1]
+    nc = G - 3
+    cell = base[:, 0].long() if D == 1 else base[:, 0].long() * nc + base[:, 1].long()
+    order = torch.sort(cell, stable=True)[1]
+    counts = torch.bincount(cell, minlength=nc ** D)
+    start = torch.zeros(nc ** D + 1, dtype=torch.int32, device=base.device)
+    start[1:] = counts.cumsum(0).to(torch.int32)
+    return order.to(torch.int32).contiguous(), start
+
+
+def ski_gram(base, w, R, grid: SkiGrid, need_A: bool = True):
+    """A = W^T W [m][m] (or None) and b = W^T r [C][m] for R [C][N] (amx_ski_gram)."""
+    N, D = base.shape
+    G, m = grid.G, grid.m
+    C = 0 if R is None else R.shape[0]
+    order, start = _ski_cells(base, G)
+    nws = ((G - 3) ** D) * ((4 ** D) ** 2 + C * 4 ** D)
+    ws = torch.empty(nws, dtype=w.dtype, device=w.device)
+    A = torch.empty(m, m, dtype=w.dtype, device=w.device) if need_A else None
+    b = torch.empty(C, m, dtype=w.dtype, device=w.device) if C else None
+    L.call("amx_ski_gram", L.ptr(w), L.ptr(R.contiguous()) if C else None, L.ptr(order), L.ptr(start), N, D, G, C,
+           int(w.dtype == torch.float64), L.ptr(ws), L.ptr(A) if need_A else None, L.ptr(b) if C else None, L.stream_ptr(w))
+    return A, b
+
+
+def ski_interp(base, w, V, grid: SkiGrid):
+    """W V^T: [C][N] for node vectors V [C][m] (amx_ski_interp)."""
+    N, D = base.shape
+    V = V.contiguous()
+    Y = torch.empty(V.shape[0], N, dtype=w.dtype, device=w.device)
+    L.call("amx_ski_interp", L.ptr(base), L.ptr(w), L.ptr(V), N, D, grid.G, V.shape[0], int(w.dtype == torch.float64),
+           L.ptr(Y), L.stream_ptr(w))
+    return Y
+
+
+def ski_cov(base1, w1, base2, w2, Q, grid: SkiGrid, scale: float = 1.0, diag: bool = False):
+    """scale * W1 Q W2^T ([N1][N2]) or its diagonal (amx_ski_cov)."""
+    N1, D = base1.shape
+    N2 = base2.shape[0]
+    out = torch.empty(N1 if diag else (N1, N2), dtype=w1.dtype, device=w1.device)
+    L.call("amx_ski_cov", L.ptr(base1), L.ptr(w1), N1, L.ptr(base2), L.ptr(w2), N2, L.ptr(Q.contiguous()), D, grid.G,
+           float(scale), int(diag), int(w1.dtype == torch.float64), L.ptr(out), L.stream_ptr(w1))
+    return out
+
+
+def _ski_solve(Kuu, A, b, sig2):
+    """The m x m core shared by training and prediction.  With M = sig2 I + K_UU A (eigenvalues sig2 + eig(A^1/2 K_UU A^1/2)
+    >= sig2: LU without a factorisation of the ill-conditioned K_UU itself):
+        P = M^-1,  x = P K_UU b = K_UU W^T Khat^-1 r,  log det M,     Khat = W K_UU W^T + sig2 I."""
+    m = Kuu.shape[0]
+    M = Kuu @ A
+    M.diagonal().add_(sig2)
+    LU, piv, _ = torch.linalg.lu_factor_ex(M)          # (no host round trip for an error flag: M is never singular)
+    del M
+    logdet = LU.diagonal().abs().log().sum()
+    P = torch.linalg.lu_solve(LU, piv, torch.eye(m, dtype=Kuu.dtype, device=Kuu.device))
+    x = P @ (Kuu @ b)
+    return P, x, logdet
+
+
+class _SkiMLLFn(torch.autograd.Function):
+    """(Z, Y [q][N], lengthscale [q][D], outputscale [q], noise [q], mean [q]) -> sum over the q outputs of the per-datum
+    marginal log likelihood of the KISS-GP model  y ~ N(mean, W K_UU W^T + noise I):
+        r^T Khat^-1 r = (r.r - b.x) / noise,          log det Khat = (N - m) log noise + log det(noise I + K_UU A),
+    A = W^T W, b = W^T r (csrc/ski.hip), x = (noise I + K_UU A)^-1 K_UU b.  Backward in closed form (u = W^T Khat^-1 r =
+    (b - A x) / noise, Q = M^-1 K_UU = noise^-1 * posterior covariance of the grid values):
+        d/dA = -(x x^T / noise + Q) / 2,   d/db = x / noise,   d/dK_UU = (u u^T - M^-T A) / 2,
+        d/dnoise = (quad - u.x) / (2 noise) - (tr M^-1 + (N - m) / noise) / 2
+    then amx_ski_gram_bwd (points) and amx_kernel_matrix_bwd on the grid (lengthscale, outputscale)."""
+
+    @staticmethod
+    def forward(ctx, Z, Y, lengthscale, outputscale, noise, mean, kind, grid):
+        N, D = Z.shape
+        q, m = Y.shape[0], grid.m
+        with _phase("ski_gram"):
+            base, w, dw = ski_weights(Z, grid)
+            R = (Y.detach() - mean.detach().reshape(q, 1)).contiguous()
+            A, b = ski_gram(base, w, R, grid)
+        _, _, U = grid.tensors(Z.dtype, Z.device)
+        tot = 0
+        per = []
+        for i in range(q):
+            sig2, s2 = float(noise[i]), float(outputscale[i])
+            with _phase("k_build"):
+                Kuu = kernel_matrix(U, U, lengthscale[i], s2, kind)
+            with _phase("grid_solve"):
+                P, x, logdet = _ski_solve(Kuu, A, b[i], sig2)
+                quad = ((R[i] * R[i]).sum() - (b[i] * x).sum()) / sig2
+                u = (b[i] - A @ x) / sig2
+                tot = tot + (-0.5 * quad - 0.5 * ((N - m) * math.log(sig2) + logdet) - 0.5 * N * math.log(2 * math.pi)) / N
+            per.append((P, x, u, quad, sig2, s2))
+            del Kuu
+        ctx.save_for_backward(lengthscale.detach())
+        ctx.state = (base, w, dw, R, A, per, kind, grid, N, D)
+        return tot
+
+    @staticmethod
+    def backward(ctx, g):
+        (ls,) = ctx.saved_tensors
+        base, w, dw, R, A, per, kind, grid, N, D = ctx.state
+        q, m = R.shape[0], grid.m
+        dt, dev = R.dtype, R.device
+        _, _, U = grid.tensors(dt, dev)
+        GA = torch.zeros(m, m, dtype=dt, device=dev)
+        gb = torch.empty(q, m, dtype=dt, device=dev)
+        d_ls, d_s2, d_noise, g_rr = [], [], [], []
+        for i, (P, x, u, quad, sig2, s2) in enumerate(per):
+            with _phase("k_build"):
+                Kuu = kernel_matrix(U, U, ls[i], s2, kind)
+            with _phase("grid_bwd"):
+                Qm = P @ Kuu
+                GA.add_(torch.outer(x, x) / sig2 + 0.5 * (Qm + Qm.T), alpha=-0.5 / N)
+                gb[i] = x / (sig2 * N)
+                PtA = P.T @ A
+                GK = (torch.outer(u, u) - 0.5 * (PtA + PtA.T)) * (0.5 / N)
+                d_noise.append((0.5 * (quad - (u * x).sum()) / sig2 - 0.5 * (torch.diagonal(P).sum() + (N - m) / sig2)) / N)
+                g_rr.append(-0.5 / (sig2 * N))
+                del Qm, PtA
+            with _phase("k_bwd"):
+                dU = torch.empty_like(U)
+                part = torch.empty((m + 3) // 4, D + 1, dtype=dt, device=dev)
+                inv_ls = (1.0 / ls[i].reshape(-1)).to(dt).contiguous()
+                L.call("amx_kernel_matrix_bwd", L.ptr(U), L.ptr(inv_ls), s2, kind, m, D, int(dt == torch.float64),
+                       L.ptr(GK.contiguous()), L.ptr(dU), L.ptr(part), L.stream_ptr(U))
+                tot = part.sum(0)
+                d_ls.append((-tot[:D] * inv_ls * inv_ls).reshape(ls[i].shape))
+                d_s2.append(tot[D])
+                del GK, Kuu
+        with _phase("ski_gram_bwd"):
+            dZ = torch.empty(N, D, dtype=dt, device=dev)
+            dr = torch.empty(q, N, dtype=dt, device=dev)
+            L.call("amx_ski_gram_bwd", L.ptr(base), L.ptr(w), L.ptr(dw), L.ptr(R), L.ptr(GA), L.ptr(gb), N, D, grid.G, q,
+                   int(dt == torch.float64), L.ptr(dZ), L.ptr(dr), L.stream_ptr(w))
+            dr = dr + 2.0 * torch.tensor(g_rr, dtype=dt, device=dev).reshape(q, 1) * R
+        return (g * dZ, g * dr, g * torch.stack(d_ls), g * torch.stack(d_s2), g * torch.stack(d_noise),
+                -g * dr.sum(1), None, None)
+
+
 class GPRegressionModel(nn.Module):
     """DKL GP regression module: feature extractor -> ScaleToBounds(-1, 1) -> ConstantMean + ScaleKernel(RBF
     with ARD lengthscales) for each of the q outputs sharing the embedding (gp.py:29-60)."""
 
+    MAX_GRID_NODES = 4096        # dense m x m grid algebra: 50^2 = 2500 nodes = 25 MB per fp32 matrix
+
     def __init__(self, X: torch.Tensor, y: torch.Tensor, feature_extractor: Type[nn.Module], embedim: int,
-                 kernel: str = "rbf") -> None:
+                 kernel: str = "rbf", grid_size: int = 50, gp: str = "kissgp") -> None:
         super().__init__()
         q = y.shape[0]
+        if gp not in ("kissgp", "exact"):
+            raise ValueError("gp must be 'kissgp' (the reference's GridInterpolationKernel model) or 'exact'")
+        if gp == "kissgp" and (embedim > 2 or grid_size < 4 or grid_size ** embedim > self.MAX_GRID_NODES or q > 8):
+            import warnings
+            warnings.warn(f"KISS-GP with grid_size={grid_size}, embedim={embedim}, {q} outputs is outside what the dense grid "
+                          "algebra of this build covers (embedim <= 2, grid_size^embedim <= 4096, <= 8 outputs): using the "
+                          "exact dense GP instead", UserWarning, stacklevel=2)
+            gp = "exact"
+        self.gp = gp
+        self.grid = SkiGrid(embedim, grid_size) if gp == "kissgp" else None
         self.train_inputs, self.train_targets = (X,), y
         self.feature_extractor = feature_extractor
         self.kind = {"rbf": 0, "matern": 1}[kernel]
@@ -219,6 +451,10 @@ class GPRegressionModel(nn.Module):
         with _phase("extractor_fwd"):
             Z = self.embed(self.train_inputs[0])
         self._cache = None
+        if self.gp == "kissgp":
+            self.grid.update(Z)
+            return _SkiMLLFn.apply(Z, self.train_targets, self.lengthscale, self.outputscale, self.noise[:, 0],
+                                   self.mean_constant[:, 0], self.kind, self.grid)
         tot = 0
         for i in range(self.train_targets.shape[0]):
             tot = tot + _ExactMLLFn.apply(Z, self.train_targets[i], self.lengthscale[i], self.outputscale[i],
@@ -240,11 +476,30 @@ class GPRegressionModel(nn.Module):
         """(Z_train, [(cholesky(K + noise I), alpha = K^-1 (y - mu)) per output]) — computed ONCE per model state
         and reused by every predict batch (dklgpr.py:202-217 calls the posterior per DataLoader batch; without the
         cache each batch redid the O(N^3) factorisation)."""
-        key = self._state_key()
+        key = self._state_key() + ((self.grid.version,) if self.gp == "kissgp" else ())
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1], self._cache[2]
         Z = self.embed(self.train_inputs[0])
         factors = []
+        if self.gp == "kissgp":
+            # per output: x = K_UU W^T Khat^-1 r (the node values of the predictive mean) and noise * Q = the posterior
+            # covariance of the node values, both m-sized; the same core as the training step (_ski_solve)
+            grid = self.grid
+            grid.update(Z)                   # (gpytorch applies its grid rule on every kernel call, train or eval mode)
+            base, w, _ = ski_weights(Z, grid)
+            q = self.train_targets.shape[0]
+            R = (self.train_targets - self.mean_constant.reshape(q, 1)).contiguous()
+            A, b = ski_gram(base, w, R, grid)
+            _, _, U = grid.tensors(Z.dtype, Z.device)
+            for i in range(q):
+                nz = float(self.noise[i, 0])
+                Kuu = kernel_matrix(U, U, self.lengthscale[i], float(self.outputscale[i]), self.kind)
+                P, x, _ = _ski_solve(Kuu, A, b[i], nz)
+                Qm = P @ Kuu
+                factors.append((x, (0.5 * nz) * (Qm + Qm.T)))
+            self._cache = (self._state_key() + (grid.version,), Z, factors)
+            self.n_factorisations = getattr(self, "n_factorisations", 0) + 1
+            return Z, factors
         for i in range(self.train_targets.shape[0]):
             ls, s2, nz, mu = self.lengthscale[i], float(self.outputscale[i]), float(self.noise[i, 0]), self.mean_constant[i, 0]
             K = kernel_matrix(Z, Z, ls, s2, self.kind, nz)
@@ -262,6 +517,17 @@ class GPRegressionModel(nn.Module):
         Z, factors = self._posterior_factors()
         Zs = self.embed(x_new)
         means, vars_ = [], []
+        if self.gp == "kissgp":
+            # gpytorch evaluates the kernel on cat(train, test) at prediction time: test points outside the tight bounds
+            # rebuild the (dynamic) grid over the union of both sets
+            if self.grid.update(Z, Zs):
+                Z, factors = self._posterior_factors()
+            bs, ws, _ = ski_weights(Zs, self.grid)
+            for i, (x, Qs) in enumerate(factors):
+                means.append(self.mean_constant[i, 0] + ski_interp(bs, ws, x.reshape(1, -1), self.grid).reshape(-1))
+                v = ski_cov(bs, ws, bs, ws, Qs, self.grid, 1.0, diag=not full_cov)
+                vars_.append(v if full_cov else v.clamp_min(0))
+            return torch.stack(means), torch.stack(vars_)
         for i in range(self.train_targets.shape[0]):
             ls, s2, mu = self.lengthscale[i], float(self.outputscale[i]), self.mean_constant[i, 0]
             Lc, alpha = factors[i]

@@ -26,6 +26,8 @@ class dklGPTrainer:
         self.dtype = torch.float32 if precision == "single" else torch.float64
         self.correlated_output = shared_embedding_space
         self.ensemble = False
+        # GP layer: "kissgp" = the reference's GridInterpolationKernel model (gp.py:41-46), "exact" = dense exact GP
+        self.gp_kind = kwargs.get("gp", "kissgp")
         self.gp_model = None
         self.likelihood = None
         self.compiled = False
@@ -84,7 +86,8 @@ class dklGPTrainer:
         models = []
         for i in range(y.shape[0]):
             fx = new_extractor() if self.ensemble else copy.deepcopy(shared_init)
-            models.append(GPRegressionModel(X, y[i:i + 1], fx, embedim, kwargs.get("base_kernel", "rbf")))
+            models.append(GPRegressionModel(X, y[i:i + 1], fx, embedim, kwargs.get("base_kernel", "rbf"),
+                                            kwargs.get("grid_size", 50), self.gp_kind))
         self.gp_model = GPModelList(models).to(self.device)
         self.likelihood = self.gp_model
         self.gp_model.train()
@@ -123,7 +126,8 @@ class dklGPTrainer:
         if freeze:
             for p in feature_extractor.parameters():
                 p.requires_grad = False
-        self.gp_model = GPRegressionModel(X, y, feature_extractor, embedim, kwargs.get("base_kernel", "rbf"))
+        self.gp_model = GPRegressionModel(X, y, feature_extractor, embedim, kwargs.get("base_kernel", "rbf"),
+                                          kwargs.get("grid_size", 50), self.gp_kind)
         self.gp_model.to(self.device)
         self.likelihood = self.gp_model          # the Gaussian noise lives in the same module (raw_noise)
         self.gp_model.train()

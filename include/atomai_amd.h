@@ -426,6 +426,32 @@ int amx_kernel_matrix_bwd_mll(const void* X, const void* inv_ls, double outputsc
                               int is_double, const void* Kinv, const void* alpha, double gscale, void* dX, void* part,
                               void* stream);
 
+/* ---- KISS-GP (structured kernel interpolation): the reference's covariance module is
+ * gpytorch.kernels.GridInterpolationKernel(base_kernel, num_dims=embedim, grid_size=50) (atomai/nets/gp.py:41-46), trained
+ * through ExactMarginalLogLikelihood (atomai/trainers/gptrainer.py:126-137, 303) and predicted with fast_pred_var
+ * (atomai/models/dklgp/dklgpr.py:146-156):  K(X, X') = W(X) K_UU W(X')^T with K_UU = amx_kernel_matrix on a regular grid
+ * of G nodes per embedding dimension and W the cubic-convolution interpolation weights (4 nodes per dimension).  D = 1 or
+ * 2; node index = i0 * G + i1; `base` [N][D] = first stencil node per dimension, `w` / `dw` [N][D][4] = weights and their
+ * derivatives w.r.t. the coordinate; C <= 8 right-hand sides; is_double selects fp64 buffers.  No float atomics: sums run
+ * in a fixed order over `order` (point indices sorted by cell = base[.][0] * (G - 3) + base[.][1]) and `cell_start`
+ * [(G-3)^D + 1] (first position of each cell in `order`). */
+int amx_ski_weights(const void* Z, const void* g0, const void* inv_delta, int N, int D, int G, int is_double, int* base,
+                    void* w, void* dw, void* stream);
+/* elements (of the value type) of amx_ski_gram's workspace `ws`, or -1 */
+long amx_ski_gram_workspace(int D, int G, int C);
+/* A [m][m] = W^T W (or NULL) and b [C][m] = W^T r for r [C][N], m = G^D */
+int amx_ski_gram(const void* w, const void* r, const int* order, const int* cell_start, int N, int D, int G, int C,
+                 int is_double, void* ws, void* A, void* b, void* stream);
+/* backward of amx_ski_gram: GA = dL/dA [m][m] (symmetric), gb = dL/db [C][m]  ->  dZ [N][D], dr [C][N] */
+int amx_ski_gram_bwd(const int* base, const void* w, const void* dw, const void* r, const void* GA, const void* gb, int N,
+                     int D, int G, int C, int is_double, void* dZ, void* dr, void* stream);
+/* Y [C][N] = W V^T for node vectors V [C][m] (predictive means) */
+int amx_ski_interp(const int* base, const void* w, const void* V, int N, int D, int G, int C, int is_double, void* Y,
+                   void* stream);
+/* out [N1][N2] = scale * W1 Q W2^T for Q [m][m]; diag != 0: out [N1] = its diagonal (N1 == N2) */
+int amx_ski_cov(const int* base1, const void* w1, int N1, const int* base2, const void* w2, int N2, const void* Q, int D,
+                int G, double scale, int diag, int is_double, void* out, void* stream);
+
 /* ---- Locator: thresholded class maps -> blob centres (atomai/predictors/predictor.py:531-639 Locator.run /
  *      rem_edge_coord; atomai/utils/img.py:554-564 cv_thresh; atomai/utils/coords.py:21-34 find_com =
  *      scipy.ndimage.label + center_of_mass).  prob: (B,H,W,C) fp32 NHWC probabilities; the first `nch`

@@ -95,22 +95,70 @@ def ski_interp_weights(x, grid):
     return _keys_cubic((np.asarray(x, np.float64)[:, None] - grid[None, :]) / h)
 
 
+def ski_dynamic_bounds(X, grid_size=50):
+    """Grid bounds per dimension as GridInterpolationKernel.forward sets them when none were passed (the reference passes
+    none: atomai/nets/gp.py:45-46) and the grid has not been built yet or an input left the tight bounds:
+    spacing = (max - min) / (grid_size - 4.02);  bounds = (min - 2.01 spacing, max + 2.01 spacing)."""
+    X = np.asarray(X, np.float64)
+    out = []
+    for mn, mx in zip(X.min(0), X.max(0)):
+        sp = (mx - mn) / (grid_size - 4.02)
+        out.append((mn - 2.01 * sp, mx + 2.01 * sp))
+    return out
+
+
+def _per_dim_bounds(bounds, D):
+    b = np.asarray(bounds, np.float64)
+    return [tuple(b)] * D if b.ndim == 1 else [tuple(v) for v in b]
+
+
+def ski_weights_and_grid(X, grid_size=50, bounds=(-1.0, 1.0)):
+    """(W [n][grid_size^D], U [grid_size^D][D]): dense interpolation weights on the product grid; node order i0 * G + i1."""
+    X = np.asarray(X, np.float64)
+    D = X.shape[1]
+    gs = [ski_grid(grid_size, b) for b in _per_dim_bounds(bounds, D)]
+    W = np.ones((X.shape[0], 1))
+    for d in range(D):                                        # Kronecker structure of the product grid, row-wise
+        Wd = ski_interp_weights(X[:, d], gs[d])
+        W = (W[:, :, None] * Wd[:, None, :]).reshape(X.shape[0], -1)
+    U = np.stack(np.meshgrid(*gs, indexing="ij"), -1).reshape(-1, D)
+    return W, U
+
+
 def ski_kernel_matrix(X1, X2, lengthscale, outputscale, kind="rbf", grid_size=50, bounds=(-1.0, 1.0)):
-    """K_SKI(X1, X2) = W1 K_UU W2^T on the product grid of `grid_size` points per embedding dimension."""
+    """K_SKI(X1, X2) = W1 K_UU W2^T on the product grid of `grid_size` points per embedding dimension (`bounds`: one
+    (lo, hi) pair for every dimension or one pair per dimension)."""
     X1, X2 = np.asarray(X1, np.float64), np.asarray(X2, np.float64)
     D = X1.shape[1]
-    g = ski_grid(grid_size, bounds)
     ls = np.broadcast_to(np.asarray(lengthscale, np.float64).reshape(-1), (D,))
-
-    def weights(X):
-        W = np.ones((X.shape[0], 1))
-        for d in range(D):                                    # Kronecker structure of the product grid, row-wise
-            Wd = ski_interp_weights(X[:, d], g)
-            W = (W[:, :, None] * Wd[:, None, :]).reshape(X.shape[0], -1)
-        return W
-    U = np.stack(np.meshgrid(*([g] * D), indexing="ij"), -1).reshape(-1, D)
+    W1, U = ski_weights_and_grid(X1, grid_size, bounds)
+    W2, _ = ski_weights_and_grid(X2, grid_size, bounds)
     Kuu = kernel_matrix(U, U, ls, outputscale, kind)
-    return weights(X1) @ Kuu @ weights(X2).T
+    return W1 @ Kuu @ W2.T
+
+
+def ski_mll(Z, y, lengthscale, outputscale, noise, mean, kind="rbf", grid_size=50, bounds=(-1.0, 1.0)):
+    """Per-datum marginal log likelihood of y ~ N(mean, K_SKI + noise I): gpytorch's ExactMarginalLogLikelihood on the
+    reference's model, by a dense N x N Cholesky (the product evaluates the same number through m x m grid algebra)."""
+    from scipy.linalg import cho_factor, cho_solve
+    N = len(y)
+    K = ski_kernel_matrix(Z, Z, lengthscale, outputscale, kind, grid_size, bounds) + noise * np.eye(N)
+    c = cho_factor(K, lower=True)
+    r = np.asarray(y, np.float64) - mean
+    return (-0.5 * r @ cho_solve(c, r) - np.log(np.diag(c[0])).sum() - 0.5 * N * np.log(2 * np.pi)) / N
+
+
+def ski_posterior(Z, y, Zs, lengthscale, outputscale, noise, mean, kind="rbf", grid_size=50, bounds=(-1.0, 1.0)):
+    """Latent posterior mean and FULL covariance at Zs of the KISS-GP model (every covariance through the interpolation,
+    the test-test block included, as GridInterpolationKernel evaluates it)."""
+    from scipy.linalg import cho_factor, cho_solve
+    N = len(y)
+    K = ski_kernel_matrix(Z, Z, lengthscale, outputscale, kind, grid_size, bounds) + noise * np.eye(N)
+    Ks = ski_kernel_matrix(Z, Zs, lengthscale, outputscale, kind, grid_size, bounds)
+    Kss = ski_kernel_matrix(Zs, Zs, lengthscale, outputscale, kind, grid_size, bounds)
+    c = cho_factor(K, lower=True)
+    mu = mean + Ks.T @ cho_solve(c, np.asarray(y, np.float64) - mean)
+    return mu, Kss - Ks.T @ cho_solve(c, Ks)
 
 
 def ski_vs_exact(N=400, D=2, lengthscale=0.6931, outputscale=0.6931, kind="rbf", grid_size=50, seed=0):

@@ -153,7 +153,7 @@ def check_posterior_cache(device):
     from oracle import gp_oracle as go
     rs = np.random.RandomState(1)
     X, y = rs.randn(60, 6), np.sin(rs.randn(60))
-    m = aoi.models.dklGPR(6, embedim=2, precision="double", device=device)
+    m = aoi.models.dklGPR(6, embedim=2, precision="double", device=device, gp="exact")
     m.fit(X, y, training_cycles=2)
     Xn = rs.randn(25, 6)
     gm = m.gp_model
@@ -241,7 +241,7 @@ def check_conv_feature_extractor(device, N=24, p=8, nf=4):
         np.testing.assert_allclose(fe.state_dict()[k].cpu().numpy(), ref.state_dict()[kr].numpy(), rtol=1e-4, atol=1e-6)
 
 
-def check_dklgpr_conv_extractor(device, N=256, p=8, cycles=2, precision="single"):
+def check_dklgpr_conv_extractor(device, N=256, p=8, cycles=2, precision="single", gp="kissgp"):
     """dklGPR(feature_extractor=convFeatureExtractor) fit + predict (config 5's shape family): loss finite and
     decreasing over the first cycles, predictions finite, variance within [0, s2], one factorisation per predict."""
     import atomai_amd as aoi
@@ -249,7 +249,7 @@ def check_dklgpr_conv_extractor(device, N=256, p=8, cycles=2, precision="single"
     rs = np.random.RandomState(0)
     X = rs.randn(N, p * p).astype(np.float32)
     y = np.tanh(X[:, : p].sum(1)).astype(np.float32)
-    m = aoi.models.dklGPR(p * p, embedim=2, precision=precision, device=device)
+    m = aoi.models.dklGPR(p * p, embedim=2, precision=precision, device=device, gp=gp)
     m.fit(X, y, training_cycles=cycles, feature_extractor=convFeatureExtractor)
     assert len(m.train_loss) == cycles and all(np.isfinite(m.train_loss))
     m.gp_model.n_factorisations = 0
@@ -303,3 +303,156 @@ def check_extractor_golden(device):
                 fl = np.abs(r32 - r64).max()
                 tol = 1e-9 * max(1.0, np.abs(r64).max()) if dt == torch.float64 else max(4 * fl, 1e-5 * np.abs(r64).max())
                 assert np.abs(got - r64).max() <= tol, (tag, dtag, k, np.abs(got - r64).max(), tol)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# KISS-GP (the reference's GridInterpolationKernel model, csrc/ski.hip + nets/gp.py:_SkiMLLFn)
+def _dense_ski_weights(Z, grid):
+    """Dense torch (autograd) restatement of the interpolation weights on `grid` (oracle/gp_oracle.py:_keys_cubic)."""
+    g0, invd, U = grid.tensors(torch.float64, Z.device)
+    N, D = Z.shape
+
+    def keys(t):
+        u = t.abs()
+        return torch.where(u <= 1, (1.5 * u - 2.5) * u * u + 1,
+                           torch.where(u <= 2, ((-0.5 * u + 2.5) * u - 4) * u + 2, torch.zeros_like(u)))
+    W = torch.ones(N, 1, dtype=torch.float64, device=Z.device)
+    for d in range(D):
+        t = (Z[:, d:d + 1] - g0[d]) * invd[d] - torch.arange(grid.G, dtype=torch.float64, device=Z.device)[None, :]
+        W = (W[:, :, None] * keys(t)[:, None, :]).reshape(N, -1)
+    return W, U
+
+
+def check_ski_mll_and_grads(device, kind, N, D, G, q=2):
+    """_SkiMLLFn (m x m grid algebra + the HIP gather kernels) == the dense N x N evaluation of the SAME model: value vs
+    the numpy oracle, every gradient vs torch autograd through W K_UU W^T + noise I and a Cholesky (fp64)."""
+    from oracle import gp_oracle as go
+    from atomai_amd.nets.gp import SkiGrid, _SkiMLLFn
+    rs = np.random.RandomState(10 * D + G)
+    Z = torch.from_numpy(rs.uniform(-0.9, 0.9, (N, D))).to(device).requires_grad_(True)
+    Y = torch.from_numpy(np.sin(3 * rs.uniform(-1, 1, (q, N)))).to(device)
+    ls = torch.tensor(rs.uniform(0.4, 1.0, (q, 1, D)), device=device, requires_grad=True)
+    s2 = torch.tensor(rs.uniform(0.7, 1.5, q), device=device, requires_grad=True)
+    nz = torch.tensor(rs.uniform(0.05, 0.3, q), device=device, requires_grad=True)
+    mu = torch.tensor(rs.uniform(-0.3, 0.3, q), device=device, requires_grad=True)
+    grid = SkiGrid(D, G)
+    assert grid.update(Z) and not grid.update(Z)
+    k = {"rbf": 0, "matern": 1}[kind]
+    mll = _SkiMLLFn.apply(Z, Y, ls, s2, nz, mu, k, grid)
+    bounds = grid.bounds
+    np.testing.assert_allclose(bounds, go.ski_dynamic_bounds(Z.detach().cpu().numpy(), G), rtol=1e-13)
+    ref = sum(go.ski_mll(Z.detach().cpu().numpy(), Y[i].cpu().numpy(), ls[i].detach().cpu().numpy(), float(s2[i]),
+                         float(nz[i]), float(mu[i]), kind, G, bounds) for i in range(q))
+    assert abs(mll.item() - ref) < 1e-10 * max(1, abs(ref)), (mll.item(), ref)
+    mll.backward()
+    Z2, ls2, s22, nz2, mu2 = (v.detach().clone().requires_grad_(True) for v in (Z, ls, s2, nz, mu))
+    W, U = _dense_ski_weights(Z2, grid)
+    tot = 0
+    for i in range(q):
+        K = W @ _torch_kernel(U, U, ls2[i].reshape(-1), s22[i], kind) @ W.T + nz2[i] * torch.eye(N, dtype=torch.float64, device=device)
+        Lc = torch.linalg.cholesky(K)
+        r = (Y[i] - mu2[i]).reshape(-1, 1)
+        al = torch.cholesky_solve(r, Lc)
+        tot = tot + (-0.5 * (r * al).sum() - torch.log(torch.diagonal(Lc)).sum() - 0.5 * N * math.log(2 * math.pi)) / N
+    tot.backward()
+    for a, b, name in ((Z, Z2, "Z"), (ls, ls2, "ls"), (s2, s22, "s2"), (nz, nz2, "noise"), (mu, mu2, "mean")):
+        scale = float(b.grad.abs().max())
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-7, atol=1e-9 * scale, err_msg=name)
+
+
+def check_ski_gram_is_deterministic_and_ragged(device, dtype):
+    """amx_ski_gram on clustered points (most cells empty, one cell holding a third of the points): equals the dense
+    W^T W / W^T r, is bit-identical between two calls, for D = 1 and 2."""
+    from atomai_amd.nets.gp import SkiGrid, ski_gram, ski_weights
+    rs = np.random.RandomState(3)
+    for D, G, N in ((1, 12, 90), (2, 8, 150)):
+        Zn = rs.uniform(-0.9, 0.9, (N, D))
+        Zn[: N // 3] = 0.3 + 1e-3 * rs.randn(N // 3, D)
+        Z = torch.from_numpy(Zn).to(dtype).to(device)
+        R = torch.from_numpy(rs.randn(3, N)).to(dtype).to(device)
+        grid = SkiGrid(D, G)
+        grid.update(Z)
+        base, w, dw = ski_weights(Z, grid)
+        A, b = ski_gram(base, w, R, grid)
+        A2, b2 = ski_gram(base, w, R, grid)
+        assert torch.equal(A, A2) and torch.equal(b, b2)
+        W, _ = _dense_ski_weights(Z.double(), grid)
+        tol = 1e-12 if dtype == torch.float64 else 2e-5
+        np.testing.assert_allclose(A.double().cpu().numpy(), (W.T @ W).cpu().numpy(), rtol=tol, atol=tol)
+        np.testing.assert_allclose(b.double().cpu().numpy(), (R.double() @ W).cpu().numpy(), rtol=tol, atol=10 * tol)
+        assert float(w.sum(-1).sub(1).abs().max()) < (1e-12 if dtype == torch.float64 else 1e-5)     # weights sum to 1
+        if dtype == torch.float64:                              # derivative of the weights: central differences
+            h = 1e-6
+            bp, wp, _ = ski_weights(Z + h, grid)
+            bm, wm, _ = ski_weights(Z - h, grid)
+            same = ((bp == base) & (bm == base))[..., None]      # (a point that crosses a node changes its stencil)
+            fd = (wp - wm) / (2 * h)
+            err = ((dw - fd).abs() * same).max()
+            assert float(err) < 1e-6 * float(dw.abs().max()) and float(same.double().mean()) > 0.9
+
+
+def check_ski_posterior(device, precision="double"):
+    """dklGPR (default gp='kissgp') fit + predict vs the numpy oracle of the same model at the trained hyper-parameters:
+    mean, variance, full covariance; batched == unbatched; ONE factorisation per model state; the dynamic grid is rebuilt
+    when prediction points leave its tight bounds."""
+    import atomai_amd as aoi
+    from oracle import gp_oracle as go
+    rs = np.random.RandomState(1)
+    X, y = rs.randn(80, 6), np.sin(rs.randn(2, 80))
+    m = aoi.models.dklGPR(6, embedim=2, precision=precision, device=device)
+    m.fit(X, y, training_cycles=2, grid_size=12)
+    gm = m.gp_model
+    assert gm.gp == "kissgp" and gm.grid.G == 12
+    Xn = X[:25]                                             # training points: inside the grid's tight bounds by construction
+    gm.n_factorisations = 0
+    mean_b, var_b = m.predict(Xn, batch_size=4)
+    mean_1, var_1 = m.predict(Xn)
+    assert gm.n_factorisations == 1
+    tol = 1e-9 if precision == "double" else 2e-4
+    np.testing.assert_allclose(mean_b, mean_1, rtol=tol, atol=tol)
+    np.testing.assert_allclose(var_b, var_1, rtol=10 * tol, atol=tol)
+    # off-sample points (they may leave the tight bounds: the dynamic grid then follows, as gpytorch's does); the oracle is
+    # evaluated on the grid the call ended with
+    Xn = X[:25] + 0.05 * rs.randn(25, 6)
+    mean_1, cov = m._compute_posterior(torch.from_numpy(Xn).to(m.dtype), full_cov=True)
+    mean_1 = mean_1.cpu().numpy()
+    var_1 = m._compute_posterior(torch.from_numpy(Xn).to(m.dtype))[1].cpu().numpy()
+    Z, Zs = m.embed(X).astype(np.float64), m.embed(Xn).astype(np.float64)
+    otol = 1e-7 if precision == "double" else 5e-3
+    for i in range(2):
+        mu, C = go.ski_posterior(Z, y[i], Zs, gm.lengthscale[i].detach().cpu().numpy().reshape(-1), float(gm.outputscale[i]),
+                                 float(gm.noise[i, 0]), float(gm.mean_constant[i, 0]), "rbf", 12, gm.grid.bounds)
+        np.testing.assert_allclose(mean_1[i], mu, rtol=otol, atol=otol)
+        np.testing.assert_allclose(var_1[i], np.diag(C), rtol=10 * otol, atol=otol)
+        np.testing.assert_allclose(cov[i].cpu().numpy(), C, rtol=0, atol=10 * otol)
+    # points far outside the training range: the grid is rebuilt over the union and the factors follow
+    v0 = gm.grid.version
+    far = torch.from_numpy(10 * rs.randn(5, 6)).to(m.dtype)
+    mf, vf = m._compute_posterior(far)
+    assert torch.isfinite(mf).all() and (vf >= 0).all()
+    lo, hi = zip(*gm.grid.tight_bounds())
+    zf = m.embed(far.cpu().numpy())
+    assert (zf >= np.array(lo) - 1e-6).all() and (zf <= np.array(hi) + 1e-6).all() and gm.grid.version >= v0
+    samples = m.sample_from_posterior(Xn, num_samples=5)
+    assert samples.shape == (5, 2, 25) and np.isfinite(samples).all()
+
+
+def check_ski_fallbacks():
+    """embedim 3 (50^3 grid nodes) and gp='exact' run the dense exact GP, with a warning in the first case."""
+    import warnings
+    import atomai_amd as aoi
+    rs = np.random.RandomState(0)
+    X, y = rs.randn(30, 5), rs.randn(30)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        m = aoi.models.dklGPR(5, embedim=3, precision="double")
+        m.fit(X, y, training_cycles=1)
+    assert m.gp_model.gp == "exact" and any("exact dense GP" in str(w.message) for w in wlist)
+    m = aoi.models.dklGPR(5, embedim=2, precision="double", gp="exact")
+    m.fit(X, y, training_cycles=1)
+    assert m.gp_model.gp == "exact" and m.gp_model.grid is None
+    m = aoi.models.dklGPR(5, embedim=1, precision="double")
+    m.fit(X, y, training_cycles=2)
+    assert m.gp_model.gp == "kissgp" and m.gp_model.grid.m == 50
+    mean, var = m.predict(X[:7])
+    assert mean.shape == (7,) and (var >= 0).all()

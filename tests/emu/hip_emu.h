@@ -250,6 +250,12 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
 
 static inline void __syncthreads() { emu::syncthreads(); }
 static inline float __shfl_xor(float v, int mask) { return emu::shfl_idx(v, emu::blk().cur->lane ^ mask); }
+static inline double __shfl_xor(double v, int mask) {      // (two 32-bit halves through the float exchange: bit patterns are copied, never computed on)
+    float h[2]; memcpy(h, &v, 8);
+    const int src = emu::blk().cur->lane ^ mask;
+    h[0] = emu::shfl_idx(h[0], src); h[1] = emu::shfl_idx(h[1], src);
+    double o; memcpy(&o, h, 8); return o;
+}
 static inline float __shfl_down(float v, int d) { int l = emu::blk().cur->lane; return emu::shfl_idx(v, l + d < 64 ? l + d : l); }
 static inline float __shfl(float v, int src) { return emu::shfl_idx(v, src); }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

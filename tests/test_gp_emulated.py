@@ -53,6 +53,25 @@ def test_posterior_is_factorised_once_per_model_state():
     G.check_posterior_cache("cpu")
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern"])
+@pytest.mark.parametrize("D,gs", [(1, 11), (2, 8)])
+def test_kiss_gp_mll_and_gradients_equal_the_dense_evaluation(kind, D, gs):
+    G.check_ski_mll_and_grads("cpu", kind, N=60, D=D, G=gs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_kiss_gp_gram_kernels(dtype):
+    G.check_ski_gram_is_deterministic_and_ragged("cpu", dtype)
+
+
+def test_kiss_gp_posterior_vs_oracle():
+    G.check_ski_posterior("cpu")
+
+
+def test_kiss_gp_fallbacks():
+    G.check_ski_fallbacks()
+
+
 def test_conv_feature_extractor_vs_stock_torch():
     G.check_conv_feature_extractor("cpu")
 
