@@ -13,7 +13,7 @@
 // over points sorted by grid cell, so two runs are bit-identical like the rest of the build):
 //   amx_ski_weights     Z -> first stencil node, the 4 weights and their derivatives per point and dimension
 //   amx_ski_gram        A and b: per-cell S x S blocks (S = 4^D) over the cell's points, then a gather of the <= 4^D cells
-//                       that contain both nodes of an entry
+//                       that contain both nodes of an entry (the band of A; the caller hands A in zeroed)
 //   amx_ski_gram_bwd    dL/dZ and dL/dr from dL/dA (symmetric) and dL/db: one wave per point, 4^D x 4^D gathers
 //   amx_ski_interp      Y = W V for node vectors V (predictive means)
 //   amx_ski_cov         scale * W1 Q W2^T (full or diagonal: predictive covariances / variances)
@@ -100,20 +100,27 @@ __global__ __launch_bounds__(256) void ski_cell_blocks_kernel(const T* __restric
         for (int c = 0; c < C; ++c) bvec[((size_t)cell * C + c) * S + a] = accb[c];
 }
 
-// (2) dense A: thread per (u, v); nodes further apart than 3 in any dimension share no cell -> 0
+// (2) A [m][m], ZERO on entry: thread per (u, offset) over the band — nodes further apart than 3 in any dimension share
+//     no cell, those entries are never touched (7^D of m entries per row: the dense writer spent 98 % of its threads on zeros)
 template <typename T, int DIM>
 __global__ __launch_bounds__(256) void ski_gram_gather_kernel(const T* __restrict__ blocks, int G, T* __restrict__ A) {
     constexpr int S = DIM == 1 ? 4 : 16;
+    constexpr int NOFF = DIM == 1 ? 7 : 49;
     const int m = DIM == 1 ? G : G * G, NC = G - 3;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (size_t)m * m) return;
-    const int u = (int)(e / m), v = (int)(e - (size_t)u * m);
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * NOFF) return;
+    const int u = e / NOFF, o = e - u * NOFF;
     T acc = T(0);
+    int v;
     if (DIM == 1) {
+        v = u + o - 3;
+        if (v < 0 || v >= G) return;
         const int lo = max(max(u, v) - 3, 0), hi = min(min(u, v), NC - 1);
         for (int c = lo; c <= hi; ++c) acc += blocks[((size_t)c * S + (u - c)) * S + (v - c)];
     } else {
-        const int ux = u / G, uy = u - ux * G, vx = v / G, vy = v - vx * G;
+        const int ux = u / G, uy = u - ux * G, vx = ux + o / 7 - 3, vy = uy + o % 7 - 3;
+        if (vx < 0 || vx >= G || vy < 0 || vy >= G) return;
+        v = vx * G + vy;
         const int xlo = max(max(ux, vx) - 3, 0), xhi = min(min(ux, vx), NC - 1);
         const int ylo = max(max(uy, vy) - 3, 0), yhi = min(min(uy, vy), NC - 1);
         for (int cx = xlo; cx <= xhi; ++cx)
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void ski_gram_gather_kernel(const T* __restric
                 acc += blocks[((size_t)(cx * NC + cy) * S + a) * S + a2];
             }
     }
-    A[e] = acc;
+    A[(size_t)u * m + v] = acc;
 }
 
 // (3) b [C][m]: thread per (c, u)
@@ -276,8 +283,8 @@ static int ski_gram_t(const void* w, const void* r, const int* order, const int*
                N, C, blocks, bvec);
     AMX_CHECK_LAUNCH();
     if (A) {
-        const size_t nblk = ((size_t)m * m + 255) / 256;
-        AMX_LAUNCH((ski_gram_gather_kernel<T, DIM>), dim3((unsigned)nblk), dim3(256), 0, st, (const T*)blocks, G, (T*)A);
+        AMX_LAUNCH((ski_gram_gather_kernel<T, DIM>), dim3(amx_ceil_div(m * (DIM == 1 ? 7 : 49), 256)), dim3(256), 0, st,
+                   (const T*)blocks, G, (T*)A);
         AMX_CHECK_LAUNCH();
     }
     if (C > 0) {

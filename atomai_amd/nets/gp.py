@@ -269,7 +269,7 @@ def ski_gram(base, w, R, grid: SkiGrid, need_A: bool = True):
     order, start = _ski_cells(base, G)
     nws = ((G - 3) ** D) * ((4 ** D) ** 2 + C * 4 ** D)
     ws = torch.empty(nws, dtype=w.dtype, device=w.device)
-    A = torch.empty(m, m, dtype=w.dtype, device=w.device) if need_A else None
+    A = torch.zeros(m, m, dtype=w.dtype, device=w.device) if need_A else None      # (the kernel writes the band only)
     b = torch.empty(C, m, dtype=w.dtype, device=w.device) if C else None
     L.call("amx_ski_gram", L.ptr(w), L.ptr(R.contiguous()) if C else None, L.ptr(order), L.ptr(start), N, D, G, C,
            int(w.dtype == torch.float64), L.ptr(ws), L.ptr(A) if need_A else None, L.ptr(b) if C else None, L.stream_ptr(w))
@@ -296,19 +296,114 @@ def ski_cov(base1, w1, base2, w2, Q, grid: SkiGrid, scale: float = 1.0, diag: bo
     return out
 
 
-def _ski_solve(Kuu, A, b, sig2):
-    """The m x m core shared by training and prediction.  With M = sig2 I + K_UU A (eigenvalues sig2 + eig(A^1/2 K_UU A^1/2)
-    >= sig2: LU without a factorisation of the ill-conditioned K_UU itself):
-        P = M^-1,  x = P K_UU b = K_UU W^T Khat^-1 r,  log det M,     Khat = W K_UU W^T + sig2 I."""
-    m = Kuu.shape[0]
-    M = Kuu @ A
-    M.diagonal().add_(sig2)
-    LU, piv, _ = torch.linalg.lu_factor_ex(M)          # (no host round trip for an error flag: M is never singular)
-    del M
-    logdet = LU.diagonal().abs().log().sum()
-    P = torch.linalg.lu_solve(LU, piv, torch.eye(m, dtype=Kuu.dtype, device=Kuu.device))
-    x = P @ (Kuu @ b)
-    return P, x, logdet
+class _SkiCoreLU:
+    """The m x m core shared by training and prediction, for ANY base kernel.  With M = sig2 I + K_UU A (eigenvalues
+    sig2 + eig(A^1/2 K_UU A^1/2) >= sig2: LU without a factorisation of the ill-conditioned K_UU itself):
+        P = M^-1,  x = P K_UU b = K_UU W^T Khat^-1 r,  log det M,     Khat = W K_UU W^T + sig2 I,
+        Q = P K_UU (= posterior covariance of the node values / sig2),   M^-T A,   tr P.
+    The LU of the 2500 x 2500 matrix of the default grid is 21 of the 22 ms of this core on the MI355X (rocSOLVER getrf
+    through torch: profiles/r06_logs/r06_lu_probe.log) — the reason for _SkiCoreKron below."""
+
+    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid):
+        self.A, self.sig2 = A, sig2
+        m = A.shape[0]
+        with _phase("k_build"):
+            Kuu = kernel_matrix(U, U, lengthscale, s2, kind)
+        with _phase("grid_solve"):
+            M = Kuu @ A
+            M.diagonal().add_(sig2)
+            LU, piv, _ = torch.linalg.lu_factor_ex(M)      # (no host round trip for an error flag: M is never singular)
+            del M
+            self.logdet = LU.diagonal().abs().log().sum()
+            self.P = torch.linalg.lu_solve(LU, piv, torch.eye(m, dtype=Kuu.dtype, device=Kuu.device))
+            self.x = self.P @ (Kuu @ b)
+        self._args = (U, lengthscale, s2, kind)
+
+    def Q(self):
+        U, ls, s2, kind = self._args
+        Qm = self.P @ kernel_matrix(U, U, ls, s2, kind)
+        return 0.5 * (Qm + Qm.T)
+
+    def PtA(self):
+        T = self.P.T @ self.A
+        return 0.5 * (T + T.T)
+
+    def trP(self):
+        return torch.diagonal(self.P).sum()
+
+
+class _SkiCoreKron:
+    """The same quantities for the RBF kernel — the only base kernel the reference's dklGPR builds (gp.py:41-44) — without an
+    m x m factorisation.  On the product grid the ARD-RBF covariance is a Kronecker product, K_UU = s2 K_0 (x) K_1 with K_d the
+    G x G one-dimensional kernels, so its eigen-decomposition costs two G x G symmetric eigenproblems (fp64, on the host:
+    0.2 ms each at G = 50): K_UU = V L V^T, V = V_0 (x) V_1, L = s2 l_0 (x) l_1.  A smooth kernel on a fine grid has a tiny
+    numerical rank: only the r eigenpairs with L > 1e-16 L_max are kept (r ~ 300 of 2500 at the initial lengthscale; the
+    discarded part of K_UU is below the rounding of the kept part).  With F = V_r L_r^1/2 (m x r), K_UU = F F^T and
+        T = sig2 I_r + F^T A F  (SPD, r x r),    log det(sig2 I_m + K_UU A) = (m - r) log sig2 + log det T,
+        x = F T^-1 F^T b,   Q = F T^-1 F^T,   M^-T A = (A - (A F) T^-1 (A F)^T) / sig2,   tr M^-1 = (m - r) / sig2 + tr T^-1
+    (push-through identities of the LU form).  One r x r Cholesky + a handful of m x m x r GEMMs."""
+
+    EPS = 1e-16
+
+    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid):
+        assert kind == 0
+        self.A, self.sig2 = A, sig2
+        dt, dev = A.dtype, A.device
+        m, G, D = A.shape[0], grid.G, grid.D
+        with _phase("k_build"):
+            # host side (numpy, fp64): two G x G eigenproblems and the choice of the kept pairs; the m x r factor itself is
+            # formed on the device from the two G x r column selections
+            import numpy as np
+            ls = lengthscale.detach().reshape(-1).double().tolist()
+            nd = grid.nodes_1d()
+            Vs, lams = [], []
+            for d in range(D):
+                x = (nd[d][1] / ls[d]) * np.arange(G, dtype=np.float64)
+                lam, V = np.linalg.eigh(np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2))
+                Vs.append(V)
+                lams.append(np.maximum(lam, 0.0))
+            if D == 1:
+                lam = lams[0] * s2
+                keep = np.nonzero(lam > self.EPS * lam.max())[0]
+                F = torch.from_numpy(Vs[0][:, keep] * np.sqrt(lam[keep])).to(dt).to(dev)
+            else:
+                lam = (s2 * lams[0][:, None] * lams[1][None, :]).reshape(-1)
+                keep = np.nonzero(lam > self.EPS * lam.max())[0]
+                a0, a1 = keep // G, keep % G
+                V0 = torch.from_numpy(np.ascontiguousarray(Vs[0][:, a0] * np.sqrt(lam[keep]))).to(dev)     # G x r, fp64
+                V1 = torch.from_numpy(np.ascontiguousarray(Vs[1][:, a1])).to(dev)
+                F = (V0[:, None, :] * V1[None, :, :]).reshape(m, -1).to(dt)
+            F = F.contiguous()
+        self.r = r = F.shape[1]
+        with _phase("grid_solve"):
+            self.AF = A @ F
+            T = F.T @ self.AF
+            T = 0.5 * (T + T.T)
+            T.diagonal().add_(sig2)
+            Lc, _ = torch.linalg.cholesky_ex(T)
+            del T
+            self.logdet = (m - r) * math.log(sig2) + 2.0 * torch.log(torch.diagonal(Lc)).sum()
+            self.Tinv = torch.cholesky_inverse(Lc)
+            self.F = F
+            self.x = F @ (self.Tinv @ (F.T @ b))
+
+    def Q(self):
+        Qm = (self.F @ self.Tinv) @ self.F.T
+        return 0.5 * (Qm + Qm.T)
+
+    def PtA(self):
+        T = (self.A - (self.AF @ self.Tinv) @ self.AF.T) / self.sig2
+        return 0.5 * (T + T.T)
+
+    def trP(self):
+        return (self.A.shape[0] - self.r) / self.sig2 + torch.diagonal(self.Tinv).sum()
+
+
+def _ski_core(U, lengthscale, s2, kind, A, b, sig2, grid):
+    return (_SkiCoreKron if kind == 0 and SKI_KRON[0] else _SkiCoreLU)(U, lengthscale, s2, kind, A, b, sig2, grid)
+
+
+SKI_KRON = [True]            # (tests compare the two cores)
 
 
 class _SkiMLLFn(torch.autograd.Function):
@@ -334,15 +429,13 @@ class _SkiMLLFn(torch.autograd.Function):
         per = []
         for i in range(q):
             sig2, s2 = float(noise[i]), float(outputscale[i])
-            with _phase("k_build"):
-                Kuu = kernel_matrix(U, U, lengthscale[i], s2, kind)
+            core = _ski_core(U, lengthscale[i], s2, kind, A, b[i], sig2, grid)
             with _phase("grid_solve"):
-                P, x, logdet = _ski_solve(Kuu, A, b[i], sig2)
+                x = core.x
                 quad = ((R[i] * R[i]).sum() - (b[i] * x).sum()) / sig2
                 u = (b[i] - A @ x) / sig2
-                tot = tot + (-0.5 * quad - 0.5 * ((N - m) * math.log(sig2) + logdet) - 0.5 * N * math.log(2 * math.pi)) / N
-            per.append((P, x, u, quad, sig2, s2))
-            del Kuu
+                tot = tot + (-0.5 * quad - 0.5 * ((N - m) * math.log(sig2) + core.logdet) - 0.5 * N * math.log(2 * math.pi)) / N
+            per.append((core, x, u, quad, sig2, s2))
         ctx.save_for_backward(lengthscale.detach())
         ctx.state = (base, w, dw, R, A, per, kind, grid, N, D)
         return tot
@@ -357,18 +450,13 @@ class _SkiMLLFn(torch.autograd.Function):
         GA = torch.zeros(m, m, dtype=dt, device=dev)
         gb = torch.empty(q, m, dtype=dt, device=dev)
         d_ls, d_s2, d_noise, g_rr = [], [], [], []
-        for i, (P, x, u, quad, sig2, s2) in enumerate(per):
-            with _phase("k_build"):
-                Kuu = kernel_matrix(U, U, ls[i], s2, kind)
+        for i, (core, x, u, quad, sig2, s2) in enumerate(per):
             with _phase("grid_bwd"):
-                Qm = P @ Kuu
-                GA.add_(torch.outer(x, x) / sig2 + 0.5 * (Qm + Qm.T), alpha=-0.5 / N)
+                GA.add_(torch.outer(x, x) / sig2 + core.Q(), alpha=-0.5 / N)
                 gb[i] = x / (sig2 * N)
-                PtA = P.T @ A
-                GK = (torch.outer(u, u) - 0.5 * (PtA + PtA.T)) * (0.5 / N)
-                d_noise.append((0.5 * (quad - (u * x).sum()) / sig2 - 0.5 * (torch.diagonal(P).sum() + (N - m) / sig2)) / N)
+                GK = (torch.outer(u, u) - core.PtA()) * (0.5 / N)
+                d_noise.append((0.5 * (quad - (u * x).sum()) / sig2 - 0.5 * (core.trP() + (N - m) / sig2)) / N)
                 g_rr.append(-0.5 / (sig2 * N))
-                del Qm, PtA
             with _phase("k_bwd"):
                 dU = torch.empty_like(U)
                 part = torch.empty((m + 3) // 4, D + 1, dtype=dt, device=dev)
@@ -378,7 +466,7 @@ class _SkiMLLFn(torch.autograd.Function):
                 tot = part.sum(0)
                 d_ls.append((-tot[:D] * inv_ls * inv_ls).reshape(ls[i].shape))
                 d_s2.append(tot[D])
-                del GK, Kuu
+                del GK
         with _phase("ski_gram_bwd"):
             dZ = torch.empty(N, D, dtype=dt, device=dev)
             dr = torch.empty(q, N, dtype=dt, device=dev)
@@ -483,7 +571,7 @@ class GPRegressionModel(nn.Module):
         factors = []
         if self.gp == "kissgp":
             # per output: x = K_UU W^T Khat^-1 r (the node values of the predictive mean) and noise * Q = the posterior
-            # covariance of the node values, both m-sized; the same core as the training step (_ski_solve)
+            # covariance of the node values, both m-sized; the same core as the training step (_ski_core)
             grid = self.grid
             grid.update(Z)                   # (gpytorch applies its grid rule on every kernel call, train or eval mode)
             base, w, _ = ski_weights(Z, grid)
@@ -493,10 +581,8 @@ class GPRegressionModel(nn.Module):
             _, _, U = grid.tensors(Z.dtype, Z.device)
             for i in range(q):
                 nz = float(self.noise[i, 0])
-                Kuu = kernel_matrix(U, U, self.lengthscale[i], float(self.outputscale[i]), self.kind)
-                P, x, _ = _ski_solve(Kuu, A, b[i], nz)
-                Qm = P @ Kuu
-                factors.append((x, (0.5 * nz) * (Qm + Qm.T)))
+                core = _ski_core(U, self.lengthscale[i], float(self.outputscale[i]), self.kind, A, b[i], nz, grid)
+                factors.append((core.x, nz * core.Q()))
             self._cache = (self._state_key() + (grid.version,), Z, factors)
             self.n_factorisations = getattr(self, "n_factorisations", 0) + 1
             return Z, factors

@@ -439,7 +439,8 @@ int amx_ski_weights(const void* Z, const void* g0, const void* inv_delta, int N,
                     void* w, void* dw, void* stream);
 /* elements (of the value type) of amx_ski_gram's workspace `ws`, or -1 */
 long amx_ski_gram_workspace(int D, int G, int C);
-/* A [m][m] = W^T W (or NULL) and b [C][m] = W^T r for r [C][N], m = G^D */
+/* A [m][m] = W^T W (or NULL; ZERO on entry: only the band |u_d - v_d| <= 3 is written) and b [C][m] = W^T r for r [C][N],
+ * m = G^D */
 int amx_ski_gram(const void* w, const void* r, const int* order, const int* cell_start, int N, int D, int G, int C,
                  int is_double, void* ws, void* A, void* b, void* stream);
 /* backward of amx_ski_gram: GA = dL/dA [m][m] (symmetric), gb = dL/db [C][m]  ->  dZ [N][D], dr [C][N] */

@@ -456,3 +456,41 @@ def check_ski_fallbacks():
     assert m.gp_model.gp == "kissgp" and m.gp_model.grid.m == 50
     mean, var = m.predict(X[:7])
     assert mean.shape == (7,) and (var >= 0).all()
+
+
+def check_ski_kron_core_equals_lu_core(device, N=300, G=20):
+    """The RBF core (Kronecker eigen-decomposition of K_UU, r x r Cholesky) against the general LU core on the same inputs:
+    marginal log likelihood, every gradient and the posterior factors; the kept rank is far below the grid size."""
+    import atomai_amd.nets.gp as gp
+    rs = np.random.RandomState(4)
+    Zn = rs.uniform(-0.9, 0.9, (N, 2))
+    Y = torch.from_numpy(np.sin(3 * Zn[:, :1].T) + 0.1 * rs.randn(1, N)).to(device)
+    grid = gp.SkiGrid(2, G)
+    res = []
+    for kron in (False, True):
+        gp.SKI_KRON[0] = kron
+        try:
+            Z = torch.from_numpy(Zn).to(device).requires_grad_(True)
+            ls = torch.tensor([[[0.7, 0.5]]], dtype=torch.float64, device=device, requires_grad=True)
+            s2 = torch.tensor([1.2], dtype=torch.float64, device=device, requires_grad=True)
+            nz = torch.tensor([0.07], dtype=torch.float64, device=device, requires_grad=True)
+            mu = torch.tensor([0.1], dtype=torch.float64, device=device, requires_grad=True)
+            grid.update(Z)
+            mll = gp._SkiMLLFn.apply(Z, Y, ls, s2, nz, mu, 0, grid)
+            mll.backward()
+            res.append([mll.detach()] + [t.grad.clone() for t in (Z, ls, s2, nz, mu)])
+        finally:
+            gp.SKI_KRON[0] = True
+    for a, b in zip(*res):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7 * float(b.abs().max()))
+    base, w, _ = gp.ski_weights(Z.detach(), grid)
+    A, b = gp.ski_gram(base, w, Y - 0.1, grid)
+    _, _, U = grid.tensors(torch.float64, Z.device)
+    ck = gp._SkiCoreKron(U, ls.detach()[0], 1.2, 0, A, b[0], 0.07, grid)
+    cl = gp._SkiCoreLU(U, ls.detach()[0], 1.2, 0, A, b[0], 0.07, grid)
+    assert ck.r <= grid.m
+    for f in ("Q", "PtA", "trP"):
+        x, y = getattr(ck, f)(), getattr(cl, f)()
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(y.abs().max()), err_msg=f)
+    np.testing.assert_allclose(ck.x.cpu().numpy(), cl.x.cpu().numpy(), rtol=1e-6, atol=1e-8 * float(cl.x.abs().max()))
+    return ck.r

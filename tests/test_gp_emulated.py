@@ -72,6 +72,10 @@ def test_kiss_gp_fallbacks():
     G.check_ski_fallbacks()
 
 
+def test_kiss_gp_kronecker_core_equals_lu_core():
+    G.check_ski_kron_core_equals_lu_core("cpu", N=120, G=12)
+
+
 def test_conv_feature_extractor_vs_stock_torch():
     G.check_conv_feature_extractor("cpu")
 

@@ -98,6 +98,11 @@ def test_kiss_gp_fallbacks():
     G.check_ski_fallbacks()
 
 
+def test_kiss_gp_kronecker_core_equals_lu_core():
+    r = G.check_ski_kron_core_equals_lu_core("cuda", N=2000, G=50)
+    assert r < 1000
+
+
 def test_kiss_gp_matches_exact_gp_at_config5_scale():
     """N = 16384 points, grid 50 x 50, fp64: the KISS-GP marginal log likelihood (m x m algebra) against the exact dense GP's
     at the same hyper-parameters — the two models differ by the interpolation error only (oracle: < 1e-4 of the output scale
