@@ -314,6 +314,181 @@ extern "C" int amx_px_bwd(const float* dl, const float* a, const float* scale, c
     return 0;
 }
 
+// ------------------------------------------------------------------ px forward + cross entropy + px backward in ONE pass
+// The training step of a Segmentor ends  logits = px(xn);  loss = CrossEntropyLoss()(logits, target);  loss.backward()
+// (atomai/trainers/trainer.py:201-207).  As three kernels that is px_fwd (reads the last activation, writes the logits),
+// ce_fwd_bwd (reads the logits, writes their gradient) and px_bwd (reads the activation AGAIN and the logits gradient, writes
+// the activation's gradient): 1.9 GB of traffic at bs 32 / 512^2 / 16 channels, all on the dependency chain between forward
+// and backward where nothing else can run.  Here one pass over the activation forms a pixel's logits in registers (the G
+// lanes that share a pixel in px_bwd's layout add their partial dot products by xor-shuffles), its softmax / loss term, the
+// logits gradient (softmax - onehot) / npix, and from it everything px_bwd produces: dxn, the px weight / bias gradient rows
+// and the BatchNorm-backward sums of the producing layer.  Neither the logits nor their gradient exist in memory.
+// Called by the trainers' fused step only (nets/fcnn.py: forward_loss); K <= 4 classes (K = 1: BCE), Cs / 4 a power of two <= 64.
+// lpart [rows]: per-workgroup loss sums (amx_reduce_rows with 1 / npix gives the mean, as for amx_ce_fwd_bwd).
+// BCE (KT == 1): the one-class head with BCEWithLogitsLoss against a float mask `tgtf` (select_loss('ce', 1), the
+// reference's default nb_classes): loss and gradient as bce_fwd_bwd_kernel forms them.
+template <int KT, bool BCE = false>
+__global__ __launch_bounds__(256) void px_ce_train_kernel(const float* __restrict__ a, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ w,
+                                                          const float* __restrict__ b, const long long* __restrict__ tgt,
+                                                          const float* __restrict__ tgtf,
+                                                          float* __restrict__ dxn, float* __restrict__ part,
+                                                          float* __restrict__ partb, float* __restrict__ bstats,
+                                                          float* __restrict__ lpart, long npix, int C, int Cs, int ppb,
+                                                          float inv_count) {
+    constexpr int K = KT;
+    const int G = Cs >> 2, PL = 256 / G;                 // (256 % G == 0: every thread is active)
+    const int tid = threadIdx.x;
+    const int pl = tid / G, cg = tid - pl * G;
+    AMX_DYN_SMEM(float, s);                       // [PL][K][Cs] + [PL][K] (+ pad) + [2][PL][Cs] + [256]
+    float4 bs1 = make_float4(0, 0, 0, 0), bs2 = make_float4(0, 0, 0, 0);   // sum dxn, sum dxn * a (raw)
+    float4 dw[KT];
+    float db[KT], bk[KT];
+    float4 wk[KT];
+    #pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        dw[k] = make_float4(0, 0, 0, 0); db[k] = 0.f; bk[k] = b[k];
+        const int c = cg * 4;
+        const float* wr = w + (size_t)k * C;
+        wk[k].x = c + 0 < C ? wr[c + 0] : 0.f; wk[k].y = c + 1 < C ? wr[c + 1] : 0.f;
+        wk[k].z = c + 2 < C ? wr[c + 2] : 0.f; wk[k].w = c + 3 < C ? wr[c + 3] : 0.f;
+    }
+    float lsum = 0.f;
+    const long p0 = (long)blockIdx.x * ppb;
+    const long p1 = p0 + ppb < npix ? p0 + ppb : npix;
+    float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+    if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
+    constexpr int U = AMX_PX_BWD_UNROLL;
+    for (long pb = p0; pb < p1; pb += (long)PL * U) {       // (workgroup-uniform trip count: the shuffles need whole waves)
+        const long p = pb + pl;
+        float4 av[U];
+        int tv[U];
+        float tf[U];
+        bool ok[U];
+        #pragma unroll
+        for (int u = 0; u < U; ++u) {             // every load of the U pixels before the first use (see px_bwd_kernel)
+            ok[u] = p + (long)u * PL < p1;
+            const long pu = ok[u] ? p + (long)u * PL : p0;
+            av[u] = amx_ld4(a + (size_t)pu * Cs + cg * 4);
+            if (BCE) { tf[u] = tgtf[pu]; tv[u] = 0; } else { tv[u] = (int)tgt[pu]; tf[u] = 0.f; }
+        }
+        #pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // (no `continue` for a missing pixel: the shuffles below need every lane of the wave)
+            float4 v = av[u];
+            const float4 raw = v;
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+            v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            float lg[KT];
+            #pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                float t = v.x * wk[k].x;
+                t = fmaf(v.y, wk[k].y, t); t = fmaf(v.z, wk[k].z, t); t = fmaf(v.w, wk[k].w, t);
+                for (int o = 1; o < G; o <<= 1) t += __shfl_xor(t, o);
+                lg[k] = t + bk[k];
+            }
+            float gk[KT], lterm;
+            if (BCE) {
+                const float xv = lg[0], e = expf(-fabsf(xv));
+                lterm = fmaxf(xv, 0.f) - xv * tf[u] + log1pf(e);
+                gk[0] = ((xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e)) - tf[u]) * inv_count;
+            } else {
+                float mx = lg[0];
+                #pragma unroll
+                for (int k = 1; k < KT; ++k) mx = fmaxf(mx, lg[k]);
+                float se = 0.f, xt = 0.f;
+                #pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    if (k == tv[u]) xt = lg[k] - mx;
+                    lg[k] = expf(lg[k] - mx); se += lg[k];
+                }
+                const float inv_s = 1.f / se;
+                lterm = logf(se) - xt;
+                #pragma unroll
+                for (int k = 0; k < KT; ++k) gk[k] = (lg[k] * inv_s - (k == tv[u] ? 1.f : 0.f)) * inv_count;
+            }
+            if (!ok[u]) continue;
+            if (cg == 0) lsum += lterm;
+            float4 d = make_float4(0, 0, 0, 0);
+            #pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float g = gk[k];
+                d.x = fmaf(g, wk[k].x, d.x); d.y = fmaf(g, wk[k].y, d.y);
+                d.z = fmaf(g, wk[k].z, d.z); d.w = fmaf(g, wk[k].w, d.w);
+                dw[k].x = fmaf(g, v.x, dw[k].x); dw[k].y = fmaf(g, v.y, dw[k].y);
+                dw[k].z = fmaf(g, v.z, dw[k].z); dw[k].w = fmaf(g, v.w, dw[k].w);
+                db[k] += g;
+            }
+            amx_st4(dxn + (size_t)(p + (long)u * PL) * Cs + cg * 4, d);
+            bs1.x += d.x; bs1.y += d.y; bs1.z += d.z; bs1.w += d.w;
+            bs2.x = fmaf(d.x, raw.x, bs2.x); bs2.y = fmaf(d.y, raw.y, bs2.y);
+            bs2.z = fmaf(d.z, raw.z, bs2.z); bs2.w = fmaf(d.w, raw.w, bs2.w);
+        }
+    }
+    #pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        amx_st4(s + ((size_t)(pl * K + k) * Cs + cg * 4), dw[k]);
+        if (cg == 0) s[(size_t)PL * K * Cs + pl * K + k] = db[k];
+    }
+    float* sb = s + (size_t)PL * K * Cs + (size_t)PL * K;
+    sb = sb + ((4 - ((size_t)(sb - s) & 3)) & 3);            // keep float4 alignment
+    amx_st4(sb + ((size_t)pl * Cs + cg * 4), bs1);
+    amx_st4(sb + ((size_t)(PL + pl) * Cs + cg * 4), bs2);
+    float* red = sb + (size_t)2 * PL * Cs;
+    red[tid] = lsum;
+    __syncthreads();
+    for (int i = tid; i < K * Cs; i += 256) {
+        float acc = 0.f;
+        for (int q = 0; q < PL; ++q) acc += s[(size_t)q * K * Cs + i];
+        part[(size_t)blockIdx.x * K * Cs + i] = acc;
+    }
+    if (tid < K) {
+        float acc = 0.f;
+        for (int q = 0; q < PL; ++q) acc += s[(size_t)PL * K * Cs + q * K + tid];
+        partb[(size_t)blockIdx.x * K + tid] = acc;
+    }
+    if (bstats) {
+        for (int i = tid; i < 2 * Cs; i += 256) {
+            const int which = i / Cs, c = i - which * Cs;
+            float acc = 0.f;
+            for (int q = 0; q < PL; ++q) acc += sb[(size_t)(which * PL + q) * Cs + c];
+            bstats[((size_t)blockIdx.x * 2 + which) * Cs + c] = acc;
+        }
+    }
+    for (int o = 128; o > 0; o >>= 1) { __syncthreads(); if (tid < o) red[tid] += red[tid + o]; }
+    if (tid == 0) lpart[blockIdx.x] = red[0];
+}
+
+extern "C" int amx_px_ce_train_supported(int Cs, int K) {
+    const int G = Cs >> 2;
+    return (Cs > 0 && !(Cs & 3) && Cs <= 256 && (G & (G - 1)) == 0 && K >= 1 && K <= 4) ? 1 : 0;
+}
+
+extern "C" int amx_px_ce_train(const float* a, const float* scale, const float* shift, const float* w, const float* b,
+                               const long long* target, const float* target_f, float* dxn, float* part, float* partb,
+                               float* bstats, float* lpart, int N, int H, int W, int C, int Cs, int K, int rows,
+                               int rows_pix, void* stream) {
+    if (!a || !w || !b || !dxn || !part || !partb || !lpart || C <= 0 || Cs < C) AMX_BADARG(1);
+    if (!amx_px_ce_train_supported(Cs, K) || (K == 1 ? !target_f : !target)) AMX_BADARG(2);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
+    const long npix = (long)N * H * W;
+    if (rows <= 0 || rows_pix <= 0 || (long)rows * rows_pix < npix) AMX_BADARG(4);
+    const int PL = 256 / (Cs / 4);
+    const size_t lds = ((size_t)PL * K * Cs + (size_t)PL * K + 4 + (size_t)2 * PL * Cs + 256) * sizeof(float);
+#define PX_CE_LAUNCH(KT_)                                                                                             \
+    AMX_LAUNCH((px_ce_train_kernel<KT_, KT_ == 1>), dim3(rows), dim3(256), lds, (hipStream_t)stream, a, scale, shift, w, b, \
+               target, target_f, dxn, part, partb, bstats, lpart, npix, C, Cs, rows_pix, 1.0f / (float)npix)
+    switch (K) {
+        case 1: PX_CE_LAUNCH(1); break;
+        case 2: PX_CE_LAUNCH(2); break;
+        case 3: PX_CE_LAUNCH(3); break;
+        default: PX_CE_LAUNCH(4); break;
+    }
+#undef PX_CE_LAUNCH
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------ cross entropy (fwd + bwd fused)
 // logits NCHW [N][K][HW], target int64 [N][HW].  loss = mean over valid pixels of (lse - x_t);
 // dlogits = (softmax - onehot) / n_valid is written in the same pass (NCHW) so that backward is free.
@@ -457,6 +632,36 @@ extern "C" int amx_scale_unless_one(float* x, const float* g, long n, void* stre
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
     AMX_LAUNCH(scale_unless_one_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, g, n);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// amx_scale_unless_one for up to four tensors in one launch (the fused training head hands dxn, its two gradient-row
+// tensors and the BatchNorm-backward sums to backward at once)
+struct ScaleSegs { float* x[4]; long n[4]; long start[5]; int nseg; };
+__global__ __launch_bounds__(256) void scale_unless_one_multi_kernel(ScaleSegs sg, const float* __restrict__ g) {
+    const float f = *g;
+    if (f == 1.0f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < sg.start[sg.nseg]; i += (long)gridDim.x * 256) {
+        int k = 0;
+        while (i >= sg.start[k + 1]) ++k;
+        sg.x[k][i - sg.start[k]] *= f;
+    }
+}
+
+extern "C" int amx_scale_unless_one_multi(float* x0, long n0, float* x1, long n1, float* x2, long n2, float* x3, long n3,
+                                          const float* g, void* stream) {
+    if (!g || !x0 || n0 <= 0) AMX_BADARG(1);
+    ScaleSegs sg = {};
+    float* xs[4] = {x0, x1, x2, x3};
+    const long ns[4] = {n0, n1, n2, n3};
+    for (int k = 0; k < 4; ++k) {
+        if (!xs[k] || ns[k] <= 0) continue;
+        sg.x[sg.nseg] = xs[k]; sg.n[sg.nseg] = ns[k]; sg.start[sg.nseg + 1] = sg.start[sg.nseg] + ns[k]; ++sg.nseg;
+    }
+    long nb = (sg.start[sg.nseg] + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    AMX_LAUNCH(scale_unless_one_multi_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, sg, g);
     AMX_CHECK_LAUNCH();
     return 0;
 }

@@ -1104,6 +1104,76 @@ class PxNode(_Node):
             tape.accumulate(s, dxn)
 
 
+class PxLossNode(_Node):
+    """The training step's head in ONE pass (amx_px_ce_train): px -> CrossEntropyLoss (BCEWithLogitsLoss for one class) ->
+    their backward, for the trainers'
+    fused step (nets/fcnn.py: forward_loss).  value = the scalar mean loss; what px_bwd would have produced for an upstream
+    gradient of 1 is kept for backward, which only scales it if the upstream gradient is not 1."""
+
+    def __init__(self, tape, src: Act, conv, target: torch.Tensor):
+        self.src, self.conv = src, conv
+        src.consumed_by(self)
+        K = conv.weight.shape[0]
+        assert conv.weight.shape[1] == src.C and conv.weight.shape[2:] == (1, 1)
+        assert target.numel() == src.npix and target.dtype == (torch.float32 if K == 1 else torch.int64)
+        self.K = K
+        s = src
+        rows = L.load().amx_rows_for(s.npix)
+        rows_pix = L.load().amx_rows_pix(s.npix)
+        need = tape.need_grad
+        self.dxn = _empty(s.t.shape, s.t)
+        self.part = _empty((rows, K, s.Cs), s.t)
+        self.partb = _empty((rows, K), s.t)
+        self.bstats = None
+        if need and s.wants_bstats(self, tape.training):
+            self.bstats = _empty((rows, 2, s.Cs), s.t)
+        lpart = _empty((rows,), s.t)
+        sp = _sp(s.t)
+        L.call("amx_px_ce_train", L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift), L.ptr(conv.weight.detach()),
+               L.ptr(conv.bias.detach()), L.ptr(target.contiguous() if K > 1 else None),
+               L.ptr(target.contiguous() if K == 1 else None), L.ptr(self.dxn), L.ptr(self.part), L.ptr(self.partb),
+               L.ptr(self.bstats), L.ptr(lpart), s.N, s.H, s.W, s.C, s.Cs, K, rows, rows_pix, sp)
+        self.value = torch.empty((), dtype=torch.float32, device=s.t.device)
+        L.call("amx_reduce_rows", L.ptr(lpart), rows, 1, 1, 1.0 / s.npix, L.ptr(self.value), sp)
+        self.rows = rows
+        self.grad_out: Optional[torch.Tensor] = None
+
+    def backward(self, tape) -> None:
+        s, g = self.src, self.grad_out
+        if g is None:
+            return
+        dxn, part, partb, bstats = self.dxn, self.part, self.partb, self.bstats
+        self.dxn = self.part = self.partb = self.bstats = None
+        sp = _sp(dxn)
+        if g.numel() == 1 and g.dtype == torch.float32 and g.device == dxn.device:
+            L.call("amx_scale_unless_one_multi", L.ptr(dxn), dxn.numel(), L.ptr(part), part.numel(), L.ptr(partb),
+                   partb.numel(), L.ptr(bstats), bstats.numel() if bstats is not None else 0, L.ptr(g.contiguous()), sp)
+        else:
+            gs = g.to(dxn.dtype).reshape(())
+            dxn, part, partb = dxn * gs, part * gs, partb * gs
+            bstats = bstats * gs if bstats is not None else None
+        if bstats is not None and s.grad is None:
+            s.bstats = (bstats, self.rows, s.Cs, 0)
+        dw = _empty((self.K * s.Cs,), s.t)
+        L.call("amx_reduce_rows", L.ptr(part), self.rows, self.K * s.Cs, self.K * s.Cs, 1.0, L.ptr(dw), sp)
+        db = grad_buffer(self.conv.bias, s.t)
+        L.call("amx_reduce_rows", L.ptr(partb), self.rows, self.K, self.K, 1.0, L.ptr(db), sp)
+        tape.add_param_grad(self.conv.weight, dw.view(self.K, s.Cs)[:, : s.C].reshape(self.K, s.C, 1, 1))
+        tape.add_param_grad(self.conv.bias, db)
+        if s.needs_grad:
+            tape.accumulate(s, dxn)
+
+
+def px_loss_fusable(src: Act, conv, target) -> bool:
+    K = conv.weight.shape[0]
+    return (FUSE_PX_LOSS and isinstance(target, torch.Tensor) and target.numel() == src.npix
+            and target.dtype == (torch.float32 if K == 1 else torch.int64)
+            and bool(L.load().amx_px_ce_train_supported(src.Cs, K)))
+
+
+FUSE_PX_LOSS = _os.environ.get("AMX_FUSE_PX_LOSS", "1") != "0"
+
+
 # ====================================================================================== tape
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 
@@ -1220,7 +1290,11 @@ class Tape:
     def output(self, src: Act) -> OutputNode:
         return self._push(OutputNode(self, src))
 
-    def px(self, src: Act, conv, mode: int = 0) -> PxNode:
+    def px(self, src: Act, conv, mode: int = 0, loss_target=None):
+        """The net's final 1x1 convolution; with `loss_target` (the trainers' fused step, training mode) the mean
+        cross-entropy loss against it instead of the logits — one pass, see PxLossNode."""
+        if loss_target is not None:
+            return self._push(PxLossNode(self, src, conv, loss_target))
         return self._push(PxNode(self, src, conv, mode))
 
     def conv_dsum(self, src: Act, conv, bn, slope: float, acts) -> Act:

@@ -33,6 +33,32 @@ class _HipNet(nn.Module):
             return self._modular(x)
         return run_tape(self._build, x, list(self.parameters()), self.training)
 
+    # ---- the trainers' fused step: prob = net(x); loss = CrossEntropyLoss()(prob, y) as ONE tape whose last node is the
+    # head + loss + their backward in a single pass over the last activation (engine.PxLossNode)
+    _loss_target = None
+    _loss_fused = False
+
+    def _px(self, tape, act, conv, px_mode: int):
+        from ..engine import px_loss_fusable
+        tgt = self._loss_target
+        if tgt is not None and tape.training and px_mode == 0 and px_loss_fusable(act, conv, tgt):
+            self._loss_fused = True
+            return tape.px(act, conv, 0, loss_target=tgt)
+        return tape.px(act, conv, px_mode)
+
+    def forward_loss(self, x: torch.Tensor, target: torch.Tensor):
+        """('loss', mean cross-entropy of net(x) against the int64 class map `target` [N][H][W] — for a one-class net the mean
+        BCE-with-logits against the float mask [N][1][H][W]) when the head and the loss run as the fused node, else
+        ('logits', net(x)) — the caller then applies its criterion as usual.  Training mode only."""
+        if not self.training or any(len(m._forward_hooks) or len(m._forward_pre_hooks) for m in self.children()):
+            return "logits", self.forward(x)
+        self._loss_target, self._loss_fused = target, False
+        try:
+            out = run_tape(self._build, x, list(self.parameters()), True)
+        finally:
+            self._loss_target = None
+        return ("loss" if self._loss_fused else "logits"), out
+
 
 def _hip_pool(x: torch.Tensor, training: bool) -> torch.Tensor:
     """2x2 max-pooling of an NCHW tensor on the HIP pooling kernels (the glue of the block-by-block path)."""
@@ -103,7 +129,7 @@ class Unet(_HipNet):
         u2 = self.c5._emit(tape, [c2, u2])
         u1 = self.upsample_block3._emit(tape, [u2])
         u1 = self.c6._emit(tape, [c1, u1], head=(self.px, px_mode))
-        return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
+        return node, (u1 if hasattr(u1, "value") else self._px(tape, u1, self.px, px_mode))
 
     def _modular(self, x):
         c1 = self.c1(x)
@@ -151,7 +177,7 @@ class dilnet(_HipNet):
         at2 = self.at2._emit(tape, [at1])
         u1 = self.up1._emit(tape, [at2])
         u1 = self.c2._emit(tape, [c1, u1], head=(self.px, px_mode))
-        return node, (u1 if hasattr(u1, "value") else tape.px(u1, self.px, px_mode))
+        return node, (u1 if hasattr(u1, "value") else self._px(tape, u1, self.px, px_mode))
 
     def _modular(self, x):
         c1 = self.c1(x)
@@ -189,7 +215,7 @@ class ResHedNet(_HipNet):
         scores = [tape.conv([n], seq[0], seq[1], 1.0)                       # conv 1x1 -> BatchNorm, no activation
                   for n, seq in ((n1, self.net1score), (n2, self.net2score), (n3, self.net3score))]
         cat = tape.resize_cat(scores, h, w, self.upsample)
-        return node, tape.px(cat, self.out, px_mode)
+        return node, self._px(tape, cat, self.out, px_mode)
 
     def _modular(self, x):
         # (hook path only: the side-output heads — pooling inside net2 / net3, three 1x1 convolutions on nb_classes channels,
@@ -236,7 +262,7 @@ class SegResNet(_HipNet):
         u2 = self.c3._emit(tape, [c2, u2])
         u1 = self.upsample_block2._emit(tape, [u2])
         u1 = self.c4._emit(tape, [c1, u1])
-        return node, tape.px(u1, self.px, px_mode)
+        return node, self._px(tape, u1, self.px, px_mode)
 
     def _modular(self, x):
         c1 = self.c1(x)

@@ -30,6 +30,7 @@ def _shuffle(arr: np.ndarray, random_state: int) -> np.ndarray:
     return shuffle(arr, random_state=random_state)
 
 
+FUSE_LOSS = os.environ.get("AMX_FUSE_PX_LOSS", "1") != "0"       # host-side switch: the fused head + loss of train_step
 EARLY_LOSS = os.environ.get("AMX_EARLY_LOSS", "1") != "0"       # host-side switch, read once at import (see _EarlyScalar)
 
 
@@ -147,8 +148,17 @@ class BaseTrainer:
         self.net.train()
         self.optimizer.zero_grad()
         feat, tar = feat.to(self.device), tar.to(self.device)
-        prob = self.net(feat)
-        loss = self.criterion(prob, tar)
+        prob = None
+        ce = type(self.criterion) is losses_metrics.losses.CrossEntropyLoss and tar.dtype == torch.int64 and tar.ndim == 3
+        bce = (type(self.criterion) is losses_metrics.losses.BCEWithLogitsLoss and tar.dtype == torch.float32
+               and tar.ndim == 4 and tar.shape[1] == 1 and tar.shape[0] == feat.shape[0] and tar.shape[2:] == feat.shape[2:])
+        if FUSE_LOSS and not self.compute_accuracy and (ce or bce) and hasattr(self.net, "forward_loss"):
+            # head + loss + their backward in one pass over the last activation (nets/fcnn.py: forward_loss); the same values
+            kind, out = self.net.forward_loss(feat, tar)
+            loss = out if kind == "loss" else self.criterion(out, tar)
+        else:
+            prob = self.net(feat)
+            loss = self.criterion(prob, tar)
         early = _EarlyScalar(loss)                 # the loss value starts its way to the host NOW (see the class)
         loss.backward()
         if self.dp is not None:

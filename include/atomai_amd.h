@@ -278,6 +278,20 @@ int amx_bce_fwd_bwd(const float* logits, const float* target, float* dlogits, fl
  * trainers/trainer.py:203-206).  x *= *g in place — and no pass at all when *g == 1 (the multiplication by one was a
  * 200 MB read + write of the logits gradient in every training step). */
 int amx_scale_unless_one(float* x, const float* g, long n, void* stream);
+/* the same for up to four tensors in one launch (unused slots: NULL / 0) */
+int amx_scale_unless_one_multi(float* x0, long n0, float* x1, long n1, float* x2, long n2, float* x3, long n3,
+                               const float* g, void* stream);
+/* px forward + loss + px backward of a training step (trainers/trainer.py:201-207: prob = net(x); loss =
+ * criterion(prob, y); loss.backward()) in ONE pass over the last activation: neither the logits nor their gradient are
+ * written.  K >= 2: CrossEntropyLoss against target int64 [N][H][W]; K == 1: BCEWithLogitsLoss against target_f float
+ * [N][1][H][W] (select_loss('ce', nb_classes), losses_metrics/losses.py:152-155).  Outputs as amx_px_bwd (dxn, part
+ * [rows][K][Cs], partb [rows][K], bstats [rows][2][Cs] or NULL) for an upstream gradient of 1, plus lpart [rows] =
+ * per-workgroup sums of the pixel losses (mean = sum / npix).  amx_px_ce_train_supported: 1 <= K <= 4 and Cs / 4 a power
+ * of two. */
+int amx_px_ce_train_supported(int Cs, int K);
+int amx_px_ce_train(const float* a, const float* scale, const float* shift, const float* w, const float* b,
+                    const long long* target, const float* target_f, float* dxn, float* part, float* partb, float* bstats,
+                    float* lpart, int N, int H, int W, int C, int Cs, int K, int rows, int rows_pix, void* stream);
 /* IoU of SegTrainer.accuracy_fn (trainers/trainer.py:727-737 -> losses_metrics/metrics.py:16-95): per-image K x K
  * confusion counts of (label, thresholded softmax / sigmoid class map) in one pass over the NCHW logits, replacing the
  * reference's host round trip (cv2.threshold per image + squeeze_channels + torch.bincount).  Exactly one of truth_i64

@@ -887,3 +887,45 @@ def check_split_two_source_dgrad(device, monkeypatch, hw=32, batch=2):
     assert calls[False].get("amx_conv2d_dgrad_fused", 0) == 0 and calls[False].get("amx_bn_bwd_apply", 0) == 1, calls
     for a, b, nm in zip(res[True], res[False], ("dx0", "dx1", "dW")):
         assert torch.equal(a, b), nm
+
+
+def check_fused_head_and_loss(device, models=(("Unet", 3, 4), ("Unet", 2, 8), ("SegResNet", 3, 4), ("ResHedNet", 3, 4), ("dilnet", 4, 8),
+                                              ("Unet", 1, 4), ("dilnet", 1, 8))):
+    """net.forward_loss (px -> CrossEntropyLoss -> their backward as one pass, engine.PxLossNode) against net(x) +
+    criterion + backward: the same loss and the same gradient of every parameter and of the input (fp32 rounding apart), with
+    an upstream gradient of 1 and of 0.37; nets whose last activation the fused kernel does not take fall back to logits."""
+    from atomai_amd.losses_metrics.losses import select_loss
+    from atomai_amd.nets import init_fcnn_model
+    rs = np.random.RandomState(7)
+    kinds = []
+    for model, ncls, nf in models:
+        crit = select_loss("ce", ncls if ncls != 2 else 3)      # (CrossEntropyLoss for >= 2 classes, BCEWithLogitsLoss for 1)
+        for gscale in (1.0, 0.37):
+            torch.manual_seed(5)
+            net, _ = init_fcnn_model(model, ncls, nb_filters=nf)
+            net.to(device).train()
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.momentum = 0.0                           # (two forwards over the same batch)
+            x = torch.from_numpy(rs.rand(3, 1, 24, 32).astype(np.float32)).to(device).requires_grad_(True)
+            if ncls == 1:
+                y = torch.from_numpy((rs.rand(3, 1, 24, 32) > 0.6).astype(np.float32)).to(device)
+            else:
+                y = torch.from_numpy(rs.randint(0, ncls, (3, 24, 32))).to(device)
+            loss0 = crit(net(x), y)
+            (loss0 * gscale).backward()
+            ref = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+            net.zero_grad()
+            x.grad = None
+            kind, out = net.forward_loss(x, y)
+            kinds.append(kind)
+            loss1 = out if kind == "loss" else crit(out, y)
+            (loss1 * gscale).backward()
+            got = [p.grad for p in net.parameters()] + [x.grad]
+            assert abs(float(loss0) - float(loss1)) < 2e-6 * max(1.0, abs(float(loss0))), (model, float(loss0), float(loss1))
+            gmax = max(float(g.abs().max()) for g in ref)
+            for (name, _), a, b in zip(list(net.named_parameters()) + [("input", None)], got, ref):
+                assert float((a - b).abs().max()) < 2e-5 * gmax, (model, ncls, name, float((a - b).abs().max()), gmax)
+    assert kinds.count("loss") >= 8, kinds                    # U-Net (16-channel-class heads), SegResNet, ... take the fused node
+    net.eval()
+    assert net.forward_loss(x, y)[0] == "logits"

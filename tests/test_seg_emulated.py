@@ -225,3 +225,7 @@ def test_lattice_xpack_is_bit_identical(monkeypatch):
 
 def test_two_source_data_gradient_as_two_wave_specialised_launches(monkeypatch):
     C.check_split_two_source_dgrad("cpu", monkeypatch)
+
+
+def test_head_and_loss_of_the_training_step_in_one_pass():
+    C.check_fused_head_and_loss("cpu")

@@ -532,3 +532,7 @@ def test_lattice_xpack_is_bit_identical(monkeypatch):
 def test_two_source_data_gradient_as_two_wave_specialised_launches(monkeypatch):
     # (the wave-specialised kernel takes a launch from two 16 x 16 tiles per CU on: 2 x 256^2 = 512 tiles on the MI355X)
     C.check_split_two_source_dgrad("cuda", monkeypatch, hw=256, batch=2)
+
+
+def test_head_and_loss_of_the_training_step_in_one_pass():
+    C.check_fused_head_and_loss("cuda")
