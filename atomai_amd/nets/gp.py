@@ -69,11 +69,18 @@ class convFeatureExtractor(nn.Module):
                     t.data = t.data.float()
         return self
 
+    def _build(self, tape, x):
+        """conv -> pool -> conv -> pool as ONE tape (NHWC throughout, pooling on the HIP kernels, the BatchNorm affine applied
+        by each consumer): no NCHW round trips and no library pooling between the blocks."""
+        node, c1 = self.c1._emit_input(tape, x, pool_next=True)
+        c2 = self.c2._emit(tape, [tape.pool(c1)])
+        return node, tape.output(tape.pool(c2))
+
     def forward(self, x):
         dt = x.dtype
         h = x.reshape(-1, 1, self.p, self.p).float()
-        h = F.max_pool2d(self.c1(h), 2, 2)
-        h = F.max_pool2d(self.c2(h), 2, 2)
+        from ._function import run_tape
+        h = run_tape(self._build, h, list(self.c1.parameters()) + list(self.c2.parameters()), self.training)
         from ._linear import linear
         return linear(h.flatten(1).to(self.fc.weight.dtype), self.fc.weight, self.fc.bias).to(dt)
 
