@@ -439,7 +439,8 @@ def host_enqueue_ms(model, nb, sync, n=3):
         t0 = time.perf_counter()
         model.net.train()
         model.optimizer.zero_grad()
-        loss = model.criterion(model.net(feat), tar)
+        kind, out = model.net.forward_loss(feat, tar)      # the fused head + loss node train_step takes (nets/fcnn.py)
+        loss = out if kind == "loss" else model.criterion(out, tar)
         loss.backward()
         if model.dp is not None:
             model.dp.allreduce_grads()
