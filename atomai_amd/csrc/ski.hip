@@ -42,7 +42,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ski_weights_kernel(const T* __restrict__ Z, const T* __restrict__ g0,
                                                           const T* __restrict__ inv_delta, int N, int D, int G,
                                                           int* __restrict__ base, T* __restrict__ w,
-                                                          T* __restrict__ dw) {
+                                                          T* __restrict__ dw, int* __restrict__ cell) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N * D) return;
     const int d = i % D;
@@ -50,6 +50,15 @@ __global__ __launch_bounds__(256) void ski_weights_kernel(const T* __restrict__ 
     int L = (int)ski_floor<T>(t);
     L = L < 1 ? 1 : (L > G - 3 ? G - 3 : L);
     base[i] = L - 1;
+    if (cell && d == 0) {                        // grid cell of the point = base[0] * (G - 3) + base[1] (the sort key of amx_ski_gram)
+        int c = L - 1;
+        if (D == 2) {
+            int L1 = (int)ski_floor<T>((Z[i + 1] - g0[1]) * inv_delta[1]);
+            L1 = L1 < 1 ? 1 : (L1 > G - 3 ? G - 3 : L1);
+            c = c * (G - 3) + L1 - 1;
+        }
+        cell[i / D] = c;
+    }
     #pragma unroll
     for (int k = 0; k < 4; ++k) {
         T wv, dv;
@@ -257,19 +266,19 @@ __global__ __launch_bounds__(256) void ski_cov_kernel(const int* __restrict__ ba
 // ================================================================== C ABI
 template <typename T>
 static int ski_weights_t(const void* Z, const void* g0, const void* inv_delta, int N, int D, int G, int* base, void* w,
-                         void* dw, hipStream_t st) {
+                         void* dw, int* cell, hipStream_t st) {
     AMX_LAUNCH((ski_weights_kernel<T>), dim3(amx_ceil_div(N * D, 256)), dim3(256), 0, st, (const T*)Z, (const T*)g0,
-               (const T*)inv_delta, N, D, G, base, (T*)w, (T*)dw);
+               (const T*)inv_delta, N, D, G, base, (T*)w, (T*)dw, cell);
     AMX_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int amx_ski_weights(const void* Z, const void* g0, const void* inv_delta, int N, int D, int G, int is_double,
-                               int* base, void* w, void* dw, void* stream) {
+                               int* base, void* w, void* dw, int* cell, void* stream) {
     if (!Z || !g0 || !inv_delta || !base || !w || !dw) AMX_BADARG(1);
     if (N <= 0 || (D != 1 && D != 2) || G < 4) AMX_BADARG(2);
     hipStream_t st = (hipStream_t)stream;
-    return is_double ? ski_weights_t<double>(Z, g0, inv_delta, N, D, G, base, w, dw, st)
-                     : ski_weights_t<float>(Z, g0, inv_delta, N, D, G, base, w, dw, st);
+    return is_double ? ski_weights_t<double>(Z, g0, inv_delta, N, D, G, base, w, dw, cell, st)
+                     : ski_weights_t<float>(Z, g0, inv_delta, N, D, G, base, w, dw, cell, st);
 }
 
 template <typename T, int DIM>

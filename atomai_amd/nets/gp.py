@@ -207,10 +207,14 @@ class SkiGrid:
     def tight_bounds(self):
         return [(lo + 2.01 * (hi - lo) / self.G, hi - 2.01 * (hi - lo) / self.G) for lo, hi in self.bounds]
 
-    def update(self, *Zs) -> bool:
-        """gpytorch's rule on the union of the given point sets; True when the grid was rebuilt."""
-        mins = torch.stack([Z.detach().min(0)[0] for Z in Zs]).min(0)[0].double().tolist()
-        maxs = torch.stack([Z.detach().max(0)[0] for Z in Zs]).max(0)[0].double().tolist()
+    def update(self, *Zs, minmax=None) -> bool:
+        """gpytorch's rule on the union of the given point sets (or on their per-dimension (mins, maxs) already on the
+        host); True when the grid was rebuilt."""
+        if minmax is not None:
+            mins, maxs = minmax
+        else:
+            mins = torch.stack([Z.detach().min(0)[0] for Z in Zs]).min(0)[0].double().tolist()
+            maxs = torch.stack([Z.detach().max(0)[0] for Z in Zs]).max(0)[0].double().tolist()
         if self.bounds is not None and not any(mn < lo or mx > hi for mn, mx, (lo, hi) in zip(mins, maxs, self.tight_bounds())):
             return False
         sp = [(mx - mn) / (self.G - 4.02) for mn, mx in zip(mins, maxs)]
@@ -243,37 +247,38 @@ class SkiGrid:
         return self._dev[key]
 
 
-def ski_weights(Z: torch.Tensor, grid: SkiGrid):
-    """(base [N][D] int32, w [N][D][4], dw [N][D][4]) of the points Z on the grid (amx_ski_weights)."""
+def ski_weights(Z: torch.Tensor, grid: SkiGrid, want_cell: bool = False):
+    """(base [N][D] int32, w [N][D][4], dw [N][D][4] [, cell [N] int32]) of the points Z on the grid (amx_ski_weights)."""
     Z = Z.detach().contiguous()
     N, D = Z.shape
     g0, inv_delta, _ = grid.tensors(Z.dtype, Z.device)
     base = torch.empty(N, D, dtype=torch.int32, device=Z.device)
     w = torch.empty(N, D, 4, dtype=Z.dtype, device=Z.device)
     dw = torch.empty_like(w)
+    cell = torch.empty(N, dtype=torch.int32, device=Z.device) if want_cell else None
     L.call("amx_ski_weights", L.ptr(Z), L.ptr(g0), L.ptr(inv_delta), N, D, grid.G, int(Z.dtype == torch.float64),
-           L.ptr(base), L.ptr(w), L.ptr(dw), L.stream_ptr(Z))
-    return base, w, dw
+           L.ptr(base), L.ptr(w), L.ptr(dw), L.ptr(cell), L.stream_ptr(Z))
+    return (base, w, dw, cell) if want_cell else (base, w, dw)
 
 
-def _ski_cells(base: torch.Tensor, G: int):
+def _ski_cells(base: torch.Tensor, G: int, cell: torch.Tensor = None):
     """Point indices sorted by grid cell and the first position of every cell (plumbing-size integer work in torch)."""
     D = base.shape[1]
     nc = G - 3
-    cell = base[:, 0].long() if D == 1 else base[:, 0].long() * nc + base[:, 1].long()
-    order = torch.sort(cell, stable=True)[1]
-    counts = torch.bincount(cell, minlength=nc ** D)
-    start = torch.zeros(nc ** D + 1, dtype=torch.int32, device=base.device)
-    start[1:] = counts.cumsum(0).to(torch.int32)
-    return order.to(torch.int32).contiguous(), start
+    if cell is None:
+        cell = base[:, 0] if D == 1 else base[:, 0] * nc + base[:, 1]                # int32
+    skey, order = torch.sort(cell, stable=True)
+    # first position of every cell in the sorted order (no histogram: torch.bincount synchronises with the host)
+    start = torch.searchsorted(skey, torch.arange(nc ** D + 1, dtype=torch.int32, device=base.device), out_int32=True)
+    return order.to(torch.int32).contiguous(), start.contiguous()
 
 
-def ski_gram(base, w, R, grid: SkiGrid, need_A: bool = True):
+def ski_gram(base, w, R, grid: SkiGrid, need_A: bool = True, cell=None):
     """A = W^T W [m][m] (or None) and b = W^T r [C][m] for R [C][N] (amx_ski_gram)."""
     N, D = base.shape
     G, m = grid.G, grid.m
     C = 0 if R is None else R.shape[0]
-    order, start = _ski_cells(base, G)
+    order, start = _ski_cells(base, G, cell)
     nws = ((G - 3) ** D) * ((4 ** D) ** 2 + C * 4 ** D)
     ws = torch.empty(nws, dtype=w.dtype, device=w.device)
     A = torch.zeros(m, m, dtype=w.dtype, device=w.device) if need_A else None      # (the kernel writes the band only)
@@ -311,7 +316,7 @@ class _SkiCoreLU:
     The LU of the 2500 x 2500 matrix of the default grid is 21 of the 22 ms of this core on the MI355X (rocSOLVER getrf
     through torch: profiles/r06_logs/r06_lu_probe.log) — the reason for _SkiCoreKron below."""
 
-    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid):
+    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid, host_ls=None):
         self.A, self.sig2 = A, sig2
         m = A.shape[0]
         with _phase("k_build"):
@@ -352,7 +357,7 @@ class _SkiCoreKron:
 
     EPS = 1e-16
 
-    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid):
+    def __init__(self, U, lengthscale, s2, kind, A, b, sig2, grid, host_ls=None):
         assert kind == 0
         self.A, self.sig2 = A, sig2
         dt, dev = A.dtype, A.device
@@ -361,7 +366,7 @@ class _SkiCoreKron:
             # host side (numpy, fp64): two G x G eigenproblems and the choice of the kept pairs; the m x r factor itself is
             # formed on the device from the two G x r column selections
             import numpy as np
-            ls = lengthscale.detach().reshape(-1).double().tolist()
+            ls = host_ls if host_ls is not None else lengthscale.detach().reshape(-1).double().tolist()
             nd = grid.nodes_1d()
             Vs, lams = [], []
             for d in range(D):
@@ -406,8 +411,8 @@ class _SkiCoreKron:
         return (self.A.shape[0] - self.r) / self.sig2 + torch.diagonal(self.Tinv).sum()
 
 
-def _ski_core(U, lengthscale, s2, kind, A, b, sig2, grid):
-    return (_SkiCoreKron if kind == 0 and SKI_KRON[0] else _SkiCoreLU)(U, lengthscale, s2, kind, A, b, sig2, grid)
+def _ski_core(U, lengthscale, s2, kind, A, b, sig2, grid, host_ls=None):
+    return (_SkiCoreKron if kind == 0 and SKI_KRON[0] else _SkiCoreLU)(U, lengthscale, s2, kind, A, b, sig2, grid, host_ls)
 
 
 SKI_KRON = [True]            # (tests compare the two cores)
@@ -424,19 +429,25 @@ class _SkiMLLFn(torch.autograd.Function):
     then amx_ski_gram_bwd (points) and amx_kernel_matrix_bwd on the grid (lengthscale, outputscale)."""
 
     @staticmethod
-    def forward(ctx, Z, Y, lengthscale, outputscale, noise, mean, kind, grid):
+    def forward(ctx, Z, Y, lengthscale, outputscale, noise, mean, kind, grid, host=None):
+        # host: (outputscale [q], noise [q], lengthscale [q][D]) as Python floats when the caller has fetched them already
+        # (GPRegressionModel.mll brings them over together with the embedding's range in ONE transfer)
         N, D = Z.shape
         q, m = Y.shape[0], grid.m
+        if host is None:
+            hv = torch.cat([outputscale.detach().reshape(-1), noise.detach().reshape(-1),
+                            lengthscale.detach().reshape(-1)]).double().tolist()
+            host = (hv[:q], hv[q:2 * q], [hv[2 * q + i * D:2 * q + (i + 1) * D] for i in range(q)])
         with _phase("ski_gram"):
-            base, w, dw = ski_weights(Z, grid)
+            base, w, dw, cell = ski_weights(Z, grid, want_cell=True)
             R = (Y.detach() - mean.detach().reshape(q, 1)).contiguous()
-            A, b = ski_gram(base, w, R, grid)
+            A, b = ski_gram(base, w, R, grid, cell=cell)
         _, _, U = grid.tensors(Z.dtype, Z.device)
         tot = 0
         per = []
         for i in range(q):
-            sig2, s2 = float(noise[i]), float(outputscale[i])
-            core = _ski_core(U, lengthscale[i], s2, kind, A, b[i], sig2, grid)
+            sig2, s2 = host[1][i], host[0][i]
+            core = _ski_core(U, lengthscale[i], s2, kind, A, b[i], sig2, grid, host[2][i])
             with _phase("grid_solve"):
                 x = core.x
                 quad = ((R[i] * R[i]).sum() - (b[i] * x).sum()) / sig2
@@ -481,7 +492,7 @@ class _SkiMLLFn(torch.autograd.Function):
                    int(dt == torch.float64), L.ptr(dZ), L.ptr(dr), L.stream_ptr(w))
             dr = dr + 2.0 * torch.tensor(g_rr, dtype=dt, device=dev).reshape(q, 1) * R
         return (g * dZ, g * dr, g * torch.stack(d_ls), g * torch.stack(d_s2), g * torch.stack(d_noise),
-                -g * dr.sum(1), None, None)
+                -g * dr.sum(1), None, None, None)
 
 
 class GPRegressionModel(nn.Module):
@@ -547,9 +558,17 @@ class GPRegressionModel(nn.Module):
             Z = self.embed(self.train_inputs[0])
         self._cache = None
         if self.gp == "kissgp":
-            self.grid.update(Z)
-            return _SkiMLLFn.apply(Z, self.train_targets, self.lengthscale, self.outputscale, self.noise[:, 0],
-                                   self.mean_constant[:, 0], self.kind, self.grid)
+            # everything the host needs of this step in ONE device -> host transfer: the embedding's range (gpytorch's grid
+            # rule) and the kernel hyper-parameters (the Kronecker core's eigenproblems run on the host)
+            q, D = self.train_targets.shape[0], Z.shape[1]
+            ls, s2, nz = self.lengthscale, self.outputscale, self.noise[:, 0]
+            Zd = Z.detach()
+            hv = torch.cat([Zd.min(0)[0].double(), Zd.max(0)[0].double(), s2.detach().reshape(-1).double(),
+                            nz.detach().reshape(-1).double(), ls.detach().reshape(-1).double()]).tolist()
+            self.grid.update(minmax=(hv[:D], hv[D:2 * D]))
+            o = 2 * D
+            host = (hv[o:o + q], hv[o + q:o + 2 * q], [hv[o + 2 * q + i * D:o + 2 * q + (i + 1) * D] for i in range(q)])
+            return _SkiMLLFn.apply(Z, self.train_targets, ls, s2, nz, self.mean_constant[:, 0], self.kind, self.grid, host)
         tot = 0
         for i in range(self.train_targets.shape[0]):
             tot = tot + _ExactMLLFn.apply(Z, self.train_targets[i], self.lengthscale[i], self.outputscale[i],

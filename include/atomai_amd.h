@@ -450,7 +450,7 @@ int amx_kernel_matrix_bwd_mll(const void* X, const void* inv_ls, double outputsc
  * in a fixed order over `order` (point indices sorted by cell = base[.][0] * (G - 3) + base[.][1]) and `cell_start`
  * [(G-3)^D + 1] (first position of each cell in `order`). */
 int amx_ski_weights(const void* Z, const void* g0, const void* inv_delta, int N, int D, int G, int is_double, int* base,
-                    void* w, void* dw, void* stream);
+                    void* w, void* dw, int* cell, void* stream);      /* cell [N] (or NULL): the point's grid cell, the sort key */
 /* elements (of the value type) of amx_ski_gram's workspace `ws`, or -1 */
 long amx_ski_gram_workspace(int D, int G, int C);
 /* A [m][m] = W^T W (or NULL; ZERO on entry: only the band |u_d - v_d| <= 3 is written) and b [C][m] = W^T r for r [C][N],
