@@ -156,6 +156,162 @@ extern "C" int amx_pool2x2_bwd(const float* g, const float* a, const float* scal
     return 0;
 }
 
+// ------------------------------------------------------------------ pool backward + the FIRST layer's weight gradient
+// U-Net / dilnet / SegResNet start with conv(1 -> F) -> LeakyReLU -> BatchNorm -> max-pool; the net input needs no
+// gradient, so the pooling backward's output dy (the complete gradient of that layer's output) has exactly ONE reader: the
+// first-layer weight-gradient kernel, which reads it back together with the activation at the very END of the backward pass,
+// where no other work is left to overlap it (pool_bwd 0.40 + conv1_wgrad 0.33 ms of a 16.7 ms U-Net step,
+// profiles/r06_step_timeline_final.txt).  The weight gradient is LINEAR in the three per-channel constants of the BatchNorm
+// backward, which are only known after this pass (they need the batch sums it produces):
+//     dW[c][t] = sum_p lrelu'(a) (k1 dy + k2 a + k3) x[p + t] = k1[c] S1[c][t] + k2[c] S2[c][t] + k3[c] S3[c][t],
+//     S1 = sum lrelu'(a) dy x_t,   S2 = sum lrelu'(a) a x_t,   S3 = sum lrelu'(a) x_t       (t = 9: x_t := 1, the bias row)
+// so this kernel forms dy in registers as pool_bwd_kernel does, adds up S1..S3 next to the BatchNorm-backward sums, and
+// never writes dy: one pass over (a, skip gradient, pooled gradient, x) instead of two passes and a 4 * Cs B/pixel tensor.
+// part3 [gridDim.x][3][10][4G]; bstats [gridDim.x][2][4G]; even H and W, dilation 1, G a power of two <= 16.
+__global__ __launch_bounds__(256) void pool_bwd_wgrad1_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ skip, const float* __restrict__ x,
+                                                              float slope, int N, int H, int W, int G,
+                                                              float* __restrict__ bstats, float* __restrict__ part3) {
+    float4 acc[32];                                   // 0, 1: sum dy, sum dy * a;  2 + 10 j + t: S_{j+1}[t]
+    #pragma unroll
+    for (int r = 0; r < 32; ++r) acc[r] = make_float4(0, 0, 0, 0);
+    const int Ho = H >> 1, Wo = W >> 1;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % G);
+        size_t r = i / G;
+        const int xo = (int)(r % Wo); r /= Wo;
+        const int yo = (int)(r % Ho); const int n = (int)(r / Ho);
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (scale) { sc = amx_ld4(scale + cg * 4); sh = amx_ld4(shift + cg * 4); }
+        float4 raw[4], v[4], sk[4];
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t o = (((size_t)n * H + 2 * yo + (k >> 1)) * W + 2 * xo + (k & 1)) * G * 4 + cg * 4;
+            raw[k] = amx_ld4(a + o);
+            sk[k] = skip ? amx_ld4(skip + o) : make_float4(0, 0, 0, 0);
+        }
+        const float4 gg = amx_ld4(g + (((size_t)n * Ho + yo) * Wo + xo) * G * 4 + cg * 4);
+        float xp[4][4];                               // input patch rows 2yo-1 .. 2yo+2, columns 2xo-1 .. 2xo+2 (zero padding)
+        #pragma unroll
+        for (int py = 0; py < 4; ++py)
+            #pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int yy = 2 * yo - 1 + py, xx = 2 * xo - 1 + px;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                xp[py][px] = in ? x[((size_t)n * H + yy) * W + xx] : 0.f;
+            }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 t = raw[k];
+            t.x = fmaf(t.x, sc.x, sh.x); t.y = fmaf(t.y, sc.y, sh.y);
+            t.z = fmaf(t.z, sc.z, sh.z); t.w = fmaf(t.w, sc.w, sh.w);
+            v[k] = t;
+        }
+        int ax = 0, ay = 0, az = 0, aw = 0;           // first maximum in scan order (torch semantics), as pool_bwd_kernel
+        float4 best = v[0];
+        #pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (v[k].x > best.x) { best.x = v[k].x; ax = k; }
+            if (v[k].y > best.y) { best.y = v[k].y; ay = k; }
+            if (v[k].z > best.z) { best.z = v[k].z; az = k; }
+            if (v[k].w > best.w) { best.w = v[k].w; aw = k; }
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 dy = sk[k];
+            dy.x += ax == k ? gg.x : 0.f; dy.y += ay == k ? gg.y : 0.f;
+            dy.z += az == k ? gg.z : 0.f; dy.w += aw == k ? gg.w : 0.f;
+            const float4 rw = raw[k];
+            acc[0].x += dy.x; acc[0].y += dy.y; acc[0].z += dy.z; acc[0].w += dy.w;
+            acc[1].x = fmaf(dy.x, rw.x, acc[1].x); acc[1].y = fmaf(dy.y, rw.y, acc[1].y);
+            acc[1].z = fmaf(dy.z, rw.z, acc[1].z); acc[1].w = fmaf(dy.w, rw.w, acc[1].w);
+            float4 u[3];
+            u[2] = make_float4(rw.x > 0.f ? 1.f : slope, rw.y > 0.f ? 1.f : slope, rw.z > 0.f ? 1.f : slope, rw.w > 0.f ? 1.f : slope);
+            u[0] = make_float4(u[2].x * dy.x, u[2].y * dy.y, u[2].z * dy.z, u[2].w * dy.w);
+            u[1] = make_float4(u[2].x * rw.x, u[2].y * rw.y, u[2].z * rw.z, u[2].w * rw.w);
+            #pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float4& b = acc[2 + 10 * j + 9];
+                b.x += u[j].x; b.y += u[j].y; b.z += u[j].z; b.w += u[j].w;
+                #pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float xv = xp[(k >> 1) + t / 3][(k & 1) + t % 3];
+                    float4& s4 = acc[2 + 10 * j + t];
+                    s4.x = fmaf(xv, u[j].x, s4.x); s4.y = fmaf(xv, u[j].y, s4.y);
+                    s4.z = fmaf(xv, u[j].z, s4.z); s4.w = fmaf(xv, u[j].w, s4.w);
+                }
+            }
+        }
+    }
+    // the 64 / G lanes of a wave that share a channel group (a thread keeps its group: (gridDim.x * 256) % G == 0), then
+    // the four waves through LDS in wave order: fixed order, no atomics
+    __shared__ float4 red[4][32][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    #pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        float4 t = acc[r];
+        for (int o = G; o < 64; o <<= 1) {
+            t.x += __shfl_xor(t.x, o); t.y += __shfl_xor(t.y, o); t.z += __shfl_xor(t.z, o); t.w += __shfl_xor(t.w, o);
+        }
+        if (lane < G) red[wave][r][lane] = t;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * G; e += 256) {
+        const int r = e / G, cgq = e - r * G;
+        float4 t = red[0][r][cgq];
+        #pragma unroll
+        for (int w = 1; w < 4; ++w) { const float4 q = red[w][r][cgq]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+        if (r < 2) amx_st4(bstats + ((size_t)blockIdx.x * 2 + r) * (G * 4) + cgq * 4, t);
+        else amx_st4(part3 + ((size_t)blockIdx.x * 30 + (r - 2)) * (G * 4) + cgq * 4, t);
+    }
+}
+
+extern "C" int amx_pool2x2_bwd_wgrad1_supported(int H, int W, int Cs, int dil) {
+    const int G = Cs >> 2;
+    return (Cs > 0 && !(Cs & 3) && G <= 16 && (G & (G - 1)) == 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && dil == 1) ? 1 : 0;
+}
+
+// rows of bstats / part3 = amx_pool2x2_bwd_rows(N, H, W, Cs)
+extern "C" int amx_pool2x2_bwd_wgrad1(const float* g, const float* a, const float* scale, const float* shift,
+                                      const float* skip, const float* x, float slope, float* bstats, float* part3, int N,
+                                      int H, int W, int Cs, void* stream) {
+    if (!g || !a || !x || !bstats || !part3) AMX_BADARG(1);
+    if (!amx_pool2x2_bwd_wgrad1_supported(H, W, Cs, 1)) AMX_BADARG(2);
+    if ((scale == nullptr) != (shift == nullptr)) AMX_BADARG(3);
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (Cs / 4);
+    AMX_LAUNCH(pool_bwd_wgrad1_kernel, dim3(pool_bwd_blocks(total)), dim3(256), 0, (hipStream_t)stream, g, a, scale, shift,
+               skip, x, slope, N, H, W, Cs / 4, bstats, part3);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
+// out [10][Cs] = k1 S1 + k2 S2 + k3 S3 (fp64, rows in order) from (chunk-reduced) part3 rows [rows][3][10][Cs];
+// k1 == NULL (no BatchNorm): out = S1.  The row layout of amx_conv1_wgrad_fused's column sums: taps 0..8, then the bias row.
+__global__ __launch_bounds__(256) void conv1_wgrad_combine_kernel(const float* __restrict__ part3, int rows, int Cs,
+                                                                  const float* __restrict__ k1, const float* __restrict__ k2,
+                                                                  const float* __restrict__ k3, float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 10 * Cs) return;
+    const int c = e % Cs;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int r = 0; r < rows; ++r)
+        #pragma unroll
+        for (int j = 0; j < 3; ++j) s[j] += (double)part3[((size_t)r * 3 + j) * 10 * Cs + e];
+    out[e] = k1 ? (float)((double)k1[c] * s[0] + (double)k2[c] * s[1] + (double)k3[c] * s[2]) : (float)s[0];
+}
+
+extern "C" int amx_conv1_wgrad_combine(const float* part3, int rows, int Cs, const float* k1, const float* k2,
+                                       const float* k3, float* out, void* stream) {
+    if (!part3 || !out || rows <= 0 || Cs <= 0 || (Cs & 3)) AMX_BADARG(1);
+    if ((k1 == nullptr) != (k2 == nullptr) || (k1 == nullptr) != (k3 == nullptr)) AMX_BADARG(2);
+    AMX_LAUNCH(conv1_wgrad_combine_kernel, dim3(amx_ceil_div(10 * Cs, 256)), dim3(256), 0, (hipStream_t)stream, part3, rows, Cs,
+               k1, k2, k3, out);
+    AMX_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------ upsample x2
 // bilinear, align_corners=False, scale 2:  out(2i)   = .25*in(i-1) + .75*in(i)
 //                                          out(2i+1) = .75*in(i)   + .25*in(i+1)   (indices clamped)

@@ -38,6 +38,8 @@ FUSE = int(_os.environ.get("AMX_FUSE", "2")) & 6
 FIRST_WGRAD_MAIN = _os.environ.get("AMX_FIRST_WGRAD_MAIN", "1") != "0"
 # data gradient of a two-source layer as one wave-specialised launch per source where the kernel takes them singly (host-side)
 DGRAD_SPLIT = _os.environ.get("AMX_DGRAD_SPLIT", "1") != "0"
+# pooling backward fused with the first layer's weight gradient (amx_pool2x2_bwd_wgrad1): dy of that layer never reaches HBM
+FUSE_POOL_WGRAD1 = _os.environ.get("AMX_FUSE_POOL_WGRAD1", "1") != "0"
 
 
 def bwd_fuse_enabled() -> bool:
@@ -70,7 +72,7 @@ class Act:
     """An activation as it lives in HBM: NHWC fp32 [N,H,W,Cs] (Cs = C padded to 4) + the pending
     per-channel affine of the producing BatchNorm (None == identity)."""
     __slots__ = ("t", "N", "H", "W", "C", "Cs", "scale", "shift", "grad", "gx", "needs_grad", "producer",
-                 "first_consumer", "bstats", "post_slope", "unmasked", "pooled")
+                 "first_consumer", "bstats", "post_slope", "unmasked", "pooled", "wg1", "wg1_parts")
 
     def __init__(self, t, C, scale=None, shift=None, needs_grad=False):
         self.t = t
@@ -83,6 +85,9 @@ class Act:
         self.gx: Optional[torch.Tensor] = None        # DilatedBlock's shared extra gradient
         self.unmasked: Optional[torch.Tensor] = None  # DilatedBlock + training Dropout: lrelu(conv) BEFORE the mask
         self.pooled: Optional["Act"] = None           # eval mode: max_pool2d of this (normalised) activation, already computed
+        self.wg1 = None                               # output of the net's FIRST layer (training): (net input [N,1,H,W], slope)
+                                                      # -> the pooling backward may form that layer's weight-gradient sums
+        self.wg1_parts = None                         # ... and leaves them here: (part3 [rows][3][10][Cs], rows)
         self.needs_grad = needs_grad
         # No object references from an activation back to graph nodes: node <-> activation cycles would keep
         # gigabytes of device memory alive until the cyclic garbage collector happens to run (erratic step times).
@@ -298,6 +303,12 @@ class ConvNode(_Node):
         self.out = self._forward(tape)
         self.out.post_slope = self.post_slope
         self.out.producer = self.bn is not None and self.post_slope == 1.0
+        # the net's first layer in training (1 input channel, 3x3, BatchNorm, no dropout mask): its consumer's pooling
+        # backward may fuse this layer's weight gradient (PoolNode.backward, amx_pool2x2_bwd_wgrad1)
+        if (FUSE_POOL_WGRAD1 and self.x_plain is not None and self.bn is not None and tape.training and tape.need_grad
+                and self.mask is None and self.post_slope == 1.0 and self.taps == 9 and self.x_plain.shape[1] == 1
+                and bwd_fuse_enabled() and bool(FUSE & 2) and not (FUSE & 4)):      # (FUSE & 4: the experiment mode that
+            self.out.wg1 = (self.x_plain, float(self.slope))                            #  materialises dpre from the real dy)
 
     # -------------------------------------------------------------------------------- forward
     def _forward(self, tape) -> Act:
@@ -579,10 +590,23 @@ class ConvNode(_Node):
             x = self.x_plain
             N, _, H, W = x.shape
             if aux is not None:
-                part = _empty((self.rows, 10, cos), a)
-                L.call("amx_conv1_wgrad_fused", L.ptr(x), L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
-                       self.slope, L.ptr(part), N, H, W, cos, self.dil, self.rows, self.rows_pix, sp)
-                tot = colsum(part, self.rows, 10 * cos)
+                if self.out.wg1_parts is not None:
+                    # the pooling backward already formed the three sums the gradient is linear in (PoolNode.backward)
+                    part3, prows = self.out.wg1_parts
+                    self.out.wg1_parts = None
+                    ncols = 30 * cos
+                    if prows > 16:                       # (the combine kernel walks the rows serially: few, fat chunks)
+                        nch = 16
+                        tmp = _empty((nch, ncols), a)
+                        L.call("amx_reduce_rows_chunked", L.ptr(part3), prows, ncols, nch, L.ptr(tmp), sp)
+                        part3, prows = tmp, -(-prows // -(-prows // nch))
+                    tot = _empty((10 * cos,), a)
+                    L.call("amx_conv1_wgrad_combine", L.ptr(part3), prows, cos, L.ptr(k1), L.ptr(k2), L.ptr(k3), L.ptr(tot), sp)
+                else:
+                    part = _empty((self.rows, 10, cos), a)
+                    L.call("amx_conv1_wgrad_fused", L.ptr(x), L.ptr(dpre), L.ptr(aux), L.ptr(k1), L.ptr(k2), L.ptr(k3),
+                           self.slope, L.ptr(part), N, H, W, cos, self.dil, self.rows, self.rows_pix, sp)
+                    tot = colsum(part, self.rows, 10 * cos)
                 L.call("amx_wgrad_reduce", L.ptr(tot), 1, 9, 1, cos, 1, 1, 0, self.cout, L.ptr(dw), sp)
                 if want_bias:
                     db = grad_buffer(self.conv.bias, a)
@@ -808,6 +832,20 @@ class PoolNode(_Node):
         if g is None or not s.needs_grad:
             return
         skip = s.grad
+        if (s.wg1 is not None and s.gx is None and s.wants_bstats(self, tape.training)
+                and L.load().amx_pool2x2_bwd_wgrad1_supported(s.H, s.W, s.Cs, 1)):
+            # first layer of the net: its weight-gradient sums come out of this pass, dy itself is not written (see the kernel)
+            x_plain, slope = s.wg1
+            rows = L.load().amx_pool2x2_bwd_rows(s.N, s.H, s.W, s.Cs)
+            bstats = _empty((rows, 2, s.Cs), g)
+            part3 = _empty((rows, 3, 10, s.Cs), g)
+            L.call("amx_pool2x2_bwd_wgrad1", L.ptr(g), L.ptr(s.t), L.ptr(s.scale), L.ptr(s.shift), L.ptr(skip),
+                   L.ptr(x_plain), slope, L.ptr(bstats), L.ptr(part3), s.N, s.H, s.W, s.Cs, _sp(g))
+            s.bstats = (bstats, rows, s.Cs, 0)
+            s.wg1_parts = (part3, rows)
+            if s.grad is None:
+                s.grad = g                                # (any tensor: the producer's backward only asks "is there a gradient")
+            return
         if s.grad is None:
             s.grad = _empty(s.t.shape, s.t)
             skip = s.gx

@@ -241,6 +241,18 @@ int amx_pool2x2_fwd(const float* a, const float* scale, const float* shift, floa
                     int Cs, void* stream);
 int amx_pool2x2_bwd(const float* g, const float* a, const float* scale, const float* shift,
                     const float* skip, float* dy, float* bstats, int N, int H, int W, int Cs, void* stream);
+/* amx_pool2x2_bwd for the output of the net's FIRST layer (conv(1 -> F) 3x3 -> LeakyReLU -> BatchNorm -> max-pool,
+ * atomai/nets/fcnn.py:83-84,121-122; the input needs no gradient) fused with that layer's weight gradient: dy is formed in
+ * registers and never written; besides bstats it emits part3 [rows][3][10][Cs], the three sums the first-layer weight /
+ * bias gradient is linear in (dW = k1 S1 + k2 S2 + k3 S3 with the constants amx_bn_bwd_finalize derives from bstats).
+ * x: the net input [N][H][W]; rows = amx_pool2x2_bwd_rows.  amx_conv1_wgrad_combine: [rows][3][10][Cs] (after an optional
+ * amx_reduce_rows_chunked) -> [10][Cs] in the row layout of amx_conv1_wgrad_fused's column sums (k1 == NULL: S1 alone). */
+int amx_pool2x2_bwd_wgrad1_supported(int H, int W, int Cs, int dil);
+int amx_pool2x2_bwd_wgrad1(const float* g, const float* a, const float* scale, const float* shift, const float* skip,
+                           const float* x, float slope, float* bstats, float* part3, int N, int H, int W, int Cs,
+                           void* stream);
+int amx_conv1_wgrad_combine(const float* part3, int rows, int Cs, const float* k1, const float* k2, const float* k3,
+                            float* out, void* stream);
 int amx_pool2x2_bwd_rows(int N, int H, int W, int Cs);
 int amx_upsample2x_fwd(const float* v, float* u, int N, int h, int w, int Cs, int mode, void* stream);
 /* UpsampleBlock forward in ONE pass (atomai/nets/blocks.py:122-132; round 5): y[N][2h][2w][Cs_out] = x2 interpolation

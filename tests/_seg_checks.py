@@ -653,12 +653,18 @@ def check_bwd_fused_in_loaders(device, cin, cout, monkeypatch, hw=32, batch=2, u
         assert float((a - b).abs().max()) <= tol, ("sums in the data-gradient epilogue", k, float((a - b).abs().max()), tol)
     # (+ the net's first layer, whose BatchNorm backward is formed by amx_conv1_wgrad_fused: it has no data gradient)
     per_run = repeats if res else 1
+    # (... or, in front of a pooling layer, by amx_pool2x2_bwd_wgrad1 + amx_conv1_wgrad_combine, which sum the three terms of
+    #  that layer's weight gradient separately: equal to rounding, not bit for bit)
+    pooled_first = calls["1"].get("amx_pool2x2_bwd_wgrad1", 0)
     assert (calls["0"]["amx_bn_bwd_apply"] - calls["1"].get("amx_bn_bwd_apply", 0)
-            == nf + calls["1"].get("amx_conv1_wgrad_fused", 0)), calls
+            == nf + calls["1"].get("amx_conv1_wgrad_fused", 0) + pooled_first), calls
     nf //= per_run
+    first_w = next(iter(out["0"])) if pooled_first else None
     for k in out["0"]:
         a, b = out["1"][k], out["0"][k]
-        if k == "x" or (k.endswith("weight") and a.ndim == 4):
+        if k == first_w:
+            assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(b.abs().max())), (k, float((a - b).abs().max()))
+        elif k == "x" or (k.endswith("weight") and a.ndim == 4):
             assert torch.equal(a, b), k
         else:
             # (a conv bias in front of a BatchNorm has a mathematically ZERO gradient: what both forms produce is the
@@ -929,3 +935,44 @@ def check_fused_head_and_loss(device, models=(("Unet", 3, 4), ("Unet", 2, 8), ("
     assert kinds.count("loss") >= 8, kinds                    # U-Net (16-channel-class heads), SegResNet, ... take the fused node
     net.eval()
     assert net.forward_loss(x, y)[0] == "logits"
+
+
+def check_pool_backward_with_first_layer_wgrad(device, models=(("Unet", 3, 4), ("Unet", 1, 16), ("dilnet", 1, 8), ("SegResNet", 3, 4))):
+    """amx_pool2x2_bwd_wgrad1 (pooling backward + the first layer's weight-gradient sums in one pass, dy never written)
+    against the two kernels it replaces: every parameter gradient of the net agrees to fp32 rounding, the first layer's
+    included, and the fused kernel is the one that ran."""
+    import atomai_amd.engine as eng
+    from atomai_amd import _lib as L
+    from atomai_amd.losses_metrics.losses import select_loss
+    from atomai_amd.nets import init_fcnn_model
+    rs = np.random.RandomState(11)
+    for model, ncls, nf in models:
+        crit = select_loss("ce", ncls if ncls != 2 else 3)
+        x = torch.from_numpy(rs.rand(3, 1, 24, 32).astype(np.float32)).to(device)
+        y = (torch.from_numpy((rs.rand(3, 1, 24, 32) > 0.6).astype(np.float32)) if ncls == 1
+             else torch.from_numpy(rs.randint(0, ncls, (3, 24, 32)))).to(device)
+        grads, calls = [], []
+        orig = L.call
+        for on in (False, True):
+            eng.FUSE_POOL_WGRAD1 = on
+            seen = []
+
+            def spy(name, *a, _seen=seen):
+                _seen.append(name)
+                return orig(name, *a)
+            L.call = eng.L.call = spy
+            try:
+                torch.manual_seed(5)
+                net, _ = init_fcnn_model(model, ncls, nb_filters=nf)
+                net.to(device).train()
+                crit(net(x), y).backward()
+            finally:
+                L.call = eng.L.call = orig
+                eng.FUSE_POOL_WGRAD1 = True
+            grads.append([p.grad.clone() for p in net.parameters()])
+            calls.append(seen)
+        assert "amx_pool2x2_bwd_wgrad1" in calls[1] and "amx_conv1_wgrad_fused" not in calls[1], model
+        assert "amx_pool2x2_bwd_wgrad1" not in calls[0] and "amx_conv1_wgrad_fused" in calls[0], model
+        gmax = max(float(g.abs().max()) for g in grads[0])
+        for (name, _), a, b in zip(net.named_parameters(), grads[1], grads[0]):
+            assert float((a - b).abs().max()) < 2e-5 * gmax, (model, name, float((a - b).abs().max()), gmax)

@@ -229,3 +229,7 @@ def test_two_source_data_gradient_as_two_wave_specialised_launches(monkeypatch):
 
 def test_head_and_loss_of_the_training_step_in_one_pass():
     C.check_fused_head_and_loss("cpu")
+
+
+def test_pool_backward_fused_with_the_first_layer_weight_gradient():
+    C.check_pool_backward_with_first_layer_wgrad("cpu")

@@ -32,6 +32,7 @@ def setenv(v):
     engine.FUSE_UPCONV = os.environ.get("AMX_FUSE_UPCONV", "1") != "0"
     engine.FIRST_WGRAD_MAIN = os.environ.get("AMX_FIRST_WGRAD_MAIN", "1") != "0"
     engine.DGRAD_SPLIT = os.environ.get("AMX_DGRAD_SPLIT", "1") != "0"
+    engine.FUSE_POOL_WGRAD1 = os.environ.get("AMX_FUSE_POOL_WGRAD1", "1") != "0"
     engine.FUSE_PX_LOSS = os.environ.get("AMX_FUSE_PX_LOSS", "1") != "0"
     from atomai_amd.trainers import trainer as _tr
     _tr.FUSE_LOSS = engine.FUSE_PX_LOSS
